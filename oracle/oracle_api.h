@@ -1,0 +1,75 @@
+/* oracle/oracle_api.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * One C interface, exported under the same names by two different CPU builds:
+ *
+ *   oracle/liboracle.so          the restatement (oracle/pwpp_oracle.cpp)
+ *   oracle/_ref/libpwpp_ref*.so  the reference's own patchworkpp.cpp, compiled
+ *                                unmodified from /root/reference against
+ *                                oracle/eigen_shim (oracle/ref_capi.cpp wraps it)
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * these libraries.  The product (libpwpp_hip.so) never does.
+ */
+#ifndef PWPP_ORACLE_API_H
+#define PWPP_ORACLE_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirror of patchwork::Params (reference patchworkpp.h:42-112), POD form. */
+typedef struct pwo_params {
+    int32_t verbose, enable_RNR, enable_RVPF, enable_TGR;
+    int32_t num_iter, num_lpr, num_min_pts, num_zones, num_rings_of_interest;
+    double RNR_ver_angle_thr, RNR_intensity_thr;
+    double sensor_height, th_seeds, th_dist, th_seeds_v, th_dist_v;
+    double max_range, min_range, uprightness_thr, adaptive_seed_selection_margin;
+    int32_t num_sectors_each_zone[4];
+    int32_t num_rings_each_zone[4];
+    int32_t max_flatness_storage, max_elevation_storage;
+    double elevation_thr[4];
+    double flatness_thr[4];
+} pwo_params;
+
+enum { PWO_ARITH_EIGEN_F32 = 0, PWO_ARITH_FXP = 1 };
+
+void pwo_default_params(pwo_params *p);                 /* patchworkpp.h:79-111 */
+int pwo_arith_supported(int arith);                     /* 1 if this build can do it */
+void *pwo_create(const pwo_params *p, int arith);       /* NULL on bad arith */
+void pwo_destroy(void *h);
+
+/* points: row-major n x cols float32 (cols = 3 or 4), as np.fromfile(..).reshape(-1,4) */
+int pwo_estimate_ground(void *h, const float *pts, int n, int cols);
+
+int pwo_num_ground(void *h);
+int pwo_num_nonground(void *h);
+int pwo_num_patches(void *h);
+void pwo_get_ground_indices(void *h, int32_t *out);     /* reference order */
+void pwo_get_nonground_indices(void *h, int32_t *out);
+void pwo_get_ground(void *h, float *out);               /* row-major (n,3) */
+void pwo_get_nonground(void *h, float *out);
+void pwo_get_centers(void *h, float *out);
+void pwo_get_normals(void *h, float *out);
+double pwo_get_height(void *h);
+double pwo_get_time_taken(void *h);
+
+/* adaptive state after the last frame (patchworkpp.cpp:338-375) */
+void pwo_get_thresholds(void *h, double *sensor_height, double *elevation_thr4, double *flatness_thr4);
+int pwo_get_history_len(void *h, int which /*0 elevation, 1 flatness*/, int ring);
+void pwo_get_history(void *h, int which, int ring, double *out);
+
+/* work counters since creation of the process: plane fits, Jacobi sweeps */
+void pwo_get_counters(long *plane_fits, long *jacobi_sweeps);
+
+/* CPU baseline: `total` frames (frame i = distinct[i % num_distinct]), each through a
+ * fresh-state object, spread over `threads` host threads.  Returns wall seconds of the
+ * parallel region; *sum_call_seconds gets the sum of the estimateGround() call times. */
+double pwo_bench(const pwo_params *p, int arith, const float *const *frames, const int *n_points,
+                 int cols, int num_distinct, int total, int threads, double *sum_call_seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
