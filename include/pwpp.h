@@ -1,0 +1,195 @@
+/* include/pwpp.h -- C-ABI of the MI355X-native Patchwork++ hot path (libpwpp_hip.so).
+ *
+ * This is the drop-in boundary for the reference's per-frame path
+ *     patchwork::PatchWorkpp::estimateGround()      /root/reference/cpp/patchworkpp/src/patchworkpp.cpp:151-336
+ * and its result getters                            /root/reference/cpp/patchworkpp/include/patchwork/patchworkpp.h:152-163
+ * Plain C: POD structs, raw pointers and sizes only; no C++ / torch / Eigen types cross it.
+ * The reference has no FFI of its own for this path (its Python module binds the C++ class
+ * directly, python/patchworkpp/pybinding.cpp:45-55); the C++ class and pybind11 module that
+ * sit on top of this header (patchwork-plusplus_amd/include/patchwork/patchworkpp.h,
+ * patchwork-plusplus_amd/python/pybinding.cpp) are what a maintainer would swap in --
+ * see INTEGRATION.md.
+ *
+ * Every entry point returns PWPP_OK (0) or a negative pwpp_status; pwpp_last_error() gives
+ * the text for the calling thread.  One handle = one device + one HIP stream; a handle is
+ * not re-entrant (like the reference object, patchworkpp.h:177-195), distinct handles are
+ * independent and may be driven from different threads.
+ */
+#ifndef PWPP_H
+#define PWPP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PWPP_VERSION_MAJOR 0
+#define PWPP_VERSION_MINOR 1
+
+typedef enum pwpp_status {
+    PWPP_OK = 0,
+    PWPP_E_ARG = -1,         /* bad argument / parameter combination              */
+    PWPP_E_HIP = -2,         /* a HIP runtime call failed                          */
+    PWPP_E_NOMEM = -3,       /* device or host allocation failed                   */
+    PWPP_E_STATE = -4,       /* call sequence error (e.g. getter before any frame) */
+    PWPP_E_UNSUPPORTED = -5, /* legal for the reference, not implemented here      */
+    PWPP_E_NODEVICE = -6     /* no usable GPU: the product path never falls back to CPU */
+} pwpp_status;
+
+/* Mirror of patchwork::Params, field for field (reference patchworkpp.h:42-112).
+ * bools are int32 (0/1); the four std::vector members are fixed arrays of 4 because the
+ * reference hard-codes four zones (patchworkpp.h:122-134, patchworkpp.cpp:580-615). */
+typedef struct pwpp_params {
+    int32_t verbose;      /* patchworkpp.h:44 */
+    int32_t enable_RNR;   /* :45 */
+    int32_t enable_RVPF;  /* :46 */
+    int32_t enable_TGR;   /* :47 */
+    int32_t num_iter;     /* :49 */
+    int32_t num_lpr;      /* :50 */
+    int32_t num_min_pts;  /* :51 */
+    int32_t num_zones;    /* :52  (must be 4, see above) */
+    int32_t num_rings_of_interest; /* :53 (<= 4: the reference keeps update_*_[4], patchworkpp.h:174-175) */
+    int32_t pad0_;
+    double RNR_ver_angle_thr; /* :55 */
+    double RNR_intensity_thr; /* :56 */
+    double sensor_height;     /* :58 */
+    double th_seeds;          /* :59 */
+    double th_dist;           /* :60 */
+    double th_seeds_v;        /* :61 */
+    double th_dist_v;         /* :62 */
+    double max_range;         /* :63 */
+    double min_range;         /* :64 */
+    double uprightness_thr;   /* :65 */
+    double adaptive_seed_selection_margin; /* :66 */
+    double intensity_thr;     /* :67 (never read by the hot path; kept for API parity) */
+    int32_t num_sectors_each_zone[4]; /* :69 */
+    int32_t num_rings_each_zone[4];   /* :70 */
+    int32_t max_flatness_storage;     /* :72 */
+    int32_t max_elevation_storage;    /* :73 */
+    double elevation_thr[4];          /* :75 */
+    double flatness_thr[4];           /* :76 */
+} pwpp_params;
+
+/* Adaptive per-stream state the reference keeps inside the object and mutates every frame
+ * (params_.sensor_height / elevation_thr / flatness_thr, patchworkpp.cpp:347-350,368). */
+typedef struct pwpp_state {
+    double sensor_height;
+    double elevation_thr[4];
+    double flatness_thr[4];
+    int32_t elevation_len[4]; /* entries in update_elevation_[i] */
+    int32_t flatness_len[4];  /* entries in update_flatness_[i]  */
+} pwpp_state;
+
+/* One processed patch (CZM bin with >= num_min_pts points), in bin traversal order. */
+typedef struct pwpp_patch_record {
+    int32_t bin;            /* flattened zone->ring->sector index (patchworkpp.cpp:184-189) */
+    int32_t concentric_idx; /* patchworkpp.cpp:174,309 */
+    int32_t n_points;
+    int32_t n_ground;       /* |regionwise_ground_|     (patchworkpp.cpp:529-531) */
+    int32_t n_nonground;    /* |regionwise_nonground_|  (patchworkpp.cpp:500,532) */
+    int32_t decision;       /* pwpp_decision */
+    float mean[3];          /* pc_mean_            (patchworkpp.cpp:59-60) */
+    float normal[3];        /* normal_             (patchworkpp.cpp:66-68) */
+    float sv[3];            /* singular_values_    (patchworkpp.cpp:63)    */
+    float pad_;
+    double d;               /* d_                  (patchworkpp.cpp:74)    */
+} pwpp_patch_record;
+
+typedef enum pwpp_decision {
+    PWPP_DEC_NOT_UPRIGHT = 1, /* patchworkpp.cpp:262-265 */
+    PWPP_DEC_FAR_GROUND = 2,  /* :266-269 */
+    PWPP_DEC_HEADING = 3,     /* :270-273 */
+    PWPP_DEC_GROUND = 4,      /* :274-277 */
+    PWPP_DEC_TGR_REJECT = 5,  /* :278-282 then :452-459 / :296-300 */
+    PWPP_DEC_TGR_REVERT = 6   /* :444-451 */
+} pwpp_decision;
+
+enum { PWPP_LAYOUT_ROW_MAJOR = 0, /* (n, cols) C-order: np.fromfile(..).reshape(-1,4), python/examples/demo_visualize.py:10-14 */
+       PWPP_LAYOUT_COL_MAJOR = 1  /* Eigen::MatrixXf default storage: cols planes of n floats (patchworkpp.h:152) */ };
+enum { PWPP_MEM_HOST = 0, PWPP_MEM_DEVICE = 1 };
+enum { PWPP_MODE_FRESH = 0,   /* every frame starts from the handle's Params (= a fresh PatchWorkpp object per frame) */
+       PWPP_MODE_STREAMS = 1  /* frame i belongs to stream i and reads+updates that stream's adaptive state
+                                 (= one long-lived PatchWorkpp object per stream, demo_sequential.cpp:54-67) */ };
+
+typedef struct pwpp_handle pwpp_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* Params() defaults, reference patchworkpp.h:79-111 */
+int pwpp_params_default(pwpp_params *p);
+/* PatchWorkpp::PatchWorkpp(Params), reference patchworkpp.h:120-150: validates, computes the
+ * CZM geometry in double exactly as the reference constructor, creates stream + workspace. */
+int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out);
+int pwpp_destroy(pwpp_handle *h);
+const char *pwpp_last_error(void);
+int pwpp_device_count(void);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+/* void PatchWorkpp::estimateGround(Eigen::MatrixXf cloud_in), reference patchworkpp.cpp:151.
+ * One frame, host memory, stream 0 of the handle, stateful like the reference object.
+ * cols is 3 or 4 (3 only legal with enable_RNR == 0 semantics of patchworkpp.cpp:379-382:
+ * RNR is skipped).  Synchronous: results are ready on return. */
+int pwpp_estimate_ground(pwpp_handle *h, const float *points, int n, int cols, int layout);
+
+/* Many independent frames in one set of launches.  points[i] is frame i (host or device
+ * memory according to `mem`), n[i] its point count.  PWPP_MODE_FRESH: each frame is
+ * processed with fresh state.  PWPP_MODE_STREAMS: frames <= streams configured with
+ * pwpp_set_num_streams(); frame i continues stream i.  Asynchronous when mem is
+ * PWPP_MEM_DEVICE: call pwpp_synchronize() before reading results. */
+int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const int32_t *n, int frames,
+                               int cols, int layout, int mem, int mode);
+int pwpp_synchronize(pwpp_handle *h);
+int pwpp_set_num_streams(pwpp_handle *h, int streams); /* (re)creates `streams` fresh stream states */
+
+/* ---- results of the last call ---------------------------------------------------------- */
+/* sizes of getGround()/getNonground()/getCenters(), reference patchworkpp.h:157-163 */
+int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32_t *n_nonground, int32_t *n_patches);
+/* getGroundIndices()/getNongroundIndices(), reference patchworkpp.h:159-160, patchworkpp.cpp:18-26.
+ * Same index SETS as the reference; order inside a list is not the reference's. */
+int pwpp_get_ground_indices(pwpp_handle *h, int frame, int32_t *out);
+int pwpp_get_nonground_indices(pwpp_handle *h, int frame, int32_t *out);
+/* getGround()/getNonground(), reference patchworkpp.h:157-158: row-major (count,3) float32,
+ * rows aligned with the index getters above. */
+int pwpp_get_ground_xyz(pwpp_handle *h, int frame, float *out);
+int pwpp_get_nonground_xyz(pwpp_handle *h, int frame, float *out);
+/* getCenters()/getNormals(), reference patchworkpp.h:162-163: row-major (n_patches,3), bin traversal order */
+int pwpp_get_centers(pwpp_handle *h, int frame, float *out);
+int pwpp_get_normals(pwpp_handle *h, int frame, float *out);
+/* per-patch detail for parity checks (no reference getter; fields are the reference's scratch members) */
+int pwpp_get_patch_records(pwpp_handle *h, int frame, pwpp_patch_record *out, int capacity);
+/* getHeight(), reference patchworkpp.h:154 (stream 0) */
+double pwpp_get_height(pwpp_handle *h);
+/* getTimeTaken(), reference patchworkpp.h:155: microseconds of the last estimate call
+ * (GPU time between HIP events on the handle's stream, batch calls: whole batch) */
+double pwpp_get_time_us(pwpp_handle *h);
+
+/* ---- adaptive state --------------------------------------------------------------------- */
+/* state after the last call; PWPP_MODE_FRESH: `index` is the frame, PWPP_MODE_STREAMS: the stream */
+int pwpp_get_state(pwpp_handle *h, int index, pwpp_state *out);
+int pwpp_get_history(pwpp_handle *h, int index, int which /*0 elevation, 1 flatness*/, int ring, double *out, int capacity);
+/* overwrite the scalars of a stream state (histories are cleared) */
+int pwpp_set_state(pwpp_handle *h, int stream, const pwpp_state *in);
+
+/* ---- device-side views and measurement --------------------------------------------------- */
+typedef struct pwpp_device_view {
+    const int32_t *indices;      /* all frames: [frame_base[f] .. +n_ground) ground, then nonground */
+    const int64_t *frame_base;   /* frames+1 prefix sums of n (host pointer, pinned)                */
+    const int32_t *counts;       /* frames x 8 int32 (host pointer, pinned): n_ground, n_nonground, n_patches, n_rnr, n_out_of_range, n_dropped, 0, 0 */
+    int32_t frames;
+    int32_t pad_;
+} pwpp_device_view;
+int pwpp_get_device_view(pwpp_handle *h, pwpp_device_view *out);
+
+/* per-kernel GPU time (HIP events on the handle's stream around every launch) */
+#define PWPP_NUM_KERNELS 6
+int pwpp_set_profiling(pwpp_handle *h, int enable);
+int pwpp_get_kernel_profile(pwpp_handle *h, double *sum_ms /*[PWPP_NUM_KERNELS]*/, int64_t *launches /*[PWPP_NUM_KERNELS]*/);
+int pwpp_reset_kernel_profile(pwpp_handle *h);
+const char *pwpp_kernel_name(int k);
+/* fixed-point shift s of the plane-fit arithmetic contract for this handle */
+int pwpp_get_fxp_shift(pwpp_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PWPP_H */

@@ -1,0 +1,728 @@
+// pwpp_capi.cpp -- host side of libpwpp_hip.so: the C-ABI of include/pwpp.h.
+//
+// Owns the device workspace, the per-stream adaptive state and the HIP stream of a handle,
+// validates parameters exactly where the reference constructor would read them
+// (/root/reference/cpp/patchworkpp/include/patchwork/patchworkpp.h:120-150) and drives the six
+// kernels of pwpp_kernels.hip.  There is no CPU fallback: without a GPU every compute entry
+// point fails with PWPP_E_NODEVICE / PWPP_E_HIP.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/pwpp.h"
+#include "pwpp_dev.h"
+
+extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev);
+extern "C" int pwpp_launch_gather_xyz(const PwppFrameDesc *fd, const int *idx, int count, float *out, hipStream_t stream);
+
+static_assert(sizeof(pwpp_state) == sizeof(PwppStateScalar), "pwpp_state must mirror PwppStateScalar");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(PWPP_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;  // elements
+    int ensure(size_t n) {
+        if (n <= cap) return PWPP_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) return fail(PWPP_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
+        cap = want;
+        return PWPP_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+template <class T>
+struct PinnedBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return PWPP_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 8 + 64;
+        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) return fail(PWPP_E_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
+        cap = want;
+        return PWPP_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+const char *kKernelNames[PWPP_NUM_KERNELS] = {"k_czm_bin", "k_czm_scan", "k_czm_scatter",
+                                              "k_patch_fit", "k_gle_tgr", "k_emit"};
+
+}  // namespace
+
+struct pwpp_handle {
+    pwpp_params params;
+    PwppDevParams dp;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipEvent_t ev_k[PWPP_NUM_KERNELS + 1] = {};
+    bool profiling = false;
+    bool profile_pending = false;
+    double prof_ms[PWPP_NUM_KERNELS] = {};
+    int64_t prof_launches[PWPP_NUM_KERNELS] = {};
+
+    // last call
+    int frames = 0;
+    int mode = PWPP_MODE_FRESH;
+    bool have_results = false;
+    bool pending = false;  // launches in flight, results not yet fetched
+    double time_us = 0.0;
+    std::vector<PwppFrameDesc> descs;  // host copy of the last batch (device pointers inside)
+
+    // workspace
+    DevBuf<PwppFrameDesc> d_frames;
+    PinnedBuf<PwppFrameDesc> h_frames;
+    PinnedBuf<int64_t> h_base;
+    DevBuf<float> d_in;  // staging for host inputs
+    DevBuf<uint16_t> d_codes;
+    DevBuf<float4> d_sorted;
+    DevBuf<int32_t> d_plist;
+    DevBuf<int32_t> d_out;
+    DevBuf<uint32_t> d_bins;  // 5 slabs of frames*(B+2): count, off, cursor, dst_a, dst_b
+    DevBuf<PwppPatchRec> d_recs;
+    DevBuf<float> d_centers, d_normals;
+    DevBuf<PwppFrameResult> d_results;
+    PinnedBuf<PwppFrameResult> h_results;
+    DevBuf<float> d_xyz;  // gather scratch
+
+    // adaptive state: streams (long history slabs) and per-frame fresh outputs (short slabs)
+    int num_streams = 0;
+    int stream_hist_cap = 0, fresh_hist_cap = 0;
+    DevBuf<PwppStateScalar> d_st_stream, d_st_fresh;
+    DevBuf<double> d_hist_stream, d_hist_fresh;
+};
+
+namespace {
+
+int fxp_shift_for(double max_range) {
+    int s = 20;
+    while (s > 0 && max_range * (double)(1 << s) > 8388607.0) --s;
+    return s;
+}
+
+int build_dev_params(const pwpp_params &p, PwppDevParams &d) {
+    if (p.num_zones != 4)
+        return fail(PWPP_E_UNSUPPORTED, "num_zones=%d: the reference hard-codes four zones (patchworkpp.h:122-134)", p.num_zones);
+    if (p.num_iter < 1) return fail(PWPP_E_UNSUPPORTED, "num_iter=%d: must be >= 1", p.num_iter);
+    if (p.num_lpr > PWPP_MAX_LPR) return fail(PWPP_E_UNSUPPORTED, "num_lpr=%d: at most %d supported", p.num_lpr, PWPP_MAX_LPR);
+    if (p.num_rings_of_interest < 0 || p.num_rings_of_interest > PWPP_MAX_ROI)
+        return fail(PWPP_E_ARG, "num_rings_of_interest=%d: the reference keeps update_*_[4] (patchworkpp.h:174-175)", p.num_rings_of_interest);
+    if (!(p.max_range > p.min_range)) return fail(PWPP_E_ARG, "max_range must exceed min_range");
+    if (p.max_flatness_storage < 0 || p.max_elevation_storage < 0) return fail(PWPP_E_ARG, "negative history storage");
+    std::memset(&d, 0, sizeof(d));
+    int bins = 0, total_rings = 0, near = 0, max_near_sectors = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (p.num_rings_each_zone[k] < 1 || p.num_sectors_each_zone[k] < 1)
+            return fail(PWPP_E_ARG, "zone %d: rings and sectors must be >= 1", k);
+        d.rings[k] = p.num_rings_each_zone[k];
+        d.sectors[k] = p.num_sectors_each_zone[k];
+        d.bin_base[k] = bins;
+        for (int r = 0; r < d.rings[k]; ++r) {
+            if (total_rings < p.num_rings_of_interest) {
+                near += d.sectors[k];
+                if (d.sectors[k] > max_near_sectors) max_near_sectors = d.sectors[k];
+            }
+            ++total_rings;
+        }
+        bins += d.rings[k] * d.sectors[k];
+    }
+    d.bin_base[4] = bins;
+    if (bins > PWPP_MAX_BINS) return fail(PWPP_E_UNSUPPORTED, "%d CZM bins: at most %d supported", bins, PWPP_MAX_BINS);
+    if (near > PWPP_MAX_NEAR_BINS) return fail(PWPP_E_UNSUPPORTED, "%d bins inside the rings of interest: at most %d", near, PWPP_MAX_NEAR_BINS);
+    d.num_bins = bins;
+    d.near_bins = near;
+    // CZM geometry, the reference constructor's expressions in double (patchworkpp.h:122-134)
+    const double mn = p.min_range, mx = p.max_range;
+    const double z2 = (7 * mn + mx) / 8.0, z3 = (3 * mn + mx) / 4.0, z4 = (mn + mx) / 2.0;
+    d.min_ranges[0] = mn;
+    d.min_ranges[1] = z2;
+    d.min_ranges[2] = z3;
+    d.min_ranges[3] = z4;
+    d.ring_sizes[0] = (z2 - mn) / p.num_rings_each_zone[0];
+    d.ring_sizes[1] = (z3 - z2) / p.num_rings_each_zone[1];
+    d.ring_sizes[2] = (z4 - z3) / p.num_rings_each_zone[2];
+    d.ring_sizes[3] = (mx - z4) / p.num_rings_each_zone[3];
+    for (int k = 0; k < 4; ++k) d.sector_sizes[k] = 2 * M_PI / p.num_sectors_each_zone[k];
+    d.enable_RNR = p.enable_RNR != 0;
+    d.enable_RVPF = p.enable_RVPF != 0;
+    d.enable_TGR = p.enable_TGR != 0;
+    d.num_iter = p.num_iter;
+    d.num_lpr = p.num_lpr < 0 ? 0 : p.num_lpr;
+    d.num_rings_of_interest = p.num_rings_of_interest;
+    d.min_pts = (uint64_t)(size_t)p.num_min_pts;  // int -> size_t as in `size() < params_.num_min_pts` (patchworkpp.cpp:191)
+    d.RNR_ver_angle_thr = p.RNR_ver_angle_thr;
+    d.RNR_intensity_thr = p.RNR_intensity_thr;
+    d.sensor_height = p.sensor_height;
+    d.th_seeds = p.th_seeds;
+    d.th_dist = p.th_dist;
+    d.th_seeds_v = p.th_seeds_v;
+    d.th_dist_v = p.th_dist_v;
+    d.max_range = p.max_range;
+    d.min_range = p.min_range;
+    d.uprightness_thr = p.uprightness_thr;
+    d.margin = p.adaptive_seed_selection_margin;
+    d.fxp_shift = fxp_shift_for(p.max_range);
+    d.max_elev_storage = p.max_elevation_storage;
+    d.max_flat_storage = p.max_flatness_storage;
+    for (int k = 0; k < 4; ++k) {
+        d.elevation_thr0[k] = p.elevation_thr[k];
+        d.flatness_thr0[k] = p.flatness_thr[k];
+    }
+    return max_near_sectors;  // >= 0
+}
+
+int use_device(pwpp_handle *h) {
+    HIPCHK(hipSetDevice(h->device));
+    return PWPP_OK;
+}
+
+void fill_default_state(const pwpp_handle *h, PwppStateScalar &s) {
+    std::memset(&s, 0, sizeof(s));
+    s.sensor_height = h->params.sensor_height;
+    for (int k = 0; k < 4; ++k) {
+        s.elevation_thr[k] = h->params.elevation_thr[k];
+        s.flatness_thr[k] = h->params.flatness_thr[k];
+    }
+}
+
+int finish_pending(pwpp_handle *h) {
+    if (!h->pending) return PWPP_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->pending = false;
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
+    h->time_us = (double)ms * 1000.0;
+    if (h->profile_pending) {
+        for (int k = 0; k < PWPP_NUM_KERNELS; ++k) {
+            float kms = 0.0f;
+            HIPCHK(hipEventElapsedTime(&kms, h->ev_k[k], h->ev_k[k + 1]));
+            h->prof_ms[k] += kms;
+            h->prof_launches[k] += 1;
+        }
+        h->profile_pending = false;
+    }
+    h->have_results = true;
+    return PWPP_OK;
+}
+
+int check_frame(pwpp_handle *h, int frame) {
+    if (!h) return fail(PWPP_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    rc = finish_pending(h);
+    if (rc) return rc;
+    if (!h->have_results) return fail(PWPP_E_STATE, "no frame has been processed yet");
+    if (frame < 0 || frame >= h->frames) return fail(PWPP_E_ARG, "frame %d out of range [0,%d)", frame, h->frames);
+    return PWPP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pwpp_last_error(void) { return g_err.c_str(); }
+
+int pwpp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *pwpp_kernel_name(int k) { return (k >= 0 && k < PWPP_NUM_KERNELS) ? kKernelNames[k] : ""; }
+
+int pwpp_params_default(pwpp_params *p) {  // reference patchworkpp.h:79-111
+    if (!p) return fail(PWPP_E_ARG, "null params");
+    std::memset(p, 0, sizeof(*p));
+    p->verbose = 0;
+    p->enable_RNR = 1;
+    p->enable_RVPF = 1;
+    p->enable_TGR = 1;
+    p->num_iter = 3;
+    p->num_lpr = 20;
+    p->num_min_pts = 10;
+    p->num_zones = 4;
+    p->num_rings_of_interest = 4;
+    p->RNR_ver_angle_thr = -15.0;
+    p->RNR_intensity_thr = 0.2;
+    p->sensor_height = 1.723;
+    p->th_seeds = 0.125;
+    p->th_dist = 0.125;
+    p->th_seeds_v = 0.25;
+    p->th_dist_v = 0.1;
+    p->max_range = 80.0;
+    p->min_range = 2.7;
+    p->uprightness_thr = 0.707;
+    p->adaptive_seed_selection_margin = -1.2;
+    p->intensity_thr = 0.0;  // uninitialised in the reference (patchworkpp.h:67), never read
+    const int sectors[4] = {16, 32, 54, 32}, rings[4] = {2, 4, 4, 4};
+    for (int k = 0; k < 4; ++k) {
+        p->num_sectors_each_zone[k] = sectors[k];
+        p->num_rings_each_zone[k] = rings[k];
+    }
+    p->max_flatness_storage = 1000;
+    p->max_elevation_storage = 1000;
+    return PWPP_OK;
+}
+
+int pwpp_set_num_streams(pwpp_handle *h, int streams) {
+    if (!h) return fail(PWPP_E_ARG, "null handle");
+    if (streams < 1) return fail(PWPP_E_ARG, "streams must be >= 1");
+    int rc = use_device(h);
+    if (rc) return rc;
+    rc = finish_pending(h);
+    if (rc) return rc;
+    if ((rc = h->d_st_stream.ensure((size_t)streams))) return rc;
+    if ((rc = h->d_hist_stream.ensure((size_t)streams * 8 * (size_t)h->stream_hist_cap))) return rc;
+    std::vector<PwppStateScalar> init((size_t)streams);
+    for (auto &s : init) fill_default_state(h, s);
+    HIPCHK(hipMemcpy(h->d_st_stream.p, init.data(), init.size() * sizeof(PwppStateScalar), hipMemcpyHostToDevice));
+    h->num_streams = streams;
+    return PWPP_OK;
+}
+
+int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
+    if (!p || !out) return fail(PWPP_E_ARG, "null argument");
+    *out = nullptr;
+    PwppDevParams dp;
+    const int max_near_sectors = build_dev_params(*p, dp);
+    if (max_near_sectors < 0) return max_near_sectors;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(PWPP_E_NODEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+    if (device < 0 || device >= ndev) return fail(PWPP_E_ARG, "device %d out of range [0,%d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    pwpp_handle *h = new pwpp_handle;
+    h->params = *p;
+    h->dp = dp;
+    h->device = device;
+    const int storage = p->max_elevation_storage > p->max_flatness_storage ? p->max_elevation_storage : p->max_flatness_storage;
+    h->stream_hist_cap = storage + max_near_sectors + 1024;
+    h->fresh_hist_cap = max_near_sectors + 2;
+    hipError_t se = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipEventCreate(&h->ev_begin);
+    if (se == hipSuccess) se = hipEventCreate(&h->ev_end);
+    for (int k = 0; k <= PWPP_NUM_KERNELS && se == hipSuccess; ++k) se = hipEventCreate(&h->ev_k[k]);
+    if (se != hipSuccess) {
+        pwpp_destroy(h);
+        return fail(PWPP_E_HIP, "stream/event creation failed: %s", hipGetErrorString(se));
+    }
+    int rc = pwpp_set_num_streams(h, 1);
+    if (rc) {
+        pwpp_destroy(h);
+        return rc;
+    }
+    if (p->verbose) std::printf("PatchWorkpp::PatchWorkpp() - INITIALIZATION COMPLETE (MI355X/HIP, %d CZM bins, fxp shift %d)\n", dp.num_bins, dp.fxp_shift);
+    *out = h;
+    return PWPP_OK;
+}
+
+int pwpp_destroy(pwpp_handle *h) {
+    if (!h) return PWPP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->d_frames.release();
+    h->h_frames.release();
+    h->h_base.release();
+    h->d_in.release();
+    h->d_codes.release();
+    h->d_sorted.release();
+    h->d_plist.release();
+    h->d_out.release();
+    h->d_bins.release();
+    h->d_recs.release();
+    h->d_centers.release();
+    h->d_normals.release();
+    h->d_results.release();
+    h->h_results.release();
+    h->d_xyz.release();
+    h->d_st_stream.release();
+    h->d_st_fresh.release();
+    h->d_hist_stream.release();
+    h->d_hist_fresh.release();
+    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    for (int k = 0; k <= PWPP_NUM_KERNELS; ++k)
+        if (h->ev_k[k]) (void)hipEventDestroy(h->ev_k[k]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PWPP_OK;
+}
+
+int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const int32_t *n, int frames, int cols,
+                               int layout, int mem, int mode) {
+    if (!h || !points || !n) return fail(PWPP_E_ARG, "null argument");
+    if (frames < 1) return fail(PWPP_E_ARG, "frames must be >= 1");
+    if (cols != 3 && cols != 4) return fail(PWPP_E_ARG, "cols=%d: 3 or 4 expected", cols);
+    if (layout != PWPP_LAYOUT_ROW_MAJOR && layout != PWPP_LAYOUT_COL_MAJOR) return fail(PWPP_E_ARG, "bad layout %d", layout);
+    if (mem != PWPP_MEM_HOST && mem != PWPP_MEM_DEVICE) return fail(PWPP_E_ARG, "bad mem %d", mem);
+    if (mode != PWPP_MODE_FRESH && mode != PWPP_MODE_STREAMS) return fail(PWPP_E_ARG, "bad mode %d", mode);
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    if (mode == PWPP_MODE_STREAMS && frames > h->num_streams)
+        return fail(PWPP_E_ARG, "%d frames but only %d streams (pwpp_set_num_streams)", frames, h->num_streams);
+
+    const int B = h->dp.num_bins, NB = B + 2;
+    int64_t total = 0, total_in = 0;
+    int max_n = 0;
+    for (int f = 0; f < frames; ++f) {
+        if (n[f] < 0 || n[f] > (1 << 22)) return fail(PWPP_E_ARG, "frame %d: %d points (0..4194304 supported)", f, n[f]);
+        if (n[f] > 0 && !points[f]) return fail(PWPP_E_ARG, "frame %d: null points", f);
+        if (mem == PWPP_MEM_DEVICE && layout == PWPP_LAYOUT_ROW_MAJOR && cols == 4 && ((uintptr_t)points[f] & 15u))
+            return fail(PWPP_E_ARG, "frame %d: device buffer must be 16-byte aligned", f);
+        total += n[f];
+        total_in += ((int64_t)n[f] * cols + 3) & ~(int64_t)3;
+        if (n[f] > max_n) max_n = n[f];
+    }
+    if (total >= ((int64_t)1 << 31)) return fail(PWPP_E_ARG, "batch of %lld points exceeds 2^31", (long long)total);
+    const size_t tp = (size_t)(total > 0 ? total : 1);
+
+    if ((rc = h->d_frames.ensure((size_t)frames))) return rc;
+    if ((rc = h->h_frames.ensure((size_t)frames))) return rc;
+    if ((rc = h->h_base.ensure((size_t)frames + 1))) return rc;
+    if ((rc = h->d_codes.ensure(tp))) return rc;
+    if ((rc = h->d_sorted.ensure(tp))) return rc;
+    if ((rc = h->d_plist.ensure(tp))) return rc;
+    if ((rc = h->d_out.ensure(tp))) return rc;
+    if ((rc = h->d_bins.ensure((size_t)frames * NB * 5))) return rc;
+    if ((rc = h->d_recs.ensure((size_t)frames * B))) return rc;
+    if ((rc = h->d_centers.ensure((size_t)frames * B * 3))) return rc;
+    if ((rc = h->d_normals.ensure((size_t)frames * B * 3))) return rc;
+    if ((rc = h->d_results.ensure((size_t)frames))) return rc;
+    if ((rc = h->h_results.ensure((size_t)frames))) return rc;
+    if (mode == PWPP_MODE_FRESH) {
+        if ((rc = h->d_st_fresh.ensure((size_t)frames))) return rc;
+        if ((rc = h->d_hist_fresh.ensure((size_t)frames * 8 * (size_t)h->fresh_hist_cap))) return rc;
+    }
+    if (mem == PWPP_MEM_HOST && (rc = h->d_in.ensure((size_t)(total_in > 0 ? total_in : 4)))) return rc;
+
+    // frame descriptors
+    h->descs.resize((size_t)frames);
+    int64_t base = 0, in_off = 0;
+    for (int f = 0; f < frames; ++f) {
+        PwppFrameDesc &d = h->descs[(size_t)f];
+        std::memset(&d, 0, sizeof(d));
+        d.n = n[f];
+        d.cols = cols;
+        d.layout = layout;
+        d.base = base;
+        if (mode == PWPP_MODE_FRESH) {
+            d.state_in = -1;
+            d.state_out = f;
+        } else {
+            d.state_in = f;
+            d.state_out = f;
+        }
+        if (mem == PWPP_MEM_HOST) {
+            d.pts = h->d_in.p + in_off;
+            if (n[f] > 0)
+                HIPCHK(hipMemcpyAsync(h->d_in.p + in_off, points[f], (size_t)n[f] * cols * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            in_off += ((int64_t)n[f] * cols + 3) & ~(int64_t)3;
+        } else {
+            d.pts = points[f];
+        }
+        h->h_base.p[f] = base;
+        base += n[f];
+    }
+    h->h_base.p[frames] = base;
+    std::memcpy(h->h_frames.p, h->descs.data(), (size_t)frames * sizeof(PwppFrameDesc));
+    HIPCHK(hipMemcpyAsync(h->d_frames.p, h->h_frames.p, (size_t)frames * sizeof(PwppFrameDesc), hipMemcpyHostToDevice, h->stream));
+
+    PwppBatch bt;
+    std::memset(&bt, 0, sizeof(bt));
+    bt.P = h->dp;
+    bt.frames = h->d_frames.p;
+    bt.num_frames = frames;
+    bt.max_n = max_n;
+    if (mode == PWPP_MODE_FRESH) {
+        bt.P.hist_cap = h->fresh_hist_cap;
+        bt.st_scalar = h->d_st_fresh.p;
+        bt.st_hist = h->d_hist_fresh.p;
+    } else {
+        bt.P.hist_cap = h->stream_hist_cap;
+        bt.st_scalar = h->d_st_stream.p;
+        bt.st_hist = h->d_hist_stream.p;
+    }
+    bt.codes = h->d_codes.p;
+    const size_t slab = (size_t)frames * NB;
+    bt.bin_count = h->d_bins.p;
+    bt.bin_off = h->d_bins.p + slab;
+    bt.bin_cursor = h->d_bins.p + 2 * slab;
+    bt.dst_a = h->d_bins.p + 3 * slab;
+    bt.dst_b = h->d_bins.p + 4 * slab;
+    bt.sorted = h->d_sorted.p;
+    bt.plist = h->d_plist.p;
+    bt.recs = h->d_recs.p;
+    bt.out_idx = h->d_out.p;
+    bt.centers = h->d_centers.p;
+    bt.normals = h->d_normals.p;
+    bt.results = h->d_results.p;
+
+    HIPCHK(hipEventRecord(h->ev_begin, h->stream));
+    // zero the histogram, the scatter cursors and the per-frame result counters
+    HIPCHK(hipMemsetAsync(bt.bin_count, 0, slab * sizeof(uint32_t), h->stream));
+    HIPCHK(hipMemsetAsync(bt.bin_cursor, 0, slab * sizeof(uint32_t), h->stream));
+    HIPCHK(hipMemsetAsync(bt.results, 0, (size_t)frames * sizeof(PwppFrameResult), h->stream));
+    const int lrc = pwpp_launch_pipeline(&bt, h->stream, h->profiling ? h->ev_k : nullptr);
+    if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    HIPCHK(hipEventRecord(h->ev_end, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_results.p, h->d_results.p, (size_t)frames * sizeof(PwppFrameResult), hipMemcpyDeviceToHost, h->stream));
+    h->profile_pending = h->profiling;
+    h->frames = frames;
+    h->mode = mode;
+    h->pending = true;
+    h->have_results = false;
+    if (mem == PWPP_MEM_HOST) return finish_pending(h);  // the caller's buffers may go away
+    return PWPP_OK;
+}
+
+int pwpp_estimate_ground(pwpp_handle *h, const float *points, int n, int cols, int layout) {
+    const float *ptrs[1] = {points};
+    const int32_t ns[1] = {n};
+    return pwpp_estimate_ground_batch(h, ptrs, ns, 1, cols, layout, PWPP_MEM_HOST, PWPP_MODE_STREAMS);
+}
+
+int pwpp_synchronize(pwpp_handle *h) {
+    if (!h) return fail(PWPP_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    return finish_pending(h);
+}
+
+int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32_t *n_nonground, int32_t *n_patches) {
+    int rc = check_frame(h, frame);
+    if (rc) return rc;
+    const PwppFrameResult &r = h->h_results.p[frame];
+    if (n_ground) *n_ground = r.n_ground;
+    if (n_nonground) *n_nonground = r.n_nonground;
+    if (n_patches) *n_patches = r.n_patches;
+    return PWPP_OK;
+}
+
+static int copy_indices(pwpp_handle *h, int frame, int32_t *out, bool ground) {
+    int rc = check_frame(h, frame);
+    if (rc) return rc;
+    const PwppFrameResult &r = h->h_results.p[frame];
+    const int64_t base = h->h_base.p[frame];
+    const int count = ground ? r.n_ground : r.n_nonground;
+    if (count > 0) {
+        if (!out) return fail(PWPP_E_ARG, "null output");
+        HIPCHK(hipMemcpy(out, h->d_out.p + base + (ground ? 0 : r.n_ground), (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    return PWPP_OK;
+}
+int pwpp_get_ground_indices(pwpp_handle *h, int frame, int32_t *out) { return copy_indices(h, frame, out, true); }
+int pwpp_get_nonground_indices(pwpp_handle *h, int frame, int32_t *out) { return copy_indices(h, frame, out, false); }
+
+static int copy_xyz(pwpp_handle *h, int frame, float *out, bool ground) {
+    int rc = check_frame(h, frame);
+    if (rc) return rc;
+    const PwppFrameResult &r = h->h_results.p[frame];
+    const int64_t base = h->h_base.p[frame];
+    const int count = ground ? r.n_ground : r.n_nonground;
+    if (count <= 0) return PWPP_OK;
+    if (!out) return fail(PWPP_E_ARG, "null output");
+    if ((rc = h->d_xyz.ensure((size_t)count * 3))) return rc;
+    const int lrc = pwpp_launch_gather_xyz(&h->descs[(size_t)frame], h->d_out.p + base + (ground ? 0 : r.n_ground), count, h->d_xyz.p, h->stream);
+    if (lrc != 0) return fail(PWPP_E_HIP, "gather launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    HIPCHK(hipMemcpyAsync(out, h->d_xyz.p, (size_t)count * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PWPP_OK;
+}
+int pwpp_get_ground_xyz(pwpp_handle *h, int frame, float *out) { return copy_xyz(h, frame, out, true); }
+int pwpp_get_nonground_xyz(pwpp_handle *h, int frame, float *out) { return copy_xyz(h, frame, out, false); }
+
+static int copy_patch_rows(pwpp_handle *h, int frame, float *out, const float *src_all) {
+    int rc = check_frame(h, frame);
+    if (rc) return rc;
+    const int np = h->h_results.p[frame].n_patches;
+    if (np <= 0) return PWPP_OK;
+    if (!out) return fail(PWPP_E_ARG, "null output");
+    HIPCHK(hipMemcpy(out, src_all + (size_t)frame * h->dp.num_bins * 3, (size_t)np * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return PWPP_OK;
+}
+int pwpp_get_centers(pwpp_handle *h, int frame, float *out) { return copy_patch_rows(h, frame, out, h ? h->d_centers.p : nullptr); }
+int pwpp_get_normals(pwpp_handle *h, int frame, float *out) { return copy_patch_rows(h, frame, out, h ? h->d_normals.p : nullptr); }
+
+int pwpp_get_patch_records(pwpp_handle *h, int frame, pwpp_patch_record *out, int capacity) {
+    int rc = check_frame(h, frame);
+    if (rc) return rc;
+    const int B = h->dp.num_bins, NB = B + 2;
+    std::vector<PwppPatchRec> recs((size_t)B);
+    std::vector<uint32_t> cnt((size_t)NB);
+    HIPCHK(hipMemcpy(recs.data(), h->d_recs.p + (size_t)frame * B, (size_t)B * sizeof(PwppPatchRec), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cnt.data(), h->d_bins.p + (size_t)frame * NB, (size_t)NB * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    int k = 0, concentric = 0;
+    for (int zone = 0; zone < 4; ++zone)
+        for (int ring = 0; ring < h->dp.rings[zone]; ++ring, ++concentric)
+            for (int sector = 0; sector < h->dp.sectors[zone]; ++sector) {
+                const int bin = h->dp.bin_base[zone] + ring * h->dp.sectors[zone] + sector;
+                if ((uint64_t)cnt[(size_t)bin] < h->dp.min_pts) continue;
+                if (k < capacity && out) {
+                    const PwppPatchRec &r = recs[(size_t)bin];
+                    pwpp_patch_record &o = out[k];
+                    std::memset(&o, 0, sizeof(o));
+                    o.bin = bin;
+                    o.concentric_idx = concentric;
+                    o.n_points = (int)cnt[(size_t)bin];
+                    o.n_ground = r.n_ground;
+                    o.n_nonground = r.n_nonground;
+                    o.decision = r.decision;
+                    for (int i = 0; i < 3; ++i) {
+                        o.mean[i] = r.mean[i];
+                        o.normal[i] = r.normal[i];
+                        o.sv[i] = r.sv[i];
+                    }
+                    o.d = r.d;
+                }
+                ++k;
+            }
+    return k;  // number of patches (>= 0)
+}
+
+double pwpp_get_height(pwpp_handle *h) {
+    pwpp_state s;
+    if (!h) return 0.0;
+    if (use_device(h) || finish_pending(h)) return 0.0;
+    if (hipMemcpy(&s, h->d_st_stream.p, sizeof(s), hipMemcpyDeviceToHost) != hipSuccess) return 0.0;
+    return s.sensor_height;
+}
+
+double pwpp_get_time_us(pwpp_handle *h) {
+    if (!h) return 0.0;
+    if (use_device(h) || finish_pending(h)) return 0.0;
+    return h->time_us;
+}
+
+int pwpp_get_state(pwpp_handle *h, int index, pwpp_state *out) {
+    if (!h || !out) return fail(PWPP_E_ARG, "null argument");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    const bool fresh = h->have_results && h->mode == PWPP_MODE_FRESH;
+    const int limit = fresh ? h->frames : h->num_streams;
+    if (index < 0 || index >= limit) return fail(PWPP_E_ARG, "state index %d out of range [0,%d)", index, limit);
+    const PwppStateScalar *src = (fresh ? h->d_st_fresh.p : h->d_st_stream.p) + index;
+    HIPCHK(hipMemcpy(out, src, sizeof(pwpp_state), hipMemcpyDeviceToHost));
+    return PWPP_OK;
+}
+
+int pwpp_get_history(pwpp_handle *h, int index, int which, int ring, double *out, int capacity) {
+    pwpp_state s;
+    int rc = pwpp_get_state(h, index, &s);
+    if (rc) return rc;
+    if (which < 0 || which > 1 || ring < 0 || ring > 3) return fail(PWPP_E_ARG, "bad history selector");
+    const bool fresh = h->mode == PWPP_MODE_FRESH && h->have_results;
+    const int cap = fresh ? h->fresh_hist_cap : h->stream_hist_cap;
+    const double *base = (fresh ? h->d_hist_fresh.p : h->d_hist_stream.p) + ((size_t)index * 8 + (size_t)which * 4 + ring) * cap;
+    const int len = which == 0 ? s.elevation_len[ring] : s.flatness_len[ring];
+    const int ncopy = len < capacity ? len : capacity;
+    if (ncopy > 0) {
+        if (!out) return fail(PWPP_E_ARG, "null output");
+        HIPCHK(hipMemcpy(out, base, (size_t)ncopy * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return len;
+}
+
+int pwpp_set_state(pwpp_handle *h, int stream, const pwpp_state *in) {
+    if (!h || !in) return fail(PWPP_E_ARG, "null argument");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    if (stream < 0 || stream >= h->num_streams) return fail(PWPP_E_ARG, "stream %d out of range", stream);
+    PwppStateScalar s;
+    std::memcpy(&s, in, sizeof(s));
+    for (int k = 0; k < 4; ++k) s.elev_len[k] = s.flat_len[k] = 0;
+    HIPCHK(hipMemcpy(h->d_st_stream.p + stream, &s, sizeof(s), hipMemcpyHostToDevice));
+    return PWPP_OK;
+}
+
+int pwpp_get_device_view(pwpp_handle *h, pwpp_device_view *out) {
+    if (!h || !out) return fail(PWPP_E_ARG, "null argument");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    if (!h->have_results) return fail(PWPP_E_STATE, "no frame has been processed yet");
+    out->indices = h->d_out.p;
+    out->frame_base = h->h_base.p;
+    out->counts = reinterpret_cast<const int32_t *>(h->h_results.p);
+    out->frames = h->frames;
+    out->pad_ = 0;
+    return PWPP_OK;
+}
+
+int pwpp_set_profiling(pwpp_handle *h, int enable) {
+    if (!h) return fail(PWPP_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    h->profiling = enable != 0;
+    return PWPP_OK;
+}
+int pwpp_get_kernel_profile(pwpp_handle *h, double *sum_ms, int64_t *launches) {
+    if (!h) return fail(PWPP_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    for (int k = 0; k < PWPP_NUM_KERNELS; ++k) {
+        if (sum_ms) sum_ms[k] = h->prof_ms[k];
+        if (launches) launches[k] = h->prof_launches[k];
+    }
+    return PWPP_OK;
+}
+int pwpp_reset_kernel_profile(pwpp_handle *h) {
+    if (!h) return fail(PWPP_E_ARG, "null handle");
+    for (int k = 0; k < PWPP_NUM_KERNELS; ++k) {
+        h->prof_ms[k] = 0.0;
+        h->prof_launches[k] = 0;
+    }
+    return PWPP_OK;
+}
+int pwpp_get_fxp_shift(pwpp_handle *h) { return h ? h->dp.fxp_shift : PWPP_E_ARG; }
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// pwpp_dev.h -- structures shared by the host side (pwpp_capi.cpp) and the gfx950 kernels
+// (pwpp_kernels.hip).  Internal; the public boundary is include/pwpp.h.
+#ifndef PWPP_DEV_H
+#define PWPP_DEV_H
+
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+#define PWPP_MAX_BINS 2048        // CZM bins per frame (default model: 504)
+#define PWPP_MAX_NEAR_BINS 1024   // bins inside the rings of interest (default: 96)
+#define PWPP_MAX_LPR 64           // num_lpr upper bound (default 20)
+#define PWPP_MAX_ROI 4            // rings of interest (reference keeps update_*_[4])
+
+// per-point CZM codes written by k_czm_bin (uint16): 0..B-1 real bins, then
+#define PWPP_CODE_RNR(B) ((B))        // reflected-noise hit      (patchworkpp.cpp:391-396)
+#define PWPP_CODE_OOR(B) ((B) + 1)    // outside (min,max] range  (patchworkpp.cpp:595,618)
+#define PWPP_CODE_DROP 0xFFFFu        // z == FLT_MIN in the input: the reference silently drops it (:591)
+
+struct PwppDevParams {
+    int32_t enable_RNR, enable_RVPF, enable_TGR;
+    int32_t num_iter, num_lpr, num_rings_of_interest;
+    uint64_t min_pts;  // (size_t)num_min_pts, the reference compares size_t < int (patchworkpp.cpp:191)
+    double RNR_ver_angle_thr, RNR_intensity_thr;
+    double sensor_height;  // initial value (fresh state)
+    double th_seeds, th_dist, th_seeds_v, th_dist_v;
+    double max_range, min_range, uprightness_thr, margin;
+    double min_ranges[4], ring_sizes[4], sector_sizes[4];  // patchworkpp.h:122-134, computed on the host in double
+    int32_t rings[4], sectors[4];
+    int32_t bin_base[5];  // first bin of zone k; [4] = B
+    int32_t num_bins;     // B
+    int32_t fxp_shift;    // s of the plane-fit arithmetic contract
+    int32_t max_elev_storage, max_flat_storage;
+    int32_t hist_cap;     // doubles per (state, which, ring) history slab
+    int32_t near_bins;    // bins with concentric_idx < num_rings_of_interest
+    double elevation_thr0[4], flatness_thr0[4];  // initial thresholds (fresh state)
+};
+
+struct PwppFrameDesc {
+    const float *pts;
+    int32_t n;
+    int32_t cols;      // 3 or 4
+    int32_t layout;    // PWPP_LAYOUT_*
+    int32_t state_in;  // index into the state arrays, -1 = fresh (defaults from params)
+    int64_t base;      // first slot of this frame in the per-point workspaces
+    int32_t state_out; // index the updated state is written to
+    int32_t pad_;
+};
+
+struct PwppStateScalar {  // = pwpp_state
+    double sensor_height;
+    double elevation_thr[4];
+    double flatness_thr[4];
+    int32_t elev_len[4];
+    int32_t flat_len[4];
+};
+
+struct PwppPatchRec {  // one per (frame, bin); written by k_patch_fit, finished by k_gle_tgr
+    float mean[3];
+    float normal[3];
+    float sv[3];
+    int32_t n_ground;
+    double d;
+    int32_t n_points;
+    int32_t n_nonground;
+    int32_t decision;
+    int32_t valid;  // 0: no fit ran in this bin (empty bin let through by num_min_pts <= 0)
+};
+
+struct PwppFrameResult {
+    int32_t n_ground, n_nonground, n_patches, n_rnr, n_oor, n_dropped, pad0, pad1;
+};
+
+// everything a launch needs, by value in the kernarg segment
+struct PwppBatch {
+    PwppDevParams P;
+    const PwppFrameDesc *frames;
+    int32_t num_frames;
+    int32_t max_n;               // largest frame of the batch
+    PwppStateScalar *st_scalar;  // [num_states]
+    double *st_hist;             // [num_states][2][4][hist_cap]
+    uint16_t *codes;             // [total points]
+    uint32_t *bin_count;         // [frames][B+2]
+    uint32_t *bin_off;           // [frames][B+2] exclusive scan of bin_count
+    uint32_t *bin_cursor;        // [frames][B+2]
+    float4 *sorted;              // [total points] {x,y,z,bits(idx)} grouped by bin; bit 31 of w = stripped by R-VPF
+    int32_t *plist;              // [total points] per patch: ground candidates from the front, non-ground from the back
+    PwppPatchRec *recs;          // [frames][B]
+    uint32_t *dst_a;             // [frames][B+2] output offset of sub-list A (candidates / whole bin)
+    uint32_t *dst_b;             // [frames][B+2] output offset of sub-list B (regionwise non-ground)
+    int32_t *out_idx;            // [total points] per frame: ground list then non-ground list
+    float *centers;              // [frames][B][3] compacted to n_patches rows
+    float *normals;              // [frames][B][3]
+    PwppFrameResult *results;    // [frames]
+};
+
+#endif

@@ -1,0 +1,271 @@
+"""ctypes binding of the C-ABI in include/pwpp.h (libpwpp_hip.so).
+
+Thin host-side plumbing for tests, bench.py and Python callers that want the batch API;
+the drop-in Python surface of the reference (module ``pypatchworkpp``) is the pybind11
+module built from pybinding.cpp next to this file.  No CPU fallback: if the shared
+library is missing or there is no GPU, constructing a :class:`Handle` raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libpwpp_hip.so")
+
+LAYOUT_ROW_MAJOR, LAYOUT_COL_MAJOR = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+MODE_FRESH, MODE_STREAMS = 0, 1
+NUM_KERNELS = 6
+
+DEC_NAMES = {1: "not_upright", 2: "far_ground", 3: "heading", 4: "ground", 5: "tgr_reject", 6: "tgr_revert"}
+
+
+class Params(ctypes.Structure):
+    """pwpp_params = patchwork::Params (reference patchworkpp.h:42-112)."""
+
+    _fields_ = (
+        [(n, ctypes.c_int32) for n in
+         "verbose enable_RNR enable_RVPF enable_TGR num_iter num_lpr num_min_pts num_zones "
+         "num_rings_of_interest pad0_".split()]
+        + [(n, ctypes.c_double) for n in
+           "RNR_ver_angle_thr RNR_intensity_thr sensor_height th_seeds th_dist th_seeds_v th_dist_v "
+           "max_range min_range uprightness_thr adaptive_seed_selection_margin intensity_thr".split()]
+        + [("num_sectors_each_zone", ctypes.c_int32 * 4), ("num_rings_each_zone", ctypes.c_int32 * 4),
+           ("max_flatness_storage", ctypes.c_int32), ("max_elevation_storage", ctypes.c_int32),
+           ("elevation_thr", ctypes.c_double * 4), ("flatness_thr", ctypes.c_double * 4)]
+    )
+
+
+class State(ctypes.Structure):
+    _fields_ = [("sensor_height", ctypes.c_double), ("elevation_thr", ctypes.c_double * 4),
+                ("flatness_thr", ctypes.c_double * 4), ("elevation_len", ctypes.c_int32 * 4),
+                ("flatness_len", ctypes.c_int32 * 4)]
+
+
+RECORD_DTYPE = np.dtype([("bin", "<i4"), ("concentric_idx", "<i4"), ("n_points", "<i4"), ("n_ground", "<i4"),
+                         ("n_nonground", "<i4"), ("decision", "<i4"), ("mean", "<f4", 3), ("normal", "<f4", 3),
+                         ("sv", "<f4", 3), ("pad_", "<f4"), ("d", "<f8")])
+
+
+class DeviceView(ctypes.Structure):
+    _fields_ = [("indices", ctypes.c_void_p), ("frame_base", ctypes.POINTER(ctypes.c_int64)),
+                ("counts", ctypes.POINTER(ctypes.c_int32)), ("frames", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class PwppError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libpwpp_hip.so (raises if it has not been built -- there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PwppError("%s not built; run __graft_entry__.build() or make -C patchwork-plusplus_amd" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.pwpp_last_error.restype = ctypes.c_char_p
+        L.pwpp_kernel_name.restype = ctypes.c_char_p
+        L.pwpp_get_height.restype = ctypes.c_double
+        L.pwpp_get_time_us.restype = ctypes.c_double
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        L.pwpp_create.argtypes = [ctypes.POINTER(Params), ci, ctypes.POINTER(vp)]
+        L.pwpp_destroy.argtypes = [vp]
+        L.pwpp_estimate_ground.argtypes = [vp, vp, ci, ci, ci]
+        L.pwpp_estimate_ground_batch.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci]
+        L.pwpp_synchronize.argtypes = [vp]
+        L.pwpp_set_num_streams.argtypes = [vp, ci]
+        L.pwpp_get_counts.argtypes = [vp, ci, vp, vp, vp]
+        for name in ("pwpp_get_ground_indices", "pwpp_get_nonground_indices", "pwpp_get_ground_xyz",
+                     "pwpp_get_nonground_xyz", "pwpp_get_centers", "pwpp_get_normals"):
+            getattr(L, name).argtypes = [vp, ci, vp]
+        L.pwpp_get_patch_records.argtypes = [vp, ci, vp, ci]
+        L.pwpp_get_height.argtypes = [vp]
+        L.pwpp_get_time_us.argtypes = [vp]
+        L.pwpp_get_state.argtypes = [vp, ci, ctypes.POINTER(State)]
+        L.pwpp_get_history.argtypes = [vp, ci, ci, ci, vp, ci]
+        L.pwpp_set_state.argtypes = [vp, ci, ctypes.POINTER(State)]
+        L.pwpp_get_device_view.argtypes = [vp, ctypes.POINTER(DeviceView)]
+        L.pwpp_set_profiling.argtypes = [vp, ci]
+        L.pwpp_get_kernel_profile.argtypes = [vp, vp, vp]
+        L.pwpp_reset_kernel_profile.argtypes = [vp]
+        L.pwpp_get_fxp_shift.argtypes = [vp]
+        L.pwpp_kernel_name.argtypes = [ci]
+        _lib = L
+    return _lib
+
+
+def default_params():
+    p = Params()
+    load().pwpp_params_default(ctypes.byref(p))
+    return p
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Handle:
+    """One pwpp_handle: one device, one HIP stream, the workspace and the adaptive state."""
+
+    def __init__(self, params=None, device=0):
+        self._L = load()
+        self.params = params if params is not None else default_params()
+        h = ctypes.c_void_p()
+        self._h = None
+        self._check(self._L.pwpp_create(ctypes.byref(self.params), device, ctypes.byref(h)))
+        self._h = h
+        self._keep = None
+
+    def _check(self, rc):
+        if rc < 0:
+            raise PwppError("pwpp error %d: %s" % (rc, self._L.pwpp_last_error().decode()))
+        return rc
+
+    def close(self):
+        if self._h:
+            self._L.pwpp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the hot path -----------------------------------------------------------------
+    def estimate_ground(self, pts):
+        """Reference estimateGround(): one host frame, stateful (stream 0)."""
+        pts = np.asarray(pts, dtype=np.float32)
+        if pts.ndim != 2:
+            raise PwppError("expected a 2-D array")
+        if pts.flags["C_CONTIGUOUS"]:
+            layout = LAYOUT_ROW_MAJOR
+        elif pts.flags["F_CONTIGUOUS"]:
+            layout = LAYOUT_COL_MAJOR
+        else:
+            pts = np.ascontiguousarray(pts)
+            layout = LAYOUT_ROW_MAJOR
+        self._check(self._L.pwpp_estimate_ground(self._h, _vp(pts), pts.shape[0], pts.shape[1], layout))
+
+    def estimate_ground_batch(self, frames, mode=MODE_FRESH):
+        """Host frames (list of (n,cols) float32 C-contiguous arrays), synchronous."""
+        frames = [np.ascontiguousarray(f, dtype=np.float32) for f in frames]
+        cols = frames[0].shape[1]
+        ptrs = (ctypes.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+        ns = (ctypes.c_int32 * len(frames))(*[f.shape[0] for f in frames])
+        self._check(self._L.pwpp_estimate_ground_batch(self._h, ptrs, ns, len(frames), cols, LAYOUT_ROW_MAJOR,
+                                                       MEM_HOST, mode))
+
+    def estimate_ground_batch_device(self, ptrs, ns, cols=4, layout=LAYOUT_ROW_MAJOR, mode=MODE_FRESH):
+        """Device-resident frames: ptrs = device addresses (ints), asynchronous until synchronize()."""
+        k = len(ptrs)
+        cp = (ctypes.c_void_p * k)(*ptrs)
+        cn = (ctypes.c_int32 * k)(*ns)
+        self._keep = (cp, cn)
+        self._check(self._L.pwpp_estimate_ground_batch(self._h, cp, cn, k, cols, layout, MEM_DEVICE, mode))
+
+    def make_device_batch(self, ptrs, ns):
+        """Pre-built ctypes argument arrays for repeated launches of the same batch."""
+        k = len(ptrs)
+        return (ctypes.c_void_p * k)(*ptrs), (ctypes.c_int32 * k)(*ns), k
+
+    def launch_device_batch(self, batch, cols=4, layout=LAYOUT_ROW_MAJOR, mode=MODE_FRESH):
+        cp, cn, k = batch
+        self._check(self._L.pwpp_estimate_ground_batch(self._h, cp, cn, k, cols, layout, MEM_DEVICE, mode))
+
+    def synchronize(self):
+        self._check(self._L.pwpp_synchronize(self._h))
+
+    def set_num_streams(self, n):
+        self._check(self._L.pwpp_set_num_streams(self._h, n))
+
+    # ---- results ----------------------------------------------------------------------
+    def counts(self, frame=0):
+        a, b, c = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        self._check(self._L.pwpp_get_counts(self._h, frame, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def _get(self, fn, frame, shape, dtype):
+        out = np.zeros(shape, dtype)
+        self._check(fn(self._h, frame, _vp(out) if out.size else None))
+        return out
+
+    def ground_indices(self, frame=0):
+        return self._get(self._L.pwpp_get_ground_indices, frame, self.counts(frame)[0], np.int32)
+
+    def nonground_indices(self, frame=0):
+        return self._get(self._L.pwpp_get_nonground_indices, frame, self.counts(frame)[1], np.int32)
+
+    def ground(self, frame=0):
+        return self._get(self._L.pwpp_get_ground_xyz, frame, (self.counts(frame)[0], 3), np.float32)
+
+    def nonground(self, frame=0):
+        return self._get(self._L.pwpp_get_nonground_xyz, frame, (self.counts(frame)[1], 3), np.float32)
+
+    def centers(self, frame=0):
+        return self._get(self._L.pwpp_get_centers, frame, (self.counts(frame)[2], 3), np.float32)
+
+    def normals(self, frame=0):
+        return self._get(self._L.pwpp_get_normals, frame, (self.counts(frame)[2], 3), np.float32)
+
+    def patch_records(self, frame=0):
+        n = self.counts(frame)[2]
+        out = np.zeros(max(n, 1), RECORD_DTYPE)
+        k = self._check(self._L.pwpp_get_patch_records(self._h, frame, _vp(out), len(out)))
+        return out[:k]
+
+    def height(self):
+        return self._L.pwpp_get_height(self._h)
+
+    def time_us(self):
+        return self._L.pwpp_get_time_us(self._h)
+
+    def state(self, index=0):
+        s = State()
+        self._check(self._L.pwpp_get_state(self._h, index, ctypes.byref(s)))
+        return s
+
+    def set_state(self, stream, sensor_height, elevation_thr, flatness_thr):
+        s = State()
+        s.sensor_height = sensor_height
+        for k in range(4):
+            s.elevation_thr[k] = elevation_thr[k]
+            s.flatness_thr[k] = flatness_thr[k]
+        self._check(self._L.pwpp_set_state(self._h, stream, ctypes.byref(s)))
+
+    def history(self, index, which, ring):
+        n = self._check(self._L.pwpp_get_history(self._h, index, which, ring, None, 0))
+        out = np.zeros(n, np.float64)
+        if n:
+            self._check(self._L.pwpp_get_history(self._h, index, which, ring, _vp(out), n))
+        return out
+
+    def device_view(self):
+        v = DeviceView()
+        self._check(self._L.pwpp_get_device_view(self._h, ctypes.byref(v)))
+        return v
+
+    def all_counts(self):
+        """(frames, 8) int32 array of per-frame counters of the last call."""
+        v = self.device_view()
+        return np.ctypeslib.as_array(v.counts, shape=(v.frames, 8)).copy()
+
+    # ---- measurement --------------------------------------------------------------------
+    def set_profiling(self, on):
+        self._check(self._L.pwpp_set_profiling(self._h, 1 if on else 0))
+
+    def reset_kernel_profile(self):
+        self._check(self._L.pwpp_reset_kernel_profile(self._h))
+
+    def kernel_profile(self):
+        ms = np.zeros(NUM_KERNELS, np.float64)
+        cnt = np.zeros(NUM_KERNELS, np.int64)
+        self._check(self._L.pwpp_get_kernel_profile(self._h, _vp(ms), _vp(cnt)))
+        return {self._L.pwpp_kernel_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(NUM_KERNELS)}
+
+    def fxp_shift(self):
+        return self._L.pwpp_get_fxp_shift(self._h)
