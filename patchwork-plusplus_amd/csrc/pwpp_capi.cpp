@@ -479,6 +479,10 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     bt.frames = h->d_frames.p;
     bt.num_frames = frames;
     bt.max_n = max_n;
+    {
+        const char *dbg = std::getenv("PWPP_DEBUG_FLAGS");  // timing ablations only; results are wrong when set
+        bt.debug = dbg ? std::atoi(dbg) : 0;
+    }
     if (mode == PWPP_MODE_FRESH) {
         bt.P.hist_cap = h->fresh_hist_cap;
         bt.st_scalar = h->d_st_fresh.p;

@@ -76,6 +76,8 @@ struct PwppBatch {
     const PwppFrameDesc *frames;
     int32_t num_frames;
     int32_t max_n;               // largest frame of the batch
+    int32_t debug;               // ablation switches for timing experiments only (PWPP_DEBUG_FLAGS); 0 in production
+    int32_t pad_;
     PwppStateScalar *st_scalar;  // [num_states]
     double *st_hist;             // [num_states][2][4][hist_cap]
     uint16_t *codes;             // [total points]

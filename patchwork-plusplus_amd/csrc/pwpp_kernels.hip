@@ -479,7 +479,7 @@ struct FitShared {
 // An empty set leaves the previous plane in force, as ref :49 does.
 // `wide`: bins above 65536 points could overflow an int64 second moment in the cross-lane
 // sum; they are reduced as two 32-bit limbs and recombined in 128 bits (exact either way).
-__device__ void reduce_and_fit(FitShared &sh, const Moments &m, bool wide, int shift) {
+__device__ void reduce_and_fit(FitShared &sh, const Moments &m, bool wide, int shift, int debug = 0) {
     long long v[16];
     v[0] = m.n;
     v[1] = m.s1[0];
@@ -538,7 +538,13 @@ __device__ void reduce_and_fit(FitShared &sh, const Moments &m, bool wide, int s
                 }
             }
             float u[9], sv[3];
-            jacobi_svd3(cov, u, sv);
+            if (debug & 1) {  // ablation: no eigen-solve
+                for (int k = 0; k < 9; ++k) u[k] = cov[k];
+                sv[0] = cov[0]; sv[1] = cov[4]; sv[2] = cov[8];
+                u[2] = 0.01f; u[5] = 0.01f; u[8] = 0.9999f;
+            } else {
+                jacobi_svd3(cov, u, sv);
+            }
             float nx = u[2], ny = u[5], nz = u[8];  // U.col(2), ref :66
             if (nz < 0) {                           // ref :68
                 nx *= -1;
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(kBlock) void k_patch_fit(PwppBatch Bt) {
     if (P.enable_RVPF) {
         for (int it = 0; it < P.num_iter; ++it) {
             if (!lpr_valid) {
-                lpr = block_lpr(sh, pts, n, use_cutoff, cutoff, P.num_lpr);
+                lpr = (Bt.debug & 2) ? -1.8 : block_lpr(sh, pts, n, use_cutoff, cutoff, P.num_lpr);
                 lpr_valid = true;
             }
             const double thr = lpr + P.th_seeds_v;  // ref :108
@@ -734,7 +740,7 @@ __global__ __launch_bounds__(kBlock) void k_patch_fit(PwppBatch Bt) {
                 const float4 p = pts[i];
                 if (!pt_stripped(p) && (double)p.z < thr) m.add(p.x, p.y, p.z, qscale);
             }
-            reduce_and_fit(sh, m, wide, P.fxp_shift);
+            reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);
             const float nx = sh.normal[0], ny = sh.normal[1], nz = sh.normal[2];
             const double d = sh.d;
             if (zone == 0 && (double)nz < P.uprightness_thr) {  // ref :489
@@ -756,7 +762,7 @@ __global__ __launch_bounds__(kBlock) void k_patch_fit(PwppBatch Bt) {
     }
 
     // ---- R-GPF, ref :513-543
-    if (!lpr_valid) lpr = block_lpr(sh, pts, n, use_cutoff, cutoff, P.num_lpr);
+    if (!lpr_valid) lpr = (Bt.debug & 2) ? -1.8 : block_lpr(sh, pts, n, use_cutoff, cutoff, P.num_lpr);
     {
         const double thr = lpr + P.th_seeds;  // ref :145
         m.clear();
@@ -764,7 +770,7 @@ __global__ __launch_bounds__(kBlock) void k_patch_fit(PwppBatch Bt) {
             const float4 p = pts[i];
             if (!pt_stripped(p) && (double)p.z < thr) m.add(p.x, p.y, p.z, qscale);
         }
-        reduce_and_fit(sh, m, wide, P.fxp_shift);
+        reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);
     }
     const int ln = lane_id();
     for (int it = 0; it < P.num_iter; ++it) {
@@ -805,7 +811,7 @@ __global__ __launch_bounds__(kBlock) void k_patch_fit(PwppBatch Bt) {
                     plist[n - 1u - (bn + (unsigned)__popcll(mn & lt))] = idx;
             }
         }
-        reduce_and_fit(sh, m, wide, P.fxp_shift);  // ref :537-542
+        reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);  // ref :537-542
     }
 
     if (threadIdx.x == 0) {

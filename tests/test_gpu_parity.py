@@ -1,0 +1,259 @@
+"""Parity of the HIP path (through the C-ABI, libpwpp_hip.so) with the CPU oracle, on a real
+MI355X.  Bar (BASELINE.json north_star): integer index sets bit-exact; plane normals and
+elevations within 1e-4 of the reference CPU path.  What is actually enforced is stronger:
+
+* against oracle/pwpp_oracle.cpp in its fxp flavour (the arithmetic contract of DESIGN.md
+  section 4) EVERYTHING is bit-identical: index sets, per-patch mean / normal / singular values /
+  d, GLE decisions, adaptive thresholds and histories;
+* against the reference's own patchworkpp.cpp (golden fixtures generated from oracle/_ref,
+  eigen-f32 flavour): identical index sets on the six KITTI frames, normals/centres < 1e-4.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import pwpp_hip
+import pwpp_synth
+from conftest import ground_mask
+
+pytestmark = pytest.mark.gpu
+
+NORMAL_TOL = 1e-4  # BASELINE.json: "plane normals/elevations within 1e-4"
+
+
+@pytest.fixture(scope="module")
+def oracle(oracle_built):
+    return oracle_built.restatement()
+
+
+def to_oracle_params(p):
+    o = ol.Params()
+    for name, _ in ol.Params._fields_:
+        v = getattr(p, name)
+        if hasattr(v, "__len__"):
+            for k in range(4):
+                getattr(o, name)[k] = v[k]
+        else:
+            setattr(o, name, v)
+    return o
+
+
+def assert_frame_equal(h, frame, ref, n_points, state_index=None, check_state=True):
+    ng, nn, npatch = h.counts(frame)
+    assert (ng, nn, npatch) == (len(ref.ground_idx), len(ref.nonground_idx), len(ref.centers))
+    g = np.sort(h.ground_indices(frame))
+    n = np.sort(h.nonground_indices(frame))
+    assert np.array_equal(g, np.sort(ref.ground_idx)), "ground index set differs"
+    assert np.array_equal(n, np.sort(ref.nonground_idx)), "non-ground index set differs"
+    assert len(np.intersect1d(g, n)) == 0
+    rec = h.patch_records(frame)
+    assert len(rec) == len(ref.records)
+    for fld in ("bin", "concentric_idx", "n_points", "n_ground", "n_nonground", "decision", "mean", "normal", "sv", "d"):
+        assert np.array_equal(rec[fld], ref.records[fld], equal_nan=True), "patch field %s differs" % fld
+    assert np.array_equal(h.centers(frame), ref.centers, equal_nan=True)
+    assert np.array_equal(h.normals(frame), ref.normals, equal_nan=True)
+    if check_state:
+        st = h.state(frame if state_index is None else state_index)
+        assert st.sensor_height == ref.sensor_height
+        assert list(st.elevation_thr) == list(ref.elevation_thr)
+        assert list(st.flatness_thr) == list(ref.flatness_thr)
+        idx = frame if state_index is None else state_index
+        for ring in range(4):
+            assert np.array_equal(h.history(idx, 0, ring), ref.hist_elev[ring])
+            assert np.array_equal(h.history(idx, 1, ring), ref.hist_flat[ring])
+
+
+def test_kitti_fresh_bitwise_vs_fxp_oracle(kitti, oracle):
+    h = pwpp_hip.Handle()
+    h.estimate_ground_batch(kitti, mode=pwpp_hip.MODE_FRESH)
+    for k, pts in enumerate(kitti):
+        ref = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(pts)
+        assert_frame_equal(h, k, ref, pts.shape[0])
+
+
+def test_kitti_fresh_vs_reference_golden(kitti, golden):
+    """IoU == 1.0 against the reference's own code (eigen-f32 flavour), normals within 1e-4."""
+    h = pwpp_hip.Handle()
+    h.estimate_ground_batch(kitti, mode=pwpp_hip.MODE_FRESH)
+    for k, pts in enumerate(kitti):
+        key = "f32/fresh/%d/" % k
+        mask = np.packbits(ground_mask(h.ground_indices(k), pts.shape[0]))
+        assert np.array_equal(mask, golden[key + "ground_mask"])  # IoU == 1.0
+        assert list(h.counts(k)) == list(golden[key + "counts"])
+        assert np.abs(h.normals(k) - golden[key + "normals"]).max() < NORMAL_TOL
+        assert np.abs(h.centers(k) - golden[key + "centers"]).max() < NORMAL_TOL
+        st = h.state(k)
+        assert abs(st.sensor_height - golden[key + "state"][0]) < NORMAL_TOL
+
+
+def test_kitti_sequence_stateful(kitti, oracle, golden):
+    """One long-lived object over frames 0..5 twice (demo_sequential semantics)."""
+    h = pwpp_hip.Handle()
+    est = ol.Estimator(oracle, arith=ol.ARITH_FXP)
+    for rep in range(2):
+        for k, pts in enumerate(kitti):
+            h.estimate_ground(pts)
+            ref = est.run(pts)
+            assert_frame_equal(h, 0, ref, pts.shape[0], state_index=0)
+            assert h.height() == ref.sensor_height
+            if rep == 0:
+                mask = np.packbits(ground_mask(h.ground_indices(0), pts.shape[0]))
+                assert np.array_equal(mask, golden["f32/seq/%d/ground_mask" % k])
+
+
+def test_multi_stream_lockstep(kitti, oracle):
+    """S independent streams stepped together: stream s sees frames s, s+1, ... (mod 6)."""
+    S = 4
+    h = pwpp_hip.Handle()
+    h.set_num_streams(S)
+    ests = [ol.Estimator(oracle, arith=ol.ARITH_FXP) for _ in range(S)]
+    for t in range(4):
+        frames = [kitti[(s + t) % 6] for s in range(S)]
+        h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_STREAMS)
+        for s in range(S):
+            assert_frame_equal(h, s, ests[s].run(frames[s]), frames[s].shape[0], state_index=s)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_synthetic_with_edge_cases(oracle, seed):
+    pts = pwpp_synth.add_edge_cases(pwpp_synth.make_cloud(seed), seed)
+    h = pwpp_hip.Handle()
+    h.estimate_ground_batch([pts], mode=pwpp_hip.MODE_FRESH)
+    ref = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(pts)
+    assert_frame_equal(h, 0, ref, pts.shape[0])
+    ng, nn, _ = h.counts(0)
+    assert ng + nn == pts.shape[0] - 1  # the z == FLT_MIN point is in neither list (ref :591)
+
+
+PARAM_VARIANTS = [
+    dict(enable_RNR=0), dict(enable_RVPF=0), dict(enable_TGR=0),
+    dict(num_iter=1), dict(num_iter=5), dict(num_lpr=1), dict(num_lpr=64), dict(num_min_pts=1), dict(num_min_pts=200),
+    dict(th_dist=0.2, th_seeds=0.3), dict(uprightness_thr=0.9), dict(max_range=50.0, min_range=1.0),
+    dict(sensor_height=2.0), dict(num_rings_of_interest=2), dict(adaptive_seed_selection_margin=-0.9),
+    dict(sectors=(36, 36, 36, 36)), dict(sectors=(8, 8, 8, 8), rings=(1, 1, 1, 1)), dict(rings=(3, 5, 2, 6)),
+    dict(elev=(-1.5, -1.4, -1.3, -1.2), flat=(1e-4, 2e-4, 3e-4, 4e-4)),
+]
+
+
+@pytest.mark.parametrize("variant", PARAM_VARIANTS, ids=lambda v: ",".join("%s=%s" % kv for kv in v.items()))
+def test_parameter_variants(kitti, oracle, variant):
+    p = pwpp_hip.default_params()
+    for k, v in variant.items():
+        if k == "sectors":
+            for i in range(4):
+                p.num_sectors_each_zone[i] = v[i]
+        elif k == "rings":
+            for i in range(4):
+                p.num_rings_each_zone[i] = v[i]
+        elif k == "elev":
+            for i in range(4):
+                p.elevation_thr[i] = v[i]
+        elif k == "flat":
+            for i in range(4):
+                p.flatness_thr[i] = v[i]
+        else:
+            setattr(p, k, v)
+    h = pwpp_hip.Handle(p)
+    est = ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP)
+    syn = pwpp_synth.add_edge_cases(pwpp_synth.make_cloud(5, beams=48, azimuth_steps=1500), 5)
+    for pts in (kitti[0], syn, kitti[4]):
+        h.estimate_ground(pts)
+        assert_frame_equal(h, 0, est.run(pts), pts.shape[0], state_index=0)
+
+
+def test_layouts_and_three_columns(kitti, oracle):
+    p = pwpp_hip.default_params()
+    p.enable_RNR = 0
+    pts = kitti[2]
+    ref = ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(pts)
+    for arr in (pts, np.asfortranarray(pts), pts[:, :3].copy(), np.asfortranarray(pts[:, :3])):
+        h = pwpp_hip.Handle(p)
+        h.estimate_ground(arr)
+        assert_frame_equal(h, 0, ref, pts.shape[0], state_index=0)
+    # with RNR on, a 3-column cloud skips RNR (ref :379-382) but must still work
+    h = pwpp_hip.Handle()
+    h.estimate_ground(pts[:, :3].copy())
+    ref3 = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(pts[:, :3].copy())
+    assert_frame_equal(h, 0, ref3, pts.shape[0], state_index=0)
+
+
+def test_xyz_getters_align_with_indices(kitti):
+    h = pwpp_hip.Handle()
+    h.estimate_ground(kitti[3])
+    assert np.array_equal(h.ground(), kitti[3][h.ground_indices(), :3])
+    assert np.array_equal(h.nonground(), kitti[3][h.nonground_indices(), :3])
+
+
+def test_ragged_and_degenerate_frames(oracle):
+    rng = np.random.default_rng(0)
+    base = pwpp_synth.make_cloud(9, beams=16, azimuth_steps=500)
+    frames = [
+        base, base[:1], base[:9], base[:10], base[:11], np.zeros((0, 4), np.float32),
+        np.tile(np.array([[10.0, 3.0, -1.7, 0.5]], np.float32), (500, 1)),           # 500 identical points
+        np.concatenate([base[:3000], np.full((5, 4), np.nan, np.float32)]),             # NaN rows -> out of range
+        (base[:2000] * np.array([1, 1, 0, 1], np.float32)),                             # all z == 0
+        np.concatenate([np.array([[6.0, 2.0, -9.0, 0.9]], np.float32), base[:4000]]),   # one deep outlier
+        rng.uniform(-90, 90, (5000, 4)).astype(np.float32),                             # noise
+    ]
+    h = pwpp_hip.Handle()
+    h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+    for k, pts in enumerate(frames):
+        ref = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(pts) if len(pts) else None
+        if ref is None:
+            assert h.counts(k) == (0, 0, 0)
+            continue
+        assert_frame_equal(h, k, ref, pts.shape[0])
+
+
+def test_dense_128_beam_cloud_36_sectors(oracle):
+    """BASELINE.json configs[4]: ~500k-point cloud, 36-sector CZM (bins far beyond LDS size)."""
+    p = pwpp_hip.default_params()
+    for i in range(4):
+        p.num_sectors_each_zone[i] = 36
+    pts = pwpp_synth.make_dense_cloud(3)
+    assert pts.shape[0] > 400000
+    h = pwpp_hip.Handle(p)
+    h.estimate_ground(pts)
+    ref = ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(pts)
+    assert_frame_equal(h, 0, ref, pts.shape[0], state_index=0)
+    h2 = pwpp_hip.Handle()  # default 16 zone-0 sectors: ~30k-point bins
+    h2.estimate_ground(pts)
+    ref2 = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(pts)
+    assert_frame_equal(h2, 0, ref2, pts.shape[0], state_index=0)
+
+
+def test_large_batch_properties(kitti):
+    """256 frames in one launch set: replays agree with each other and with the single-frame
+    path, every frame is partitioned (size-independent properties, no oracle needed)."""
+    F = 256
+    frames = [kitti[i % 6] for i in range(F)]
+    h = pwpp_hip.Handle()
+    h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+    counts = h.all_counts()
+    for i in range(F):
+        assert tuple(counts[i, :3]) == tuple(counts[i % 6, :3])
+        assert counts[i, 0] + counts[i, 1] + counts[i, 5] == frames[i].shape[0]
+    for i in (6, 100, 255):
+        assert np.array_equal(np.sort(h.ground_indices(i)), np.sort(h.ground_indices(i % 6)))
+        assert np.array_equal(h.normals(i), h.normals(i % 6))
+    g = h.ground_indices(255)
+    n = h.nonground_indices(255)
+    assert np.array_equal(np.sort(np.concatenate([g, n])), np.arange(frames[255].shape[0]))
+
+
+def test_pybind_module_end_to_end(kitti, golden):
+    import pypatchworkpp
+    params = pypatchworkpp.Parameters()
+    pw = pypatchworkpp.patchworkpp(params)
+    for k in range(3):
+        pw.estimateGround(kitti[k])
+        gi = pw.getGroundIndices()
+        assert gi.dtype == np.int32 and pw.getGround().shape == (len(gi), 3)
+        mask = np.packbits(ground_mask(gi, kitti[k].shape[0]))
+        assert np.array_equal(mask, golden["f32/seq/%d/ground_mask" % k])
+        assert np.array_equal(pw.getGround(), kitti[k][gi, :3])
+        assert len(gi) + len(pw.getNongroundIndices()) == kitti[k].shape[0]
+        assert pw.getCenters().shape == pw.getNormals().shape
+        assert abs(pw.getHeight() - golden["f32/seq/%d/state" % k][0]) < 1e-4
+        assert pw.getTimeTaken() > 0
+    pw.estimateGround(np.asfortranarray(kitti[0]).astype(np.float64))  # any array convertible to float32
