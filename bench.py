@@ -85,21 +85,19 @@ def main():
     ap.add_argument("--workload", default="kitti", choices=["kitti", "dense"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-events", action="store_true")
+    ap.add_argument("--skip-latency", action="store_true")
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import pwpp_dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+    world, rank, local_rank = pwpp_dist.init("nccl", dev)  # RCCL; no-op for a single process
 
     import pwpp_hip
 
@@ -108,12 +106,13 @@ def main():
         args.frames = 128
     F = args.frames
     # F distinct device buffers carved from one allocation; each frame starts 16-byte aligned
-    ns = [src[(i + rank) % len(src)].shape[0] for i in range(F)]
+    which = pwpp_dist.shard_sources(len(src), F, rank)
+    ns = [src[j].shape[0] for j in which]
     offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
     big = torch.empty((int(offs[-1]), 4), dtype=torch.float32, device=dev)
     src_dev = [torch.from_numpy(s).to(dev) for s in src]
     for i in range(F):
-        big[offs[i]:offs[i + 1]].copy_(src_dev[(i + rank) % len(src)])
+        big[offs[i]:offs[i + 1]].copy_(src_dev[which[i]])
     torch.cuda.synchronize()
     ptrs = [big.data_ptr() + int(offs[i]) * 16 for i in range(F)]
 
@@ -134,42 +133,36 @@ def main():
         assert counts[i, 0] + counts[i, 1] + counts[i, 5] == ns[i], "partition property violated in frame %d" % i
     by_src = {}
     for i in range(F):
-        by_src.setdefault((i + rank) % len(src), set()).add(tuple(int(v) for v in counts[i, :3]))
+        by_src.setdefault(which[i], set()).add(tuple(int(v) for v in counts[i, :3]))
     assert all(len(v) == 1 for v in by_src.values()), "replayed frames disagree: %r" % by_src
 
     if not args.no_profile_events:
         h.set_profiling(True)
         h.reset_kernel_profile()
-    if world > 1:
-        dist.barrier()
+    pwpp_dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    pwpp_dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, total_frames = pwpp_dist.aggregate(elapsed, F * args.steps, dev)  # MAX time, SUM frames over ranks
     prof = h.kernel_profile() if not args.no_profile_events else {}
     h.set_profiling(False)
 
     # single-frame latency (configs[1]): one KITTI frame, device-resident, fresh state
     one = h.make_device_batch(ptrs[:1], ns[:1])
     lat = []
-    for _ in range(30):
+    for _ in range(0 if args.skip_latency else 30):
         t1 = time.perf_counter()
         h.launch_device_batch(one, cols=4, mode=pwpp_hip.MODE_FRESH)
         h.synchronize()
         lat.append(time.perf_counter() - t1)
     lat_gpu_us = h.time_us()
-    lat = sorted(lat)[len(lat) // 2]
+    lat = sorted(lat)[len(lat) // 2] if lat else 0.0
 
     if rank == 0:
-        total_frames = F * args.steps * world
         fps = total_frames / elapsed
         b_alg = float(sum(20 * ns[i] + 24 * int(n_patches[i]) for i in range(F)))  # bytes per batch (one GPU)
         out = {
@@ -210,8 +203,7 @@ def main():
             except Exception as e:  # the checker libs are optional at bench time
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    pwpp_dist.finalize()
 
 
 if __name__ == "__main__":

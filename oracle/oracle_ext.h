@@ -37,6 +37,7 @@ void pwo_ext_set_state(void *h, double sensor_height, const double *elevation_th
 void pwo_ext_jacobi(const float *cov9_rowmajor, float *u9_rowmajor, float *sv3);
 int pwo_ext_fxp_shift(double max_range);
 int32_t pwo_ext_quantise(float v, int shift);
+long pwo_ext_max_sweeps(int reset); /* largest Jacobi sweep count of one fit since the last reset (this thread) */
 
 #ifdef __cplusplus
 }

@@ -87,6 +87,8 @@ int32_t fxp_quantise(float v, int s) {  // Q(v)
 // Eigen/src/Jacobi/Jacobi.h makeJacobi() / apply_rotation_in_the_plane().
 // a is row-major 3x3; u gets the left singular vectors in columns (row-major 3x3).
 // ---------------------------------------------------------------------------------
+thread_local long g_max_sweeps = 0;
+
 void jacobi_svd3(const float a[9], float u[9], float sv[3], long *sweeps) {
     const float tiny = FLT_MIN, precision = 2.0f * FLT_EPSILON;
     float scale = 0.0f;
@@ -110,6 +112,7 @@ void jacobi_svd3(const float a[9], float u[9], float sv[3], long *sweeps) {
     for (int sweep = 0; sweep < 1000; ++sweep) {
         bool finished = true;
         if (sweeps) ++*sweeps;
+        if (sweep + 1 > g_max_sweeps) g_max_sweeps = sweep + 1;
         for (int p = 1; p < 3; ++p) {
             for (int q = 0; q < p; ++q) {
                 const float thr = f_max(tiny, precision * max_diag);
@@ -718,6 +721,11 @@ void pwo_ext_set_state(void *h, double sensor_height, const double *elev, const 
 }
 void pwo_ext_jacobi(const float *cov9, float *u9, float *sv3) { jacobi_svd3(cov9, u9, sv3, nullptr); }
 int pwo_ext_fxp_shift(double max_range) { return fxp_shift_for(max_range); }
+long pwo_ext_max_sweeps(int reset) {
+    const long v = g_max_sweeps;
+    if (reset) g_max_sweeps = 0;
+    return v;
+}
 int32_t pwo_ext_quantise(float v, int shift) { return fxp_quantise(v, shift); }
 
 double pwo_bench(const pwo_params *p, int arith, const float *const *frames, const int *n_points, int cols,

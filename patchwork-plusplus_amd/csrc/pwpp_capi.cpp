@@ -87,8 +87,9 @@ struct PinnedBuf {
     }
 };
 
-const char *kKernelNames[PWPP_NUM_KERNELS] = {"k_czm_bin", "k_czm_scan", "k_czm_scatter",
-                                              "k_patch_fit", "k_gle_tgr", "k_emit"};
+const char *kKernelNames[PWPP_NUM_KERNELS] = {"k_czm_bin", "k_czm_scan", "k_czm_scatter", "k_fit_rows<16>",
+                                              "k_fit_rows<32>", "k_fit_rows<64>", "k_fit_wave",
+                                              "k_fit_stream", "k_gle_tgr", "k_emit"};
 
 }  // namespace
 
@@ -122,11 +123,14 @@ struct pwpp_handle {
     DevBuf<int32_t> d_plist;
     DevBuf<int32_t> d_out;
     DevBuf<uint32_t> d_bins;  // 5 slabs of frames*(B+2): count, off, cursor, dst_a, dst_b
+    DevBuf<uint32_t> d_cls_start;  // frames * 8
+    DevBuf<uint16_t> d_cls_list;   // frames * B
     DevBuf<PwppPatchRec> d_recs;
     DevBuf<float> d_centers, d_normals;
     DevBuf<PwppFrameResult> d_results;
     PinnedBuf<PwppFrameResult> h_results;
     DevBuf<float> d_xyz;  // gather scratch
+    DevBuf<unsigned long long> d_dbg;  // timing probes (PWPP_DEBUG_FLAGS & 4)
 
     // adaptive state: streams (long history slabs) and per-frame fresh outputs (short slabs)
     int num_streams = 0;
@@ -375,11 +379,14 @@ int pwpp_destroy(pwpp_handle *h) {
     h->d_out.release();
     h->d_bins.release();
     h->d_recs.release();
+    h->d_cls_start.release();
+    h->d_cls_list.release();
     h->d_centers.release();
     h->d_normals.release();
     h->d_results.release();
     h->h_results.release();
     h->d_xyz.release();
+    h->d_dbg.release();
     h->d_st_stream.release();
     h->d_st_fresh.release();
     h->d_hist_stream.release();
@@ -431,9 +438,12 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     if ((rc = h->d_out.ensure(tp))) return rc;
     if ((rc = h->d_bins.ensure((size_t)frames * NB * 5))) return rc;
     if ((rc = h->d_recs.ensure((size_t)frames * B))) return rc;
+    if ((rc = h->d_cls_start.ensure((size_t)frames * 8))) return rc;
+    if ((rc = h->d_cls_list.ensure((size_t)frames * B))) return rc;
     if ((rc = h->d_centers.ensure((size_t)frames * B * 3))) return rc;
     if ((rc = h->d_normals.ensure((size_t)frames * B * 3))) return rc;
     if ((rc = h->d_results.ensure((size_t)frames))) return rc;
+    if ((rc = h->d_dbg.ensure(64))) return rc;
     if ((rc = h->h_results.ensure((size_t)frames))) return rc;
     if (mode == PWPP_MODE_FRESH) {
         if ((rc = h->d_st_fresh.ensure((size_t)frames))) return rc;
@@ -499,6 +509,8 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     bt.bin_cursor = h->d_bins.p + 2 * slab;
     bt.dst_a = h->d_bins.p + 3 * slab;
     bt.dst_b = h->d_bins.p + 4 * slab;
+    bt.cls_start = h->d_cls_start.p;
+    bt.cls_list = h->d_cls_list.p;
     bt.sorted = h->d_sorted.p;
     bt.plist = h->d_plist.p;
     bt.recs = h->d_recs.p;
@@ -506,12 +518,14 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     bt.centers = h->d_centers.p;
     bt.normals = h->d_normals.p;
     bt.results = h->d_results.p;
+    bt.dbg = h->d_dbg.p;
 
     HIPCHK(hipEventRecord(h->ev_begin, h->stream));
     // zero the histogram, the scatter cursors and the per-frame result counters
     HIPCHK(hipMemsetAsync(bt.bin_count, 0, slab * sizeof(uint32_t), h->stream));
     HIPCHK(hipMemsetAsync(bt.bin_cursor, 0, slab * sizeof(uint32_t), h->stream));
     HIPCHK(hipMemsetAsync(bt.results, 0, (size_t)frames * sizeof(PwppFrameResult), h->stream));
+    if (bt.debug & 4) HIPCHK(hipMemsetAsync(bt.dbg, 0, 64 * sizeof(unsigned long long), h->stream));
     const int lrc = pwpp_launch_pipeline(&bt, h->stream, h->profiling ? h->ev_k : nullptr);
     if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
@@ -728,5 +742,16 @@ int pwpp_reset_kernel_profile(pwpp_handle *h) {
     return PWPP_OK;
 }
 int pwpp_get_fxp_shift(pwpp_handle *h) { return h ? h->dp.fxp_shift : PWPP_E_ARG; }
+
+/* not part of the public header: timing probes of the last call (PWPP_DEBUG_FLAGS & 4) */
+int pwpp_debug_read(pwpp_handle *h, unsigned long long *out64) {
+    if (!h || !out64) return fail(PWPP_E_ARG, "null argument");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    if (!h->d_dbg.p) return fail(PWPP_E_STATE, "no probes");
+    HIPCHK(hipMemcpy(out64, h->d_dbg.p, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PWPP_OK;
+}
 
 }  // extern "C"

@@ -1,0 +1,334 @@
+// pwpp_common.hpp -- device helpers shared by the gfx950 kernels of this library.
+// The arithmetic helpers implement the contract of DESIGN.md section 4; citations are
+// /root/reference/cpp/patchworkpp/src/patchworkpp.cpp unless a header is named.
+#ifndef PWPP_COMMON_HPP
+#define PWPP_COMMON_HPP
+
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <hip/hip_runtime.h>
+
+#include "pwpp_dev.h"
+
+#define PWPP_LAYOUT_ROW_MAJOR 0
+#define PWPP_LAYOUT_COL_MAJOR 1
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void load_point(const PwppFrameDesc &fd, int i, float &x, float &y, float &z, float &w) {
+    if (fd.layout == PWPP_LAYOUT_ROW_MAJOR) {
+        if (fd.cols == 4) {
+            const float4 v = reinterpret_cast<const float4 *>(fd.pts)[i];  // 16 B/lane, 1 KiB per wave instruction
+            x = v.x;
+            y = v.y;
+            z = v.z;
+            w = v.w;
+        } else {
+            const float *p = fd.pts + (size_t)3 * (size_t)i;
+            x = p[0];
+            y = p[1];
+            z = p[2];
+            w = 0.0f;
+        }
+    } else {  // column-major planes (Eigen::MatrixXf storage)
+        const size_t n = (size_t)fd.n;
+        x = fd.pts[i];
+        y = fd.pts[n + i];
+        z = fd.pts[2 * n + i];
+        w = fd.cols == 4 ? fd.pts[3 * n + i] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ double i128_to_double(__int128 v) {  // one rounding, to nearest even
+    const bool neg = v < 0;
+    const unsigned __int128 a = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
+    const unsigned long long hi = (unsigned long long)(a >> 64), lo = (unsigned long long)a;
+    double r;
+    if (hi == 0) {
+        r = (double)lo;
+    } else {
+        const int sh = 64 - __clzll((long long)hi);  // bits above bit 63
+        unsigned long long top = (unsigned long long)(a >> sh);
+        const unsigned __int128 rest = a & ((((unsigned __int128)1) << sh) - 1);
+        top |= (rest != 0) ? 1ull : 0ull;  // sticky bit, far below the 53-bit mantissa
+        r = ldexp((double)top, sh);
+    }
+    return neg ? -r : r;
+}
+
+__device__ __forceinline__ float f_abs(float v) { return v < 0.0f ? -v : v; }
+__device__ __forceinline__ float f_max(float a, float b) { return a < b ? b : a; }
+
+// Eigen 3.4.0 JacobiSVD<MatrixX3f>(cov, ComputeFullU) as used at ref :62 -- two-sided Jacobi,
+// real square case, float.  a: row-major symmetric 3x3.  Outputs U (row-major) and the
+// singular values sorted descending.  Same operation sequence as oracle/pwpp_oracle.cpp
+// jacobi_svd3 and oracle/eigen_shim (all three are compared bitwise by the tests).
+__device__ void jacobi_svd3(const float a[9], float u[9], float sv[3]) {
+    const float tiny = FLT_MIN, precision = 2.0f * FLT_EPSILON;
+    float scale = 0.0f;
+    bool invalid = false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float v = f_abs(a[k]);
+        if (!(v == v) || v > FLT_MAX) invalid = true;
+        if (v > scale) scale = v;
+    }
+    if (invalid) {
+        const float nanv = __uint_as_float(0x7fc00000u);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) u[k] = nanv;
+        sv[0] = sv[1] = sv[2] = nanv;
+        return;
+    }
+    if (scale == 0.0f) scale = 1.0f;
+    float w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = a[k] / scale;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) u[k] = (k % 4 == 0) ? 1.0f : 0.0f;
+    float max_diag = f_max(f_abs(w[0]), f_max(f_abs(w[4]), f_abs(w[8])));
+
+    for (int sweep = 0; sweep < 1000; ++sweep) {
+        bool finished = true;
+#pragma unroll
+        for (int p = 1; p < 3; ++p) {
+#pragma unroll
+            for (int q = 0; q < p; ++q) {
+                const float thr = f_max(tiny, precision * max_diag);
+                if (f_abs(w[p * 3 + q]) > thr || f_abs(w[q * 3 + p]) > thr) {
+                    finished = false;
+                    const float m00 = w[p * 3 + p], m01 = w[p * 3 + q], m10 = w[q * 3 + p], m11 = w[q * 3 + q];
+                    const float t = m00 + m11, d = m10 - m01;
+                    float c1, s1;
+                    if (f_abs(d) < tiny) {
+                        s1 = 0.0f;
+                        c1 = 1.0f;
+                    } else {
+                        const float r = t / d;
+                        const float h = sqrtf(1.0f + r * r);
+                        s1 = 1.0f / h;
+                        c1 = r / h;
+                    }
+                    const float b00 = c1 * m00 + s1 * m10;
+                    const float b01 = c1 * m01 + s1 * m11;
+                    const float b11 = -s1 * m01 + c1 * m11;
+                    float cr, sr;
+                    const float deno = 2.0f * f_abs(b01);
+                    if (deno < tiny) {
+                        cr = 1.0f;
+                        sr = 0.0f;
+                    } else {
+                        const float tau = (b00 - b11) / deno;
+                        const float ww = sqrtf(tau * tau + 1.0f);
+                        const float tt = (tau > 0.0f) ? 1.0f / (tau + ww) : 1.0f / (tau - ww);
+                        const float sign_t = tt > 0.0f ? 1.0f : -1.0f;
+                        const float nn = 1.0f / sqrtf(tt * tt + 1.0f);
+                        sr = -sign_t * (b01 / f_abs(b01)) * f_abs(tt) * nn;
+                        cr = nn;
+                    }
+                    const float cl = c1 * cr - s1 * (-sr);
+                    const float sl = c1 * (-sr) + s1 * cr;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float x = w[p * 3 + k], y = w[q * 3 + k];
+                        w[p * 3 + k] = cl * x + sl * y;
+                        w[q * 3 + k] = -sl * x + cl * y;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float x = u[k * 3 + p], y = u[k * 3 + q];
+                        u[k * 3 + p] = cl * x - (-sl) * y;
+                        u[k * 3 + q] = (-sl) * x + cl * y;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float x = w[k * 3 + p], y = w[k * 3 + q];
+                        w[k * 3 + p] = cr * x - sr * y;
+                        w[k * 3 + q] = sr * x + cr * y;
+                    }
+                    max_diag = f_max(max_diag, f_max(f_abs(w[p * 3 + p]), f_abs(w[q * 3 + q])));
+                }
+            }
+        }
+        if (finished) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float dgl = w[i * 3 + i];
+        sv[i] = f_abs(dgl);
+        if (dgl < 0.0f) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) u[k * 3 + i] = -u[k * 3 + i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sv[i] *= scale;
+    bool stop = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (!stop) {
+            int pos = i;
+#pragma unroll
+            for (int j = i + 1; j < 3; ++j)
+                if (sv[j] > sv[pos]) pos = j;
+            if (sv[pos] == 0.0f) {
+                stop = true;
+            } else if (pos != i) {
+                const float ts = sv[i];
+                sv[i] = sv[pos];
+                sv[pos] = ts;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float tu = u[k * 3 + i];
+                    u[k * 3 + i] = u[k * 3 + pos];
+                    u[k * 3 + pos] = tu;
+                }
+            }
+        }
+    }
+}
+
+// Q(v)
+__device__ __forceinline__ int fxp_quantise(float v, float scale) {
+    float t = v * scale;
+    if (!(t == t)) return 0;
+    t = rintf(t);
+    if (t > 8388607.0f) t = 8388607.0f;
+    if (t < -8388607.0f) t = -8388607.0f;
+    return (int)t;
+}
+
+// order-preserving map float -> uint32 (for the lowest-point selection)
+__device__ __forceinline__ unsigned z_key(float z) {
+    const unsigned b = __float_as_uint(z);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_z(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+struct Moments {  // per-lane partial sums of the quantised coordinates
+    long long n, s1[3], s2[6];
+    __device__ __forceinline__ void clear() {
+        n = 0;
+        s1[0] = s1[1] = s1[2] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s2[k] = 0;
+    }
+    __device__ __forceinline__ void add(float x, float y, float z, float scale) {
+        const int qx = fxp_quantise(x, scale), qy = fxp_quantise(y, scale), qz = fxp_quantise(z, scale);
+        n += 1;
+        s1[0] += qx;
+        s1[1] += qy;
+        s1[2] += qz;
+        s2[0] += (long long)qx * qx;
+        s2[1] += (long long)qx * qy;
+        s2[2] += (long long)qx * qz;
+        s2[3] += (long long)qy * qy;
+        s2[4] += (long long)qy * qz;
+        s2[5] += (long long)qz * qz;
+    }
+};
+
+
+// ------------------------------------------------------------------------------------------
+// plane of ref :47-75 from the exact integer moments of a point set:
+//   mean_a = float( (S1_a / n) * 2^-s )
+//   cov_ab = float( ((n*S2_ab - S1_a*S1_b) / (n*(n-1))) * 2^-2s )     numerator exact in 128 bits
+// then Eigen's JacobiSVD on the float covariance, normal = U.col(2) flipped to z >= 0 (:66-68),
+// d = -(normal . mean) as a float dot product widened to double (:74).
+// ------------------------------------------------------------------------------------------
+struct PlaneFit {
+    float nx, ny, nz;
+    float mean[3];
+    float sv[3];
+    double d;
+};
+
+__device__ __forceinline__ void plane_from_totals(long long n, const long long s1[3], const __int128 s2[6], int shift,
+                                                  int debug, PlaneFit &out) {
+    const double inv = 1.0 / (double)(1 << shift);
+    const double den = (double)n * (double)(n - 1);
+    float mean[3], cov[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) mean[a] = (float)(((double)s1[a] / (double)n) * inv);
+    const int map[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = a; b < 3; ++b) {
+            const __int128 num = (__int128)n * s2[map[a * 3 + b]] - (__int128)s1[a] * (__int128)s1[b];
+            const float c = (float)((i128_to_double(num) / den) * (inv * inv));
+            cov[a * 3 + b] = c;
+            cov[b * 3 + a] = c;
+        }
+    }
+    float u[9], sv[3];
+    if (debug & 1) {  // timing ablation only: no eigen-solve
+#pragma unroll
+        for (int k = 0; k < 9; ++k) u[k] = cov[k];
+        sv[0] = cov[0];
+        sv[1] = cov[4];
+        sv[2] = cov[8];
+        u[2] = 0.01f;
+        u[5] = 0.01f;
+        u[8] = 0.9999f;
+    } else {
+        jacobi_svd3(cov, u, sv);
+    }
+    float nx = u[2], ny = u[5], nz = u[8];  // U.col(2), ref :66
+    if (nz < 0) {                           // ref :68
+        nx *= -1;
+        ny *= -1;
+        nz *= -1;
+    }
+    const float dot = nx * mean[0] + ny * mean[1] + nz * mean[2];  // ref :74, float dot
+    out.nx = nx;
+    out.ny = ny;
+    out.nz = nz;
+    out.mean[0] = mean[0];
+    out.mean[1] = mean[1];
+    out.mean[2] = mean[2];
+    out.sv[0] = sv[0];
+    out.sv[1] = sv[1];
+    out.sv[2] = sv[2];
+    out.d = -dot;
+}
+
+// ref :551-554  (float products, float adds left to right, one double add)
+__device__ __forceinline__ double plane_dist(float nx, float ny, float nz, double d, float x, float y, float z) {
+    return nx * x + ny * y + nz * z + d;
+}
+
+// patch size classes of the fit kernels
+#define PWPP_NUM_CLASSES 6
+__device__ __forceinline__ int patch_class(unsigned n) {
+    if (n <= 128u) return 0;    // k_fit_rows<16>: 16 lanes per patch, 4 patches per wave, points parked in LDS
+    if (n <= 256u) return 1;    // k_fit_rows<32>
+    if (n <= 512u) return 2;    // k_fit_rows<64>: one wave
+    if (n <= 16384u) return 3;  // k_fit_wave: one wave, points streamed from L2 per stage
+    return 5;                   // k_fit_stream: one workgroup, radix-select LPR (class 4 is unused)
+}
+
+}  // namespace
+
+#endif

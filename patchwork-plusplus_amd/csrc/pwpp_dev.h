@@ -84,6 +84,8 @@ struct PwppBatch {
     uint32_t *bin_count;         // [frames][B+2]
     uint32_t *bin_off;           // [frames][B+2] exclusive scan of bin_count
     uint32_t *bin_cursor;        // [frames][B+2]
+    uint32_t *cls_start;         // [frames][8] first entry of each size class in cls_list (7 used)
+    uint16_t *cls_list;          // [frames][B] patch bins grouped by size class
     float4 *sorted;              // [total points] {x,y,z,bits(idx)} grouped by bin; bit 31 of w = stripped by R-VPF
     int32_t *plist;              // [total points] per patch: ground candidates from the front, non-ground from the back
     PwppPatchRec *recs;          // [frames][B]
@@ -93,6 +95,7 @@ struct PwppBatch {
     float *centers;              // [frames][B][3] compacted to n_patches rows
     float *normals;              // [frames][B][3]
     PwppFrameResult *results;    // [frames]
+    unsigned long long *dbg;     // [64] timing probes, only written when debug & 4
 };
 
 #endif

@@ -1,0 +1,1056 @@
+// pwpp_fit.hip -- K4: per-patch plane fitting (LPR seeds, R-VPF, R-GPF, final plane), the
+// 58 % of the reference's CPU time (ref :467-549 extract_piecewiseground, :77-149
+// extract_initial_seeds, :47-75 estimate_plane, :551-554 calc_point_to_plane_d, plus the
+// per-bin std::sort of :199 which this design does not need).
+//
+// A patch is a CZM bin with >= num_min_pts points: 10 ... ~30 000 points, median ~170.  Its
+// work is a chain of 4-7 dependent plane fits, each = one pass over the points + a serial
+// 3x3 eigen-solve.  The points of a patch are read from HBM/L2 ONCE into registers (8 per
+// lane) and stay there for the whole chain; how many lanes a patch gets depends on its size
+// (k_czm_scan sorts the patches of a frame into size classes):
+//
+//   class 0..2  n <= 128 / 256 / 512   k_fit_rows<16|32|64>: 16/32/64 lanes per patch, so one
+//                                      wave carries 4/2/1 patches; everything is wave-local
+//                                      (shuffles, ballots), no LDS, no barriers
+//   class 3..4  n <= 2048 / 8192       k_fit_block<256|1024>: one workgroup per patch, cross-wave
+//                                      sums through LDS, 2 barriers per fit
+//   class 5     larger                 k_fit_stream: points streamed from L2/HBM on every pass
+//
+// All reductions are integer, so every variant produces bit-identical
+// planes and the same index sets whatever the lane count.
+#include <stdlib.h>
+#include <string.h>
+
+#include "pwpp_common.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kPPT = 8;  // points per lane held in registers
+
+// ------------------------------------------------------------------------------------------
+// row = G consecutive lanes of a wave working on one patch
+// ------------------------------------------------------------------------------------------
+// Cross-lane primitives.  The four steps inside a 16-lane DPP row are register-to-register
+// (v_*_dpp quad_perm / row_half_mirror / row_mirror, ~8 cycles each); 16 <-> 16 goes through
+// ds_swizzle(SWAP,16) and the two 32-lane halves are combined with v_readlane + scalar ALU.
+// A 64-lane all-reduce is ~8 instructions instead of 6 dependent ds_bpermute round trips.
+#define PWPP_DPP(x, ctrl) __builtin_amdgcn_update_dpp(0, (x), (ctrl), 0xF, 0xF, true)
+#define PWPP_DPP_XOR1 0xB1   // quad_perm [1,0,3,2]
+#define PWPP_DPP_XOR2 0x4E   // quad_perm [2,3,0,1]
+#define PWPP_DPP_HMIR 0x141  // row_half_mirror
+#define PWPP_DPP_MIR 0x140   // row_mirror
+#define PWPP_SWZ16 0x401F    // ds_swizzle BITMASK_PERM xor 16
+
+template <int G>
+struct Row {
+    static_assert(G == 16 || G == 32 || G == 64, "row width");
+    static constexpr unsigned long long kMask = (G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull);
+    __device__ static __forceinline__ int first_lane() { return lane_id() & ~(G - 1); }
+
+    __device__ static __forceinline__ unsigned min_u32(unsigned v) {
+        int x = (int)v, t;
+        t = PWPP_DPP(x, PWPP_DPP_XOR1); x = (unsigned)t < (unsigned)x ? t : x;
+        t = PWPP_DPP(x, PWPP_DPP_XOR2); x = (unsigned)t < (unsigned)x ? t : x;
+        t = PWPP_DPP(x, PWPP_DPP_HMIR); x = (unsigned)t < (unsigned)x ? t : x;
+        t = PWPP_DPP(x, PWPP_DPP_MIR); x = (unsigned)t < (unsigned)x ? t : x;
+        if (G >= 32) {
+            t = __builtin_amdgcn_ds_swizzle(x, PWPP_SWZ16);
+            x = (unsigned)t < (unsigned)x ? t : x;
+        }
+        if (G == 64) {
+            const unsigned a = (unsigned)__builtin_amdgcn_readlane(x, 0), b = (unsigned)__builtin_amdgcn_readlane(x, 32);
+            x = (int)(a < b ? a : b);
+        }
+        return (unsigned)x;
+    }
+    __device__ static __forceinline__ int sum_i32(int x) {
+        x += PWPP_DPP(x, PWPP_DPP_XOR1);
+        x += PWPP_DPP(x, PWPP_DPP_XOR2);
+        x += PWPP_DPP(x, PWPP_DPP_HMIR);
+        x += PWPP_DPP(x, PWPP_DPP_MIR);
+        if (G >= 32) x += __builtin_amdgcn_ds_swizzle(x, PWPP_SWZ16);
+        if (G == 64) x = __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 32);
+        return x;
+    }
+    __device__ static __forceinline__ long long step64(long long v, int ctrl_kind) {
+        int lo = (int)(unsigned)(unsigned long long)v, hi = (int)((unsigned long long)v >> 32);
+        int tl, th;
+        switch (ctrl_kind) {
+            case 0: tl = PWPP_DPP(lo, PWPP_DPP_XOR1); th = PWPP_DPP(hi, PWPP_DPP_XOR1); break;
+            case 1: tl = PWPP_DPP(lo, PWPP_DPP_XOR2); th = PWPP_DPP(hi, PWPP_DPP_XOR2); break;
+            case 2: tl = PWPP_DPP(lo, PWPP_DPP_HMIR); th = PWPP_DPP(hi, PWPP_DPP_HMIR); break;
+            case 3: tl = PWPP_DPP(lo, PWPP_DPP_MIR); th = PWPP_DPP(hi, PWPP_DPP_MIR); break;
+            default: tl = __builtin_amdgcn_ds_swizzle(lo, PWPP_SWZ16); th = __builtin_amdgcn_ds_swizzle(hi, PWPP_SWZ16); break;
+        }
+        return v + (long long)(((unsigned long long)(unsigned)th << 32) | (unsigned long long)(unsigned)tl);
+    }
+    __device__ static __forceinline__ long long sum_i64(long long v) {
+        v = step64(v, 0);
+        v = step64(v, 1);
+        v = step64(v, 2);
+        v = step64(v, 3);
+        if (G >= 32) v = step64(v, 4);
+        if (G == 64) {
+            const int lo = (int)(unsigned)(unsigned long long)v, hi = (int)((unsigned long long)v >> 32);
+            const unsigned long long a = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, 0) << 32) |
+                                         (unsigned)__builtin_amdgcn_readlane(lo, 0);
+            const unsigned long long b = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, 32) << 32) |
+                                         (unsigned)__builtin_amdgcn_readlane(lo, 32);
+            v = (long long)(a + b);
+        }
+        return v;
+    }
+    __device__ static __forceinline__ unsigned long long ballot(bool p) {
+        return (__ballot(p) >> first_lane()) & kMask;
+    }
+    // exclusive prefix sum over the row; total = row sum
+    __device__ static __forceinline__ unsigned excl_scan(unsigned v, unsigned &total) {
+        const int j = lane_id() & (G - 1);
+        unsigned incl = v;
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) {
+            const unsigned t = (unsigned)__shfl_up((int)incl, o, G);
+            if (j >= o) incl += t;
+        }
+        total = (unsigned)__shfl((int)incl, G - 1, G);
+        return incl - v;
+    }
+};
+
+// 8-key sorting network (19 compare-exchanges), ascending
+__device__ __forceinline__ void ce(unsigned &a, unsigned &b) {
+    const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo;
+    b = hi;
+}
+__device__ __forceinline__ void sort8(unsigned k[8]) {
+    ce(k[0], k[1]); ce(k[2], k[3]); ce(k[4], k[5]); ce(k[6], k[7]);
+    ce(k[0], k[2]); ce(k[1], k[3]); ce(k[4], k[6]); ce(k[5], k[7]);
+    ce(k[1], k[2]); ce(k[5], k[6]); ce(k[0], k[4]); ce(k[3], k[7]);
+    ce(k[1], k[5]); ce(k[2], k[6]);
+    ce(k[1], k[4]); ce(k[3], k[6]);
+    ce(k[2], k[4]); ce(k[3], k[5]);
+    ce(k[3], k[4]);
+}
+
+// Lowest-point representative, ref :84-103, without sorting the bin.  Every lane holds up to 8
+// candidate keys (0xFFFFFFFF = none), sorted; `total` candidates exist in the row.  The row
+// repeatedly extracts its minimum ("tournament"), which yields the min(num_lpr,total) smallest
+// z in ASCENDING order -- exactly the terms and the order of the reference's double sum (:99-102).
+// EMIT: also store the extracted keys (used by the block kernels to merge per-wave lists).
+template <int G, bool EMIT>
+__device__ __forceinline__ double tournament(unsigned key[8], int total, int num_lpr, unsigned *emit) {
+    const int j = lane_id() & (G - 1);
+    const int keff = total < num_lpr ? total : num_lpr;
+    double sum = 0.0;
+    for (int r = 0; r < num_lpr; ++r) {
+        const bool take = r < keff;  // row-uniform
+        if (!__any(take)) break;     // wave-uniform
+        const unsigned head = key[0];
+        const unsigned m = Row<G>::min_u32(head);
+        if (take) sum += (double)key_z(m);
+        const unsigned long long rb = Row<G>::ballot(take && head == m);
+        const int lowest = __ffsll((long long)rb) - 1;
+        if (EMIT && take && j == 0) emit[r] = m;
+        if (take && j == lowest) {  // pop
+#pragma unroll
+            for (int k = 0; k < 7; ++k) key[k] = key[k + 1];
+            key[7] = 0xFFFFFFFFu;
+        }
+    }
+    return keff ? sum / (double)keff : 0.0;  // ref :103
+}
+
+// The <= 8 points of a patch that one lane owns.  They are fetched from HBM/L2 once and parked
+// in a lane-private LDS slot (rows / 256-thread kernels: 128 B per lane) -- not in registers,
+// which the eigen-solve needs -- and re-read from there at every stage of the fit chain.
+struct LanePts {
+    float x[kPPT], y[kPPT], z[kPPT];
+};
+
+// base[k * stride] is point k of this lane (LDS slot or the bin record in global memory)
+__device__ __forceinline__ void load_lane_points(LanePts &lp, const float4 *base, unsigned stride, unsigned valid) {
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid >> k & 1u) v = base[(unsigned)k * stride];
+        lp.x[k] = v.x;
+        lp.y[k] = v.y;
+        lp.z[k] = v.z;
+    }
+}
+
+// keys of the points eligible for the LPR (active, not below the zone-0 cut-off of ref :88-96)
+__device__ __forceinline__ int lane_lpr_keys(const LanePts &lp, unsigned act, bool on, bool use_cutoff, double cutoff,
+                                             unsigned key[8]) {
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        const bool e = on && (act >> k & 1u) && !(use_cutoff && (double)lp.z[k] < cutoff);
+        key[k] = e ? z_key(lp.z[k]) : 0xFFFFFFFFu;
+        cnt += e ? 1 : 0;
+    }
+    sort8(key);
+    return cnt;
+}
+
+// ------------------------------------------------------------------------------------------
+// The fit chain of one patch as a small state machine, so that the (large) eigen-solve and
+// the LPR selection are instantiated once per kernel and rows of one wave may be at different
+// points of the chain:
+//   ST_VPF   R-VPF round (zone 0 only): seeds z < lpr + th_seeds_v -> plane -> strip (ref :484-507)
+//   ST_SEED  R-GPF seeds z < lpr + th_seeds -> plane E0                           (ref :513-514)
+//   ST_LAZY  the R-VPF plane of a zone 1-3 bin, needed only if ST_SEED found no seed: ref :49
+//            then leaves that plane in force.  (The reference always fits it, :486-487, and the
+//            next fit overwrites it; skipping it changes nothing observable.)
+//   ST_ITER  R-GPF round: keep dist < th_dist -> plane; the last round also writes the split
+//            and the final plane is fitted on the ground set                       (ref :516-543)
+// ------------------------------------------------------------------------------------------
+enum { ST_VPF = 0, ST_SEED = 1, ST_ITER = 2, ST_LAZY = 3, ST_DONE = 4 };
+
+__device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &pl, unsigned n, unsigned n_ground) {
+    rec->mean[0] = pl.mean[0];
+    rec->mean[1] = pl.mean[1];
+    rec->mean[2] = pl.mean[2];
+    rec->normal[0] = pl.nx;
+    rec->normal[1] = pl.ny;
+    rec->normal[2] = pl.nz;
+    rec->sv[0] = pl.sv[0];
+    rec->sv[1] = pl.sv[1];
+    rec->sv[2] = pl.sv[2];
+    rec->d = pl.d;
+    rec->n_points = (int)n;
+    rec->n_ground = (int)n_ground;
+    rec->n_nonground = (int)(n - n_ground);
+    rec->decision = 0;
+    rec->valid = 1;
+}
+
+// per-lane part of one stage: which points enter the fit (and, for ST_ITER, which are ground)
+__device__ __forceinline__ unsigned lane_stage_moments(const LanePts &lp, unsigned act, int kind, double thr_seed,
+                                                       double th_dist, const PlaneFit &pl, float qscale, Moments &m) {
+    m.clear();
+    unsigned gmask = 0;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        bool inc = false;
+        if (act >> k & 1u) {
+            if (kind == ST_ITER) {
+                const double dist = plane_dist(pl.nx, pl.ny, pl.nz, pl.d, lp.x[k], lp.y[k], lp.z[k]);
+                inc = dist < th_dist;  // ref :525,529 (one-sided)
+            } else if (kind != ST_DONE) {
+                inc = (double)lp.z[k] < thr_seed;  // ref :108,145
+            }
+        }
+        if (inc) {
+            gmask |= 1u << k;
+            m.add(lp.x[k], lp.y[k], lp.z[k], qscale);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the 8 unrolled points sequential: register pressure
+    }
+    return gmask;
+}
+
+// returns the points of this lane that the R-VPF plane removes (ref :495-503)
+__device__ __forceinline__ unsigned lane_strip(const LanePts &lp, unsigned act, bool on, const PlaneFit &pl, double th_dist_v) {
+    unsigned hit = 0;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        if (on && (act >> k & 1u)) {
+            const double dist = plane_dist(pl.nx, pl.ny, pl.nz, pl.d, lp.x[k], lp.y[k], lp.z[k]);
+            if (fabs(dist) < th_dist_v) hit |= 1u << k;  // ref :499
+        }
+    }
+    return hit;
+}
+
+// ------------------------------------------------------------------------------------------
+// classes 0-2: G lanes per patch, wave-local
+// ------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kBlock, 4) void k_fit_rows(PwppBatch Bt, int cls) {
+    // grid = (frames, blocks per frame): the frame is the FAST dimension.  Most blocks of a frame's
+    // worst-case grid are empty; with the frame in blockIdx.y the working blocks formed a pattern
+    // of period 32 = 8 XCDs x 4 SEs and landed on a quarter of the CUs (3x slower, measured).
+    const int f = blockIdx.x;
+    const PwppDevParams &P = Bt.P;
+    const int NB = P.num_bins + 2;
+    const uint32_t *cs = Bt.cls_start + (size_t)f * 8;
+    const unsigned cbeg = cs[cls], cend = cs[cls + 1];
+    const unsigned tid = blockIdx.y * kBlock + threadIdx.x;
+    if (cbeg + (tid & ~63u) / G >= cend) return;  // this wave has no patch
+    const unsigned slot = cbeg + tid / G;
+    const bool alive = slot < cend;  // row-uniform
+    const int j = lane_id() & (G - 1);
+    const int bin = alive ? (int)Bt.cls_list[(size_t)f * P.num_bins + slot] : 0;
+    const unsigned n = alive ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
+    const PwppFrameDesc fd = Bt.frames[f];
+    const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
+    const float4 *pts = Bt.sorted + fd.base + off;
+    int *plist = Bt.plist + fd.base + off;
+    const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
+    const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
+    const double cutoff = P.margin * sensor_height;  // ref :90
+    const bool use_cutoff = zone == 0;
+    const float qscale = (float)(1 << P.fxp_shift);
+
+    const unsigned long long t_begin = (Bt.debug & 4) ? wall_clock64() : 0ull;
+    // park this lane's points in its LDS slot
+    __shared__ float4 s_pts[kPPT][kBlock];
+    unsigned valid = 0, strip = 0;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        const unsigned i = (unsigned)j + (unsigned)k * G;
+        if (i < n) {
+            s_pts[k][threadIdx.x] = pts[i];
+            valid |= 1u << k;
+        }
+    }
+    const float4 *mine = &s_pts[0][threadIdx.x];
+
+    PlaneFit pl;
+    pl.nx = pl.ny = pl.nz = 0.0f;
+    pl.mean[0] = pl.mean[1] = pl.mean[2] = 0.0f;
+    pl.sv[0] = pl.sv[1] = pl.sv[2] = 0.0f;
+    pl.d = 0.0;
+    double lpr = 0.0;
+    bool lpr_valid = false;
+    int kind = !alive ? ST_DONE : ((P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED);  // row-uniform
+    int it = 0;
+
+    for (int guard = 0; guard < 4 * P.num_iter + 8; ++guard) {
+        if (!__any(kind != ST_DONE)) break;
+        long long cnt;
+        {
+            LanePts lp;
+            load_lane_points(lp, mine, kBlock, valid);
+            const unsigned act = valid & ~strip;
+            // ---- lowest-point representative (ref :84-103) where the working set is new
+            const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
+            if (__any(need_lpr)) {
+                unsigned key[8];
+                const int c = lane_lpr_keys(lp, act, need_lpr, use_cutoff, cutoff, key);
+                const int total = Row<G>::sum_i32(c);
+                const double l = tournament<G, false>(key, total, P.num_lpr, nullptr);
+                if (need_lpr) {
+                    lpr = l;
+                    lpr_valid = true;
+                }
+            }
+            // ---- the point set of this stage and its plane
+            const double thr_seed = lpr + ((kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds);
+            Moments m;
+            const unsigned gmask = lane_stage_moments(lp, act, kind, thr_seed, P.th_dist, pl, qscale, m);
+            cnt = Row<G>::sum_i64(m.n);
+            long long s1[3];
+            __int128 s2[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s1[k] = Row<G>::sum_i64(m.s1[k]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s2[k] = (__int128)Row<G>::sum_i64(m.s2[k]);  // <= 512 points: fits int64
+            // the last R-GPF round writes the split BEFORE its plane is replaced (ref :529-541)
+            if (kind == ST_ITER && it == P.num_iter - 1) {
+                const unsigned ngm = valid & ~gmask;
+                unsigned tot_g, tot_n;
+                unsigned bg = Row<G>::excl_scan((unsigned)__popc(gmask), tot_g);
+                unsigned bn = Row<G>::excl_scan((unsigned)__popc(ngm), tot_n);
+#pragma unroll
+                for (int k = 0; k < kPPT; ++k) {
+                    if ((valid >> k & 1u) == 0) continue;
+                    const int idx = (int)(__float_as_uint(mine[k * kBlock].w) & 0x7fffffffu);
+                    if (gmask >> k & 1u)
+                        plist[bg++] = idx;  // regionwise_ground_ from the front
+                    else
+                        plist[n - 1u - (bn++)] = idx;  // regionwise_nonground_ (R-VPF strips included) from the back
+                }
+            }
+            if (kind != ST_DONE && cnt > 0) plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);  // empty: ref :49
+        }
+        // ---- what comes next for this row
+        if (kind == ST_VPF) {
+            const bool vertical = (double)pl.nz < P.uprightness_thr;  // ref :489
+            if (__any(vertical)) {
+                asm volatile("" ::: "memory");  // re-read the points: they must not stay live across the solve
+                LanePts lp;
+                load_lane_points(lp, mine, kBlock, valid);
+                const unsigned hit = lane_strip(lp, valid & ~strip, vertical, pl, P.th_dist_v);
+                strip |= hit;
+                if (Row<G>::ballot(hit != 0) != 0ull) lpr_valid = false;  // the working set changed
+            }
+            ++it;
+            if (!vertical || it >= P.num_iter) {  // ref :506 / loop end
+                kind = ST_SEED;
+                it = 0;
+            }
+        } else if (kind == ST_SEED) {
+            kind = (cnt == 0 && P.enable_RVPF != 0 && zone != 0) ? ST_LAZY : ST_ITER;
+        } else if (kind == ST_LAZY) {
+            kind = ST_ITER;
+        } else if (kind == ST_ITER) {
+            if (it == P.num_iter - 1) {
+                if (j == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt);
+                kind = ST_DONE;
+            }
+            ++it;
+        }
+        asm volatile("" ::: "memory");
+    }
+    if ((Bt.debug & 4) && lane_id() == 0) {  // timing probe: wave lifetime in 100 MHz ticks
+        const unsigned long long dt = wall_clock64() - t_begin;
+        atomicMax(&Bt.dbg[cls * 4 + 0], dt);
+        atomicAdd(&Bt.dbg[cls * 4 + 1], dt);
+        atomicAdd(&Bt.dbg[cls * 4 + 2], 1ull);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// class 3: 512 < n <= 16384 points.  Still ONE WAVE per patch: a workgroup per patch would leave
+// all but one wave idle during the serial eigen-solve (measured: 2.5 + 7.5 ms per 1024 frames
+// for 256- and 1024-thread workgroups), whereas independent waves keep every SIMD issuing.
+// The points do not fit a lane-private LDS slot any more; they are streamed from L2 at every
+// stage in chunks of 512 (8 per lane, 1 KiB per wave load instruction).
+// ------------------------------------------------------------------------------------------
+struct ChunkPts {
+    LanePts lp;
+    unsigned w[kPPT];
+    unsigned valid, strip;
+};
+
+__device__ __forceinline__ void load_chunk(ChunkPts &cp, const float4 *pts, unsigned n, unsigned c) {
+    cp.valid = 0;
+    cp.strip = 0;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        const unsigned i = (c << 9) + (unsigned)k * 64u + (unsigned)lane_id();
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) {
+            v = pts[i];
+            cp.valid |= 1u << k;
+        }
+        const unsigned wb = __float_as_uint(v.w);
+        cp.lp.x[k] = v.x;
+        cp.lp.y[k] = v.y;
+        cp.lp.z[k] = v.z;
+        cp.w[k] = wb & 0x7fffffffu;
+        if (wb & 0x80000000u) cp.strip |= 1u << k;  // removed by R-VPF earlier (flag lives in the bin record)
+    }
+}
+
+// sum of the `take` smallest keys held by the wave (<= 8 sorted keys per lane), ascending order
+__device__ __forceinline__ double tournament_sum64(unsigned key[8], int take, double sum) {
+    for (int r = 0; r < take; ++r) {  // wave-uniform trip count
+        const unsigned head = key[0];
+        const unsigned m = Row<64>::min_u32(head);
+        sum += (double)key_z(m);
+        const int lowest = __ffsll((long long)__ballot(head == m)) - 1;
+        if (lane_id() == lowest) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) key[k] = key[k + 1];
+            key[7] = 0xFFFFFFFFu;
+        }
+    }
+    return sum;
+}
+
+// LPR (ref :84-103) of a streamed patch.  Two light passes: (1) every lane's smallest eligible
+// key; the keff-th smallest of those 64 values, U, bounds the keff-th smallest key overall;
+// (2) the keys below U are gathered (<= 8 per lane, practically 0-2) and summed in ascending
+// order, topped up with copies of U.  If a lane would have to hold more than 8, or fewer than
+// keff lanes own an eligible point, an exact but slower extraction by distinct values runs.
+__device__ double wave_stream_lpr(const float4 *pts, unsigned n, unsigned nchunk, bool use_cutoff, double cutoff,
+                                  int num_lpr) {
+    const int ln = lane_id();
+    unsigned lmin = 0xFFFFFFFFu;
+    int elig = 0;
+    for (unsigned c = 0; c < nchunk; ++c) {
+        ChunkPts cp;
+        load_chunk(cp, pts, n, c);
+        const unsigned act = cp.valid & ~cp.strip;
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
+            const unsigned key = e ? z_key(cp.lp.z[k]) : 0xFFFFFFFFu;
+            lmin = key < lmin ? key : lmin;
+            elig += e ? 1 : 0;
+        }
+    }
+    const int total = Row<64>::sum_i32(elig);
+    const int keff = total < num_lpr ? total : num_lpr;
+    if (keff == 0) return 0.0;  // ref :103
+    const int nl = __popcll(__ballot(lmin != 0xFFFFFFFFu));
+    bool exact_path = nl < keff;
+    double sum = 0.0;
+    if (!exact_path) {
+        // U = keff-th smallest lane minimum
+        unsigned cur = lmin, U = 0;
+        for (int r = 0; r < keff; ++r) {
+            U = Row<64>::min_u32(cur);
+            const int lowest = __ffsll((long long)__ballot(cur == U)) - 1;
+            if (ln == lowest) cur = 0xFFFFFFFFu;
+        }
+        unsigned key[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) key[k] = 0xFFFFFFFFu;
+        int neq = 0;  // keys equal to U (only the existence of >= keff keys <= U is needed; kept for the debug build)
+        (void)neq;
+        bool overflow = false;
+        for (unsigned c = 0; c < nchunk; ++c) {
+            ChunkPts cp;
+            load_chunk(cp, pts, n, c);
+            const unsigned act = cp.valid & ~cp.strip;
+#pragma unroll
+            for (int k = 0; k < kPPT; ++k) {
+                const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
+                const unsigned kk = z_key(cp.lp.z[k]);
+                neq += (e && kk == U) ? 1 : 0;
+                const bool cand = e && kk < U;
+                if (__any(cand)) {  // sorted insertion; whatever falls off the end must be "none"
+                    unsigned x = cand ? kk : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) ce(key[q], x);
+                    overflow = overflow || (x != 0xFFFFFFFFu);
+                }
+            }
+        }
+        if (__any(overflow)) {
+            exact_path = true;
+        } else {
+            int nless = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) nless += key[q] != 0xFFFFFFFFu ? 1 : 0;
+            const int c_less = Row<64>::sum_i32(nless);
+            const int take = c_less < keff ? c_less : keff;
+            sum = tournament_sum64(key, take, 0.0);
+            const double zu = (double)key_z(U);
+            for (int r = take; r < keff; ++r) sum += zu;  // copies of U (there are at least keff keys <= U)
+        }
+    }
+    if (exact_path) {
+        // extraction by distinct values, ascending: one pass per distinct value among the keff smallest
+        sum = 0.0;
+        int remaining = keff;
+        bool first = true;
+        unsigned prev = 0;
+        while (remaining > 0) {
+            unsigned vmin = 0xFFFFFFFFu;
+            int vcnt = 0;
+            for (unsigned c = 0; c < nchunk; ++c) {
+                ChunkPts cp;
+                load_chunk(cp, pts, n, c);
+                const unsigned act = cp.valid & ~cp.strip;
+#pragma unroll
+                for (int k = 0; k < kPPT; ++k) {
+                    const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
+                    const unsigned kk = z_key(cp.lp.z[k]);
+                    if (e && (first || kk > prev)) {
+                        if (kk < vmin) {
+                            vmin = kk;
+                            vcnt = 1;
+                        } else if (kk == vmin) {
+                            ++vcnt;
+                        }
+                    }
+                }
+            }
+            const unsigned v = Row<64>::min_u32(vmin);
+            if (v == 0xFFFFFFFFu) break;  // (only NaN-keyed leftovers)
+            const int mult = Row<64>::sum_i32(vmin == v ? vcnt : 0);
+            const int take = mult < remaining ? mult : remaining;
+            const double zv = (double)key_z(v);
+            for (int r = 0; r < take; ++r) sum += zv;
+            remaining -= take;
+            prev = v;
+            first = false;
+        }
+    }
+    return sum / (double)keff;  // ref :103
+}
+
+__global__ __launch_bounds__(kBlock, 4) void k_fit_wave(PwppBatch Bt) {
+    const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
+    const PwppDevParams &P = Bt.P;
+    const int NB = P.num_bins + 2;
+    const uint32_t *cs = Bt.cls_start + (size_t)f * 8;
+    const unsigned slot = cs[3] + blockIdx.y * kWaves + (unsigned)wave_id();
+    if (slot >= cs[4]) return;  // wave-uniform
+    const int bin = Bt.cls_list[(size_t)f * P.num_bins + slot];
+    const unsigned n = Bt.bin_count[(size_t)f * NB + bin];
+    const PwppFrameDesc fd = Bt.frames[f];
+    const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
+    float4 *pts = Bt.sorted + fd.base + off;
+    int *plist = Bt.plist + fd.base + off;
+    const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
+    const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
+    const double cutoff = P.margin * sensor_height;
+    const bool use_cutoff = zone == 0;
+    const float qscale = (float)(1 << P.fxp_shift);
+    const unsigned nchunk = (n + 511u) >> 9;
+    const int ln = lane_id();
+
+    PlaneFit pl;
+    pl.nx = pl.ny = pl.nz = 0.0f;
+    pl.mean[0] = pl.mean[1] = pl.mean[2] = 0.0f;
+    pl.sv[0] = pl.sv[1] = pl.sv[2] = 0.0f;
+    pl.d = 0.0;
+    double lpr = 0.0;
+    bool lpr_valid = false;
+    int kind = (P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED;  // wave-uniform
+    int it = 0;
+
+    for (int guard = 0; guard < 4 * P.num_iter + 8 && kind != ST_DONE; ++guard) {
+        if ((kind == ST_VPF || kind == ST_SEED) && !lpr_valid) {
+            lpr = wave_stream_lpr(pts, n, nchunk, use_cutoff, cutoff, P.num_lpr);
+            lpr_valid = true;
+        }
+        const double thr_seed = lpr + ((kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds);
+        const bool last = kind == ST_ITER && it == P.num_iter - 1;
+        Moments m;
+        m.clear();
+        unsigned run_g = 0, run_n = 0;
+        for (unsigned c = 0; c < nchunk; ++c) {
+            ChunkPts cp;
+            load_chunk(cp, pts, n, c);
+            Moments mc;
+            const unsigned gmask = lane_stage_moments(cp.lp, cp.valid & ~cp.strip, kind, thr_seed, P.th_dist, pl, qscale, mc);
+            m.n += mc.n;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) m.s1[k] += mc.s1[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) m.s2[k] += mc.s2[k];
+            if (last) {  // the split is written BEFORE the plane is replaced (ref :529-541)
+                const unsigned ngm = cp.valid & ~gmask;
+                unsigned tg, tn;
+                unsigned bg = run_g + Row<64>::excl_scan((unsigned)__popc(gmask), tg);
+                unsigned bn = run_n + Row<64>::excl_scan((unsigned)__popc(ngm), tn);
+                run_g += tg;
+                run_n += tn;
+#pragma unroll
+                for (int k = 0; k < kPPT; ++k) {
+                    if (gmask >> k & 1u)
+                        plist[bg++] = (int)cp.w[k];
+                    else if (ngm >> k & 1u)
+                        plist[n - 1u - (bn++)] = (int)cp.w[k];
+                }
+            }
+        }
+        const long long cnt = Row<64>::sum_i64(m.n);
+        {
+            long long s1[3];
+            __int128 s2[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s1[k] = Row<64>::sum_i64(m.s1[k]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s2[k] = (__int128)Row<64>::sum_i64(m.s2[k]);  // <= 16384 points: fits int64
+            if (cnt > 0) plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);  // empty: ref :49
+        }
+        if (kind == ST_VPF) {
+            const bool vertical = (double)pl.nz < P.uprightness_thr;  // ref :489
+            if (vertical) {
+                bool any = false;
+                for (unsigned c = 0; c < nchunk; ++c) {
+                    ChunkPts cp;
+                    load_chunk(cp, pts, n, c);
+                    const unsigned hit = lane_strip(cp.lp, cp.valid & ~cp.strip, true, pl, P.th_dist_v);
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k) {
+                        if (hit >> k & 1u) {
+                            const unsigned i = (c << 9) + (unsigned)k * 64u + (unsigned)ln;
+                            reinterpret_cast<unsigned *>(pts)[(size_t)i * 4 + 3] = cp.w[k] | 0x80000000u;
+                        }
+                    }
+                    any = any || hit != 0;
+                }
+                if (__any(any)) lpr_valid = false;  // the working set changed
+            }
+            ++it;
+            if (!vertical || it >= P.num_iter) {
+                kind = ST_SEED;
+                it = 0;
+            }
+        } else if (kind == ST_SEED) {
+            kind = (cnt == 0 && P.enable_RVPF != 0 && zone != 0) ? ST_LAZY : ST_ITER;
+        } else if (kind == ST_LAZY) {
+            kind = ST_ITER;
+        } else {  // ST_ITER
+            if (last) {
+                if (ln == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt);
+                kind = ST_DONE;
+            }
+            ++it;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// class 5: bins too large for registers, streamed from L2/HBM on every pass
+// ------------------------------------------------------------------------------------------
+struct FitShared {
+    long long part[kWaves][16];
+    float normal[3];
+    float mean[3];
+    float sv[3];
+    float pad_;
+    double d;
+    double lpr;
+    unsigned hist[256];
+    unsigned sel_keys[PWPP_MAX_LPR];
+    unsigned sel_sorted[PWPP_MAX_LPR];
+    unsigned sel_count;
+    unsigned prefix;
+    unsigned krem;
+    unsigned keff;
+    unsigned cnt_g;
+    unsigned cnt_ng;
+};
+
+// Block-wide sum of the moments and, if the set is non-empty, the plane of ref :47-75.
+// An empty set leaves the previous plane in force, as ref :49 does.
+// `wide`: bins above 65536 points could overflow an int64 second moment in the cross-lane
+// sum; they are reduced as two 32-bit limbs and recombined in 128 bits (exact either way).
+__device__ void reduce_and_fit(FitShared &sh, const Moments &m, bool wide, int shift, int debug = 0) {
+    long long v[16];
+    v[0] = m.n;
+    v[1] = m.s1[0];
+    v[2] = m.s1[1];
+    v[3] = m.s1[2];
+    const int nv = wide ? 16 : 10;
+    if (!wide) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[4 + k] = m.s2[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            v[4 + k] = m.s2[k] & 0xffffffffll;
+            v[10 + k] = m.s2[k] >> 32;
+        }
+    }
+    const int wv = wave_id(), ln = lane_id();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k < nv) {
+            const long long t = wave_sum_i64(v[k]);
+            if (ln == 0) sh.part[wv][k] = t;
+        }
+    }
+    __syncthreads();
+    if (wv == 0) {
+        long long t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            t[k] = 0;
+            if (k < nv) {
+#pragma unroll
+                for (int q = 0; q < kWaves; ++q) t[k] += sh.part[q][k];
+            }
+        }
+        const long long n = t[0];
+        if (n > 0) {
+            __int128 s2[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s2[k] = wide ? ((__int128)t[10 + k] * (__int128)4294967296ll + (__int128)t[4 + k]) : (__int128)t[4 + k];
+            const long long s1[3] = {t[1], t[2], t[3]};
+            PlaneFit pf;
+            plane_from_totals(n, s1, s2, shift, debug, pf);
+            if (ln == 0) {
+                sh.normal[0] = pf.nx;
+                sh.normal[1] = pf.ny;
+                sh.normal[2] = pf.nz;
+                sh.mean[0] = pf.mean[0];
+                sh.mean[1] = pf.mean[1];
+                sh.mean[2] = pf.mean[2];
+                sh.sv[0] = pf.sv[0];
+                sh.sv[1] = pf.sv[1];
+                sh.sv[2] = pf.sv[2];
+                sh.d = pf.d;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool pt_stripped(const float4 &p) { return (__float_as_uint(p.w) & 0x80000000u) != 0; }
+
+// Lowest-point representative height, ref :84-103, without sorting the bin: the reference
+// needs (a) how many points lie below the adaptive cut-off (zone 0 only, :88-96), (b) the
+// num_lpr smallest z among the others, summed in ascending order in double (:99-102).
+// A 4-pass 8-bit radix select finds the k-th smallest key; the elements below its 24-bit
+// prefix are gathered in the last pass, the rest is implied by the last histogram.
+__device__ double block_lpr(FitShared &sh, const float4 *pts, unsigned n, bool use_cutoff, double cutoff, int num_lpr) {
+    const int ln = lane_id(), wv = wave_id();
+    unsigned prefix = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int bits = 24 - 8 * pass;
+        sh.hist[threadIdx.x] = 0;  // kBlock == 256 counters
+        if (threadIdx.x == 0 && pass == 3) sh.sel_count = 0;
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < n; i += kBlock) {
+            const float4 p = pts[i];
+            if (pt_stripped(p)) continue;
+            if (use_cutoff && (double)p.z < cutoff) continue;  // init_idx prefix, ref :88-96
+            const unsigned key = z_key(p.z);
+            if (pass > 0) {
+                const unsigned hp = key >> (bits + 8);
+                if (hp != prefix) {
+                    if (pass == 3 && hp < prefix) {
+                        const unsigned s = atomicAdd(&sh.sel_count, 1u);
+                        if (s < PWPP_MAX_LPR) sh.sel_keys[s] = key;
+                    }
+                    continue;
+                }
+            }
+            atomicAdd(&sh.hist[(key >> bits) & 255u], 1u);
+        }
+        __syncthreads();
+        if (wv == 0) {
+            const unsigned c0 = sh.hist[4 * ln], c1 = sh.hist[4 * ln + 1], c2 = sh.hist[4 * ln + 2], c3 = sh.hist[4 * ln + 3];
+            const unsigned s = c0 + c1 + c2 + c3;
+            unsigned incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(incl, o, 64);
+                if (ln >= o) incl += t;
+            }
+            unsigned kk;
+            if (pass == 0) {
+                const unsigned total = __shfl(incl, 63, 64);
+                const unsigned keff = total < (unsigned)num_lpr ? total : (unsigned)num_lpr;
+                if (ln == 0) sh.keff = keff;
+                kk = keff;
+            } else {
+                kk = sh.krem;
+            }
+            const unsigned excl = incl - s;
+            if (kk >= 1 && excl < kk && kk <= incl) {  // exactly one lane
+                unsigned run = excl, dgt = 4 * ln;
+                if (run + c0 >= kk) {
+                } else {
+                    run += c0;
+                    ++dgt;
+                    if (run + c1 >= kk) {
+                    } else {
+                        run += c1;
+                        ++dgt;
+                        if (run + c2 >= kk) {
+                        } else {
+                            run += c2;
+                            ++dgt;
+                        }
+                    }
+                }
+                sh.prefix = (prefix << 8) | dgt;
+                sh.krem = kk - run;  // rank inside the chosen bucket, 1-based
+            }
+        }
+        __syncthreads();
+        if (sh.keff == 0) return 0.0;  // ref :103 "in case divide by 0"
+        prefix = sh.prefix;
+    }
+    // wave 0: order the gathered keys (all below the last bucket) and add up, ascending
+    if (wv == 0) {
+        const unsigned c = sh.sel_count;  // < keff <= PWPP_MAX_LPR
+        if ((unsigned)ln < c) {
+            const unsigned mine = sh.sel_keys[ln];
+            unsigned rank = 0;
+            for (unsigned j = 0; j < c; ++j) {
+                const unsigned o = sh.sel_keys[j];
+                rank += (o < mine || (o == mine && j < (unsigned)ln)) ? 1u : 0u;
+            }
+            sh.sel_sorted[rank] = mine;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (ln == 0) {
+            const unsigned keff = sh.keff;
+            double sum = 0;
+            for (unsigned j = 0; j < c; ++j) sum += key_z(sh.sel_sorted[j]);
+            unsigned r = keff - c;
+            const unsigned p24 = prefix >> 8;
+            for (unsigned dgt = 0; dgt < 256 && r > 0; ++dgt) {
+                unsigned m = sh.hist[dgt];
+                if (m > r) m = r;
+                const double z = key_z((p24 << 8) | dgt);
+                for (unsigned t = 0; t < m; ++t) sum += z;
+                r -= m;
+            }
+            sh.lpr = sum / (int)keff;  // ref :103
+        }
+    }
+    __syncthreads();
+    return sh.lpr;
+}
+
+// ref :551-554  (float products, float adds left to right, one double add)
+__device__ __forceinline__ double point_to_plane(float nx, float ny, float nz, double d, const float4 &p) {
+    return nx * p.x + ny * p.y + nz * p.z + d;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt) {
+    __shared__ FitShared sh;
+    const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
+    const PwppDevParams &P = Bt.P;
+    const int NB = P.num_bins + 2;
+    const uint32_t *cs = Bt.cls_start + (size_t)f * 8;
+    const unsigned slot = cs[5] + blockIdx.y;
+    if (slot >= cs[6]) return;
+    const int bin = Bt.cls_list[(size_t)f * P.num_bins + slot];
+    const unsigned n = Bt.bin_count[(size_t)f * NB + bin];
+    PwppPatchRec *rec = Bt.recs + (size_t)f * P.num_bins + bin;
+    const PwppFrameDesc fd = Bt.frames[f];
+    const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
+    float4 *pts = Bt.sorted + fd.base + off;
+    int *plist = Bt.plist + fd.base + off;
+    const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
+    const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
+    const double cutoff = P.margin * sensor_height;  // ref :90
+    const bool use_cutoff = zone == 0;
+    const float qscale = (float)(1 << P.fxp_shift);
+    const bool wide = n > 65536u;
+
+    if (threadIdx.x == 0) {
+        sh.normal[0] = sh.normal[1] = sh.normal[2] = 0.0f;
+        sh.mean[0] = sh.mean[1] = sh.mean[2] = 0.0f;
+        sh.sv[0] = sh.sv[1] = sh.sv[2] = 0.0f;
+        sh.d = 0.0;
+        sh.cnt_g = 0;
+        sh.cnt_ng = 0;
+    }
+    __syncthreads();
+
+    double lpr = 0.0;
+    bool lpr_valid = false;
+    Moments m;
+
+    // ---- R-VPF, ref :482-508
+    if (P.enable_RVPF) {
+        for (int it = 0; it < P.num_iter; ++it) {
+            if (!lpr_valid) {
+                lpr = (Bt.debug & 2) ? -1.8 : block_lpr(sh, pts, n, use_cutoff, cutoff, P.num_lpr);
+                lpr_valid = true;
+            }
+            const double thr = lpr + P.th_seeds_v;  // ref :108
+            m.clear();
+            for (unsigned i = threadIdx.x; i < n; i += kBlock) {
+                const float4 p = pts[i];
+                if (!pt_stripped(p) && (double)p.z < thr) m.add(p.x, p.y, p.z, qscale);
+            }
+            reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);
+            const float nx = sh.normal[0], ny = sh.normal[1], nz = sh.normal[2];
+            const double d = sh.d;
+            if (zone == 0 && (double)nz < P.uprightness_thr) {  // ref :489
+                int any = 0;
+                for (unsigned i = threadIdx.x; i < n; i += kBlock) {
+                    float4 p = pts[i];
+                    if (pt_stripped(p)) continue;
+                    const double dist = point_to_plane(nx, ny, nz, d, p);
+                    if (fabs(dist) < P.th_dist_v) {  // ref :499 -> non_ground_dst
+                        reinterpret_cast<unsigned *>(pts)[(size_t)i * 4 + 3] = __float_as_uint(p.w) | 0x80000000u;
+                        any = 1;
+                    }
+                }
+                if (__syncthreads_or(any)) lpr_valid = false;  // the working set changed
+            } else {
+                break;  // ref :506
+            }
+        }
+    }
+
+    // ---- R-GPF, ref :513-543
+    if (!lpr_valid) lpr = (Bt.debug & 2) ? -1.8 : block_lpr(sh, pts, n, use_cutoff, cutoff, P.num_lpr);
+    {
+        const double thr = lpr + P.th_seeds;  // ref :145
+        m.clear();
+        for (unsigned i = threadIdx.x; i < n; i += kBlock) {
+            const float4 p = pts[i];
+            if (!pt_stripped(p) && (double)p.z < thr) m.add(p.x, p.y, p.z, qscale);
+        }
+        reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);
+    }
+    const int ln = lane_id();
+    for (int it = 0; it < P.num_iter; ++it) {
+        const bool last = it == P.num_iter - 1;
+        const float nx = sh.normal[0], ny = sh.normal[1], nz = sh.normal[2];
+        const double d = sh.d;
+        m.clear();
+        for (unsigned i0 = 0; i0 < n; i0 += kBlock) {
+            const unsigned i = i0 + threadIdx.x;
+            const bool in = i < n;
+            float4 p = make_float4(0, 0, 0, 0);
+            if (in) p = pts[i];
+            const bool stripped = in && pt_stripped(p);
+            const bool active = in && !stripped;
+            bool g = false;
+            if (active) {
+                const double dist = point_to_plane(nx, ny, nz, d, p);
+                g = dist < P.th_dist;  // ref :525,529 (one-sided)
+            }
+            if (g) m.add(p.x, p.y, p.z, qscale);
+            if (last) {
+                // regionwise_ground_ from the front, regionwise_nonground_ (R-VPF strips included,
+                // ref :500,532) from the back of this patch's slot range
+                const int idx = (int)(__float_as_uint(p.w) & 0x7fffffffu);
+                const unsigned long long mg = __ballot(g);
+                const unsigned long long mn = __ballot(in && !g);
+                const unsigned long long lt = (1ull << ln) - 1ull;
+                unsigned bg = 0, bn = 0;
+                if (ln == 0) {
+                    if (mg) bg = atomicAdd(&sh.cnt_g, (unsigned)__popcll(mg));
+                    if (mn) bn = atomicAdd(&sh.cnt_ng, (unsigned)__popcll(mn));
+                }
+                bg = __shfl(bg, 0, 64);
+                bn = __shfl(bn, 0, 64);
+                if (g)
+                    plist[bg + (unsigned)__popcll(mg & lt)] = idx;
+                else if (in)
+                    plist[n - 1u - (bn + (unsigned)__popcll(mn & lt))] = idx;
+            }
+        }
+        reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);  // ref :537-542
+    }
+
+    if (threadIdx.x == 0) {
+        rec->mean[0] = sh.mean[0];
+        rec->mean[1] = sh.mean[1];
+        rec->mean[2] = sh.mean[2];
+        rec->normal[0] = sh.normal[0];
+        rec->normal[1] = sh.normal[1];
+        rec->normal[2] = sh.normal[2];
+        rec->sv[0] = sh.sv[0];
+        rec->sv[1] = sh.sv[1];
+        rec->sv[2] = sh.sv[2];
+        rec->d = sh.d;
+        rec->n_points = (int)n;
+        rec->n_ground = (int)sh.cnt_g;
+        rec->n_nonground = (int)(n - sh.cnt_g);
+        rec->decision = 0;
+        rec->valid = 1;
+    }
+}
+
+}  // namespace
+
+// launches of K4; ev (optional) = 6 events recorded around the five launches
+extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev) {
+    const PwppBatch &B = *batch;
+    const int F = B.num_frames, nb = B.P.num_bins;
+    const unsigned min_pts = B.P.min_pts < 1 ? 1u : (unsigned)(B.P.min_pts > 0xffffffffull ? 0xffffffffu : B.P.min_pts);
+    // a class whose patches have more than `lo` points holds at most max_n / lo of them per frame
+    auto cap = [&](unsigned lo) -> unsigned {
+        unsigned c = (unsigned)B.max_n / (lo > min_pts ? lo : min_pts);
+        if (c > (unsigned)nb) c = (unsigned)nb;
+        return c < 1 ? 1u : c;
+    };
+    if (ev) (void)hipEventRecord(ev[0], stream);
+    hipLaunchKernelGGL(k_fit_rows<16>, dim3(F, (cap(1) + 15) / 16), dim3(kBlock), 0, stream, B, 0);
+    if (ev) (void)hipEventRecord(ev[1], stream);
+    hipLaunchKernelGGL(k_fit_rows<32>, dim3(F, (cap(129) + 7) / 8), dim3(kBlock), 0, stream, B, 1);
+    if (ev) (void)hipEventRecord(ev[2], stream);
+    hipLaunchKernelGGL(k_fit_rows<64>, dim3(F, (cap(257) + 3) / 4), dim3(kBlock), 0, stream, B, 2);
+    if (ev) (void)hipEventRecord(ev[3], stream);
+    hipLaunchKernelGGL(k_fit_wave, dim3(F, (cap(513) + kWaves - 1) / kWaves), dim3(kBlock), 0, stream, B);
+    if (ev) (void)hipEventRecord(ev[4], stream);
+    hipLaunchKernelGGL(k_fit_stream, dim3(F, cap(16385)), dim3(kBlock), 0, stream, B);
+    if (ev) (void)hipEventRecord(ev[5], stream);
+    return (int)hipGetLastError();
+}

@@ -1,13 +1,14 @@
 // pwpp_kernels.hip -- the Patchwork++ estimateGround() hot path as hand-written HIP for
 // gfx950 (MI355X, CDNA4: wave64, 256 CUs in 8 XCDs, 160 KiB LDS/CU, HBM3E).
 //
-// One batch of F independent frames goes through six launches; every launch covers all
-// frames (grid.y = frame), so a 1024-frame batch is 6 launches, not 6144:
+// One batch of F independent frames goes through eleven launches; every launch covers all
+// frames (grid.y = frame), so a 1024-frame batch is 11 launches, not 11264:
 //
 //   K1 k_czm_bin      RNR + CZM code per point + per-frame bin histogram   (ref :377-400, :578-622)
 //   K2 k_czm_scan     exclusive scan of the histogram -> bin offsets
 //   K3 k_czm_scatter  points grouped by bin: {x,y,z,idx} 16 B records      (ref :602-614 emplace_back)
-//   K4 k_patch_fit    per patch: LPR seeds, R-VPF, R-GPF, final plane       (ref :77-149, :47-75, :467-554)
+//   K4 k_fit_*        per patch: LPR seeds, R-VPF, R-GPF, final plane       (ref :77-149, :47-75, :467-554)
+//                     six launches by patch size class, see pwpp_fit.hip
 //   K5 k_gle_tgr      per frame: GLE ladder, A-GLE history, TGR, thresholds (ref :211-309, :338-375, :402-464)
 //   K6 k_emit         ground / non-ground index lists                       (ref :28-31, :18-26)
 //
@@ -26,63 +27,13 @@
 // the result does not depend on thread count, wave scheduling or the order the scatter
 // atomics happened to produce, and oracle/pwpp_oracle.cpp (PWO_ARITH_FXP) reproduces it
 // bit for bit on the CPU.
-#include <float.h>
-#include <math.h>
-#include <stdint.h>
-
-#include <hip/hip_runtime.h>
-
-#include "pwpp_dev.h"
-
-#define PWPP_LAYOUT_ROW_MAJOR 0
-#define PWPP_LAYOUT_COL_MAJOR 1
+#include "pwpp_common.hpp"
 
 namespace {
 
 constexpr int kBlock = 256;          // 4 waves
-constexpr int kWaves = kBlock / 64;
+
 constexpr int kPtsPerBlock = 1024;   // K1/K3: 4 points per thread, 16 KiB of input per workgroup
-
-// ------------------------------------------------------------------------------------------
-// small helpers
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
-
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-__device__ __forceinline__ void load_point(const PwppFrameDesc &fd, int i, float &x, float &y, float &z, float &w) {
-    if (fd.layout == PWPP_LAYOUT_ROW_MAJOR) {
-        if (fd.cols == 4) {
-            const float4 v = reinterpret_cast<const float4 *>(fd.pts)[i];  // 16 B/lane, 1 KiB per wave instruction
-            x = v.x;
-            y = v.y;
-            z = v.z;
-            w = v.w;
-        } else {
-            const float *p = fd.pts + (size_t)3 * (size_t)i;
-            x = p[0];
-            y = p[1];
-            z = p[2];
-            w = 0.0f;
-        }
-    } else {  // column-major planes (Eigen::MatrixXf storage)
-        const size_t n = (size_t)fd.n;
-        x = fd.pts[i];
-        y = fd.pts[n + i];
-        z = fd.pts[2 * n + i];
-        w = fd.cols == 4 ? fd.pts[3 * n + i] : 0.0f;
-    }
-}
 
 // atan2 for the sector angle (ref xy2theta :568-571).  The CPU reference calls glibc's
 // atan2; ocml's differs from it by at most an ulp or two, which can only change
@@ -216,6 +167,44 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
         Bt.results[f].n_rnr = (int)cnt[Bt.P.num_bins];
         Bt.results[f].n_oor = (int)cnt[Bt.P.num_bins + 1];
     }
+    // patches of this frame grouped by size class (work lists of the K4 kernels)
+    __shared__ unsigned s_cnt[PWPP_NUM_CLASSES], s_start[PWPP_NUM_CLASSES + 1], s_cur[PWPP_NUM_CLASSES];
+    const int B = Bt.P.num_bins;
+    if (threadIdx.x < PWPP_NUM_CLASSES) {
+        s_cnt[threadIdx.x] = 0;
+        s_cur[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += kBlock) {
+        const unsigned n = cnt[b];
+        if ((uint64_t)n < Bt.P.min_pts) continue;  // small bin (ref :191-195)
+        if (n == 0) {  // only with num_min_pts <= 0: no fit runs (ref :49); K5 inherits the previous plane
+            PwppPatchRec *rec = Bt.recs + (size_t)f * B + b;
+            rec->valid = 0;
+            rec->n_points = 0;
+            rec->n_ground = 0;
+            rec->n_nonground = 0;
+            continue;
+        }
+        atomicAdd(&s_cnt[patch_class(n)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int c = 0; c < PWPP_NUM_CLASSES; ++c) {
+            s_start[c] = run;
+            run += s_cnt[c];
+        }
+        s_start[PWPP_NUM_CLASSES] = run;
+        for (int c = 0; c <= PWPP_NUM_CLASSES; ++c) Bt.cls_start[(size_t)f * 8 + c] = s_start[c];
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += kBlock) {
+        const unsigned n = cnt[b];
+        if ((uint64_t)n < Bt.P.min_pts || n == 0) continue;
+        const int c = patch_class(n);
+        Bt.cls_list[(size_t)f * B + s_start[c] + atomicAdd(&s_cur[c], 1u)] = (uint16_t)b;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -259,577 +248,6 @@ __global__ __launch_bounds__(kBlock) void k_czm_scatter(PwppBatch Bt) {
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         if (code[j] != PWPP_CODE_DROP) sorted[off[code[j]] + s_base[code[j]] + rank[j]] = pt[j];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K4  per-patch plane fitting
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double i128_to_double(__int128 v) {  // one rounding, to nearest even
-    const bool neg = v < 0;
-    const unsigned __int128 a = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
-    const unsigned long long hi = (unsigned long long)(a >> 64), lo = (unsigned long long)a;
-    double r;
-    if (hi == 0) {
-        r = (double)lo;
-    } else {
-        const int sh = 64 - __clzll((long long)hi);  // bits above bit 63
-        unsigned long long top = (unsigned long long)(a >> sh);
-        const unsigned __int128 rest = a & ((((unsigned __int128)1) << sh) - 1);
-        top |= (rest != 0) ? 1ull : 0ull;  // sticky bit, far below the 53-bit mantissa
-        r = ldexp((double)top, sh);
-    }
-    return neg ? -r : r;
-}
-
-__device__ __forceinline__ float f_abs(float v) { return v < 0.0f ? -v : v; }
-__device__ __forceinline__ float f_max(float a, float b) { return a < b ? b : a; }
-
-// Eigen 3.4.0 JacobiSVD<MatrixX3f>(cov, ComputeFullU) as used at ref :62 -- two-sided Jacobi,
-// real square case, float.  a: row-major symmetric 3x3.  Outputs U (row-major) and the
-// singular values sorted descending.  Same operation sequence as oracle/pwpp_oracle.cpp
-// jacobi_svd3 and oracle/eigen_shim (all three are compared bitwise by the tests).
-__device__ void jacobi_svd3(const float a[9], float u[9], float sv[3]) {
-    const float tiny = FLT_MIN, precision = 2.0f * FLT_EPSILON;
-    float scale = 0.0f;
-    bool invalid = false;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const float v = f_abs(a[k]);
-        if (!(v == v) || v > FLT_MAX) invalid = true;
-        if (v > scale) scale = v;
-    }
-    if (invalid) {
-        const float nanv = __uint_as_float(0x7fc00000u);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) u[k] = nanv;
-        sv[0] = sv[1] = sv[2] = nanv;
-        return;
-    }
-    if (scale == 0.0f) scale = 1.0f;
-    float w[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) w[k] = a[k] / scale;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) u[k] = (k % 4 == 0) ? 1.0f : 0.0f;
-    float max_diag = f_max(f_abs(w[0]), f_max(f_abs(w[4]), f_abs(w[8])));
-
-    for (int sweep = 0; sweep < 1000; ++sweep) {
-        bool finished = true;
-#pragma unroll
-        for (int p = 1; p < 3; ++p) {
-#pragma unroll
-            for (int q = 0; q < p; ++q) {
-                const float thr = f_max(tiny, precision * max_diag);
-                if (f_abs(w[p * 3 + q]) > thr || f_abs(w[q * 3 + p]) > thr) {
-                    finished = false;
-                    const float m00 = w[p * 3 + p], m01 = w[p * 3 + q], m10 = w[q * 3 + p], m11 = w[q * 3 + q];
-                    const float t = m00 + m11, d = m10 - m01;
-                    float c1, s1;
-                    if (f_abs(d) < tiny) {
-                        s1 = 0.0f;
-                        c1 = 1.0f;
-                    } else {
-                        const float r = t / d;
-                        const float h = sqrtf(1.0f + r * r);
-                        s1 = 1.0f / h;
-                        c1 = r / h;
-                    }
-                    const float b00 = c1 * m00 + s1 * m10;
-                    const float b01 = c1 * m01 + s1 * m11;
-                    const float b11 = -s1 * m01 + c1 * m11;
-                    float cr, sr;
-                    const float deno = 2.0f * f_abs(b01);
-                    if (deno < tiny) {
-                        cr = 1.0f;
-                        sr = 0.0f;
-                    } else {
-                        const float tau = (b00 - b11) / deno;
-                        const float ww = sqrtf(tau * tau + 1.0f);
-                        const float tt = (tau > 0.0f) ? 1.0f / (tau + ww) : 1.0f / (tau - ww);
-                        const float sign_t = tt > 0.0f ? 1.0f : -1.0f;
-                        const float nn = 1.0f / sqrtf(tt * tt + 1.0f);
-                        sr = -sign_t * (b01 / f_abs(b01)) * f_abs(tt) * nn;
-                        cr = nn;
-                    }
-                    const float cl = c1 * cr - s1 * (-sr);
-                    const float sl = c1 * (-sr) + s1 * cr;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float x = w[p * 3 + k], y = w[q * 3 + k];
-                        w[p * 3 + k] = cl * x + sl * y;
-                        w[q * 3 + k] = -sl * x + cl * y;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float x = u[k * 3 + p], y = u[k * 3 + q];
-                        u[k * 3 + p] = cl * x - (-sl) * y;
-                        u[k * 3 + q] = (-sl) * x + cl * y;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float x = w[k * 3 + p], y = w[k * 3 + q];
-                        w[k * 3 + p] = cr * x - sr * y;
-                        w[k * 3 + q] = sr * x + cr * y;
-                    }
-                    max_diag = f_max(max_diag, f_max(f_abs(w[p * 3 + p]), f_abs(w[q * 3 + q])));
-                }
-            }
-        }
-        if (finished) break;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float dgl = w[i * 3 + i];
-        sv[i] = f_abs(dgl);
-        if (dgl < 0.0f) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) u[k * 3 + i] = -u[k * 3 + i];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) sv[i] *= scale;
-    bool stop = false;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        if (!stop) {
-            int pos = i;
-#pragma unroll
-            for (int j = i + 1; j < 3; ++j)
-                if (sv[j] > sv[pos]) pos = j;
-            if (sv[pos] == 0.0f) {
-                stop = true;
-            } else if (pos != i) {
-                const float ts = sv[i];
-                sv[i] = sv[pos];
-                sv[pos] = ts;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float tu = u[k * 3 + i];
-                    u[k * 3 + i] = u[k * 3 + pos];
-                    u[k * 3 + pos] = tu;
-                }
-            }
-        }
-    }
-}
-
-// Q(v)
-__device__ __forceinline__ int fxp_quantise(float v, float scale) {
-    float t = v * scale;
-    if (!(t == t)) return 0;
-    t = rintf(t);
-    if (t > 8388607.0f) t = 8388607.0f;
-    if (t < -8388607.0f) t = -8388607.0f;
-    return (int)t;
-}
-
-// order-preserving map float -> uint32 (for the lowest-point selection)
-__device__ __forceinline__ unsigned z_key(float z) {
-    const unsigned b = __float_as_uint(z);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float key_z(unsigned k) {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-
-struct Moments {  // per-lane partial sums of the quantised coordinates
-    long long n, s1[3], s2[6];
-    __device__ __forceinline__ void clear() {
-        n = 0;
-        s1[0] = s1[1] = s1[2] = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s2[k] = 0;
-    }
-    __device__ __forceinline__ void add(float x, float y, float z, float scale) {
-        const int qx = fxp_quantise(x, scale), qy = fxp_quantise(y, scale), qz = fxp_quantise(z, scale);
-        n += 1;
-        s1[0] += qx;
-        s1[1] += qy;
-        s1[2] += qz;
-        s2[0] += (long long)qx * qx;
-        s2[1] += (long long)qx * qy;
-        s2[2] += (long long)qx * qz;
-        s2[3] += (long long)qy * qy;
-        s2[4] += (long long)qy * qz;
-        s2[5] += (long long)qz * qz;
-    }
-};
-
-struct FitShared {
-    long long part[kWaves][16];
-    float normal[3];
-    float mean[3];
-    float sv[3];
-    float pad_;
-    double d;
-    double lpr;
-    unsigned hist[256];
-    unsigned sel_keys[PWPP_MAX_LPR];
-    unsigned sel_sorted[PWPP_MAX_LPR];
-    unsigned sel_count;
-    unsigned prefix;
-    unsigned krem;
-    unsigned keff;
-    unsigned cnt_g;
-    unsigned cnt_ng;
-};
-
-// Block-wide sum of the moments and, if the set is non-empty, the plane of ref :47-75.
-// An empty set leaves the previous plane in force, as ref :49 does.
-// `wide`: bins above 65536 points could overflow an int64 second moment in the cross-lane
-// sum; they are reduced as two 32-bit limbs and recombined in 128 bits (exact either way).
-__device__ void reduce_and_fit(FitShared &sh, const Moments &m, bool wide, int shift, int debug = 0) {
-    long long v[16];
-    v[0] = m.n;
-    v[1] = m.s1[0];
-    v[2] = m.s1[1];
-    v[3] = m.s1[2];
-    const int nv = wide ? 16 : 10;
-    if (!wide) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v[4 + k] = m.s2[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            v[4 + k] = m.s2[k] & 0xffffffffll;
-            v[10 + k] = m.s2[k] >> 32;
-        }
-    }
-    const int wv = wave_id(), ln = lane_id();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if (k < nv) {
-            const long long t = wave_sum_i64(v[k]);
-            if (ln == 0) sh.part[wv][k] = t;
-        }
-    }
-    __syncthreads();
-    if (wv == 0) {
-        long long t[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            t[k] = 0;
-            if (k < nv) {
-#pragma unroll
-                for (int q = 0; q < kWaves; ++q) t[k] += sh.part[q][k];
-            }
-        }
-        const long long n = t[0];
-        if (n > 0) {
-            __int128 s2[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) s2[k] = wide ? ((__int128)t[10 + k] * (__int128)4294967296ll + (__int128)t[4 + k]) : (__int128)t[4 + k];
-            const long long s1[3] = {t[1], t[2], t[3]};
-            const double inv = 1.0 / (double)(1 << shift);
-            const double den = (double)n * (double)(n - 1);
-            float mean[3], cov[9];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) mean[a] = (float)(((double)s1[a] / (double)n) * inv);
-            const int map[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-#pragma unroll
-                for (int b = a; b < 3; ++b) {
-                    const __int128 num = (__int128)n * s2[map[a * 3 + b]] - (__int128)s1[a] * (__int128)s1[b];
-                    const float c = (float)((i128_to_double(num) / den) * (inv * inv));
-                    cov[a * 3 + b] = c;
-                    cov[b * 3 + a] = c;
-                }
-            }
-            float u[9], sv[3];
-            if (debug & 1) {  // ablation: no eigen-solve
-                for (int k = 0; k < 9; ++k) u[k] = cov[k];
-                sv[0] = cov[0]; sv[1] = cov[4]; sv[2] = cov[8];
-                u[2] = 0.01f; u[5] = 0.01f; u[8] = 0.9999f;
-            } else {
-                jacobi_svd3(cov, u, sv);
-            }
-            float nx = u[2], ny = u[5], nz = u[8];  // U.col(2), ref :66
-            if (nz < 0) {                           // ref :68
-                nx *= -1;
-                ny *= -1;
-                nz *= -1;
-            }
-            const float dot = nx * mean[0] + ny * mean[1] + nz * mean[2];  // ref :74, float dot
-            if (ln == 0) {
-                sh.normal[0] = nx;
-                sh.normal[1] = ny;
-                sh.normal[2] = nz;
-                sh.mean[0] = mean[0];
-                sh.mean[1] = mean[1];
-                sh.mean[2] = mean[2];
-                sh.sv[0] = sv[0];
-                sh.sv[1] = sv[1];
-                sh.sv[2] = sv[2];
-                sh.d = -dot;
-            }
-        }
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ bool pt_stripped(const float4 &p) { return (__float_as_uint(p.w) & 0x80000000u) != 0; }
-
-// Lowest-point representative height, ref :84-103, without sorting the bin: the reference
-// needs (a) how many points lie below the adaptive cut-off (zone 0 only, :88-96), (b) the
-// num_lpr smallest z among the others, summed in ascending order in double (:99-102).
-// A 4-pass 8-bit radix select finds the k-th smallest key; the elements below its 24-bit
-// prefix are gathered in the last pass, the rest is implied by the last histogram.
-__device__ double block_lpr(FitShared &sh, const float4 *pts, unsigned n, bool use_cutoff, double cutoff, int num_lpr) {
-    const int ln = lane_id(), wv = wave_id();
-    unsigned prefix = 0;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int bits = 24 - 8 * pass;
-        sh.hist[threadIdx.x] = 0;  // kBlock == 256 counters
-        if (threadIdx.x == 0 && pass == 3) sh.sel_count = 0;
-        __syncthreads();
-        for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-            const float4 p = pts[i];
-            if (pt_stripped(p)) continue;
-            if (use_cutoff && (double)p.z < cutoff) continue;  // init_idx prefix, ref :88-96
-            const unsigned key = z_key(p.z);
-            if (pass > 0) {
-                const unsigned hp = key >> (bits + 8);
-                if (hp != prefix) {
-                    if (pass == 3 && hp < prefix) {
-                        const unsigned s = atomicAdd(&sh.sel_count, 1u);
-                        if (s < PWPP_MAX_LPR) sh.sel_keys[s] = key;
-                    }
-                    continue;
-                }
-            }
-            atomicAdd(&sh.hist[(key >> bits) & 255u], 1u);
-        }
-        __syncthreads();
-        if (wv == 0) {
-            const unsigned c0 = sh.hist[4 * ln], c1 = sh.hist[4 * ln + 1], c2 = sh.hist[4 * ln + 2], c3 = sh.hist[4 * ln + 3];
-            const unsigned s = c0 + c1 + c2 + c3;
-            unsigned incl = s;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned t = __shfl_up(incl, o, 64);
-                if (ln >= o) incl += t;
-            }
-            unsigned kk;
-            if (pass == 0) {
-                const unsigned total = __shfl(incl, 63, 64);
-                const unsigned keff = total < (unsigned)num_lpr ? total : (unsigned)num_lpr;
-                if (ln == 0) sh.keff = keff;
-                kk = keff;
-            } else {
-                kk = sh.krem;
-            }
-            const unsigned excl = incl - s;
-            if (kk >= 1 && excl < kk && kk <= incl) {  // exactly one lane
-                unsigned run = excl, dgt = 4 * ln;
-                if (run + c0 >= kk) {
-                } else {
-                    run += c0;
-                    ++dgt;
-                    if (run + c1 >= kk) {
-                    } else {
-                        run += c1;
-                        ++dgt;
-                        if (run + c2 >= kk) {
-                        } else {
-                            run += c2;
-                            ++dgt;
-                        }
-                    }
-                }
-                sh.prefix = (prefix << 8) | dgt;
-                sh.krem = kk - run;  // rank inside the chosen bucket, 1-based
-            }
-        }
-        __syncthreads();
-        if (sh.keff == 0) return 0.0;  // ref :103 "in case divide by 0"
-        prefix = sh.prefix;
-    }
-    // wave 0: order the gathered keys (all below the last bucket) and add up, ascending
-    if (wv == 0) {
-        const unsigned c = sh.sel_count;  // < keff <= PWPP_MAX_LPR
-        if ((unsigned)ln < c) {
-            const unsigned mine = sh.sel_keys[ln];
-            unsigned rank = 0;
-            for (unsigned j = 0; j < c; ++j) {
-                const unsigned o = sh.sel_keys[j];
-                rank += (o < mine || (o == mine && j < (unsigned)ln)) ? 1u : 0u;
-            }
-            sh.sel_sorted[rank] = mine;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (ln == 0) {
-            const unsigned keff = sh.keff;
-            double sum = 0;
-            for (unsigned j = 0; j < c; ++j) sum += key_z(sh.sel_sorted[j]);
-            unsigned r = keff - c;
-            const unsigned p24 = prefix >> 8;
-            for (unsigned dgt = 0; dgt < 256 && r > 0; ++dgt) {
-                unsigned m = sh.hist[dgt];
-                if (m > r) m = r;
-                const double z = key_z((p24 << 8) | dgt);
-                for (unsigned t = 0; t < m; ++t) sum += z;
-                r -= m;
-            }
-            sh.lpr = sum / (int)keff;  // ref :103
-        }
-    }
-    __syncthreads();
-    return sh.lpr;
-}
-
-// ref :551-554  (float products, float adds left to right, one double add)
-__device__ __forceinline__ double point_to_plane(float nx, float ny, float nz, double d, const float4 &p) {
-    return nx * p.x + ny * p.y + nz * p.z + d;
-}
-
-__global__ __launch_bounds__(kBlock) void k_patch_fit(PwppBatch Bt) {
-    __shared__ FitShared sh;
-    const int f = blockIdx.y, bin = blockIdx.x;
-    const PwppDevParams &P = Bt.P;
-    const int NB = P.num_bins + 2;
-    const unsigned n = Bt.bin_count[(size_t)f * NB + bin];
-    if ((uint64_t)n < P.min_pts) return;  // small bin: all non-ground, handled by K6 (ref :191-195)
-    PwppPatchRec *rec = Bt.recs + (size_t)f * P.num_bins + bin;
-    if (n == 0) {  // only reachable with num_min_pts <= 0: no fit runs (ref :49), K5 inherits the previous plane
-        if (threadIdx.x == 0) {
-            rec->valid = 0;
-            rec->n_points = 0;
-            rec->n_ground = 0;
-            rec->n_nonground = 0;
-        }
-        return;
-    }
-    const PwppFrameDesc fd = Bt.frames[f];
-    const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    float4 *pts = Bt.sorted + fd.base + off;
-    int *plist = Bt.plist + fd.base + off;
-    const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
-    const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
-    const double cutoff = P.margin * sensor_height;  // ref :90
-    const bool use_cutoff = zone == 0;
-    const float qscale = (float)(1 << P.fxp_shift);
-    const bool wide = n > 65536u;
-
-    if (threadIdx.x == 0) {
-        sh.normal[0] = sh.normal[1] = sh.normal[2] = 0.0f;
-        sh.mean[0] = sh.mean[1] = sh.mean[2] = 0.0f;
-        sh.sv[0] = sh.sv[1] = sh.sv[2] = 0.0f;
-        sh.d = 0.0;
-        sh.cnt_g = 0;
-        sh.cnt_ng = 0;
-    }
-    __syncthreads();
-
-    double lpr = 0.0;
-    bool lpr_valid = false;
-    Moments m;
-
-    // ---- R-VPF, ref :482-508
-    if (P.enable_RVPF) {
-        for (int it = 0; it < P.num_iter; ++it) {
-            if (!lpr_valid) {
-                lpr = (Bt.debug & 2) ? -1.8 : block_lpr(sh, pts, n, use_cutoff, cutoff, P.num_lpr);
-                lpr_valid = true;
-            }
-            const double thr = lpr + P.th_seeds_v;  // ref :108
-            m.clear();
-            for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-                const float4 p = pts[i];
-                if (!pt_stripped(p) && (double)p.z < thr) m.add(p.x, p.y, p.z, qscale);
-            }
-            reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);
-            const float nx = sh.normal[0], ny = sh.normal[1], nz = sh.normal[2];
-            const double d = sh.d;
-            if (zone == 0 && (double)nz < P.uprightness_thr) {  // ref :489
-                int any = 0;
-                for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-                    float4 p = pts[i];
-                    if (pt_stripped(p)) continue;
-                    const double dist = point_to_plane(nx, ny, nz, d, p);
-                    if (fabs(dist) < P.th_dist_v) {  // ref :499 -> non_ground_dst
-                        reinterpret_cast<unsigned *>(pts)[(size_t)i * 4 + 3] = __float_as_uint(p.w) | 0x80000000u;
-                        any = 1;
-                    }
-                }
-                if (__syncthreads_or(any)) lpr_valid = false;  // the working set changed
-            } else {
-                break;  // ref :506
-            }
-        }
-    }
-
-    // ---- R-GPF, ref :513-543
-    if (!lpr_valid) lpr = (Bt.debug & 2) ? -1.8 : block_lpr(sh, pts, n, use_cutoff, cutoff, P.num_lpr);
-    {
-        const double thr = lpr + P.th_seeds;  // ref :145
-        m.clear();
-        for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-            const float4 p = pts[i];
-            if (!pt_stripped(p) && (double)p.z < thr) m.add(p.x, p.y, p.z, qscale);
-        }
-        reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);
-    }
-    const int ln = lane_id();
-    for (int it = 0; it < P.num_iter; ++it) {
-        const bool last = it == P.num_iter - 1;
-        const float nx = sh.normal[0], ny = sh.normal[1], nz = sh.normal[2];
-        const double d = sh.d;
-        m.clear();
-        for (unsigned i0 = 0; i0 < n; i0 += kBlock) {
-            const unsigned i = i0 + threadIdx.x;
-            const bool in = i < n;
-            float4 p = make_float4(0, 0, 0, 0);
-            if (in) p = pts[i];
-            const bool stripped = in && pt_stripped(p);
-            const bool active = in && !stripped;
-            bool g = false;
-            if (active) {
-                const double dist = point_to_plane(nx, ny, nz, d, p);
-                g = dist < P.th_dist;  // ref :525,529 (one-sided)
-            }
-            if (g) m.add(p.x, p.y, p.z, qscale);
-            if (last) {
-                // regionwise_ground_ from the front, regionwise_nonground_ (R-VPF strips included,
-                // ref :500,532) from the back of this patch's slot range
-                const int idx = (int)(__float_as_uint(p.w) & 0x7fffffffu);
-                const unsigned long long mg = __ballot(g);
-                const unsigned long long mn = __ballot(in && !g);
-                const unsigned long long lt = (1ull << ln) - 1ull;
-                unsigned bg = 0, bn = 0;
-                if (ln == 0) {
-                    if (mg) bg = atomicAdd(&sh.cnt_g, (unsigned)__popcll(mg));
-                    if (mn) bn = atomicAdd(&sh.cnt_ng, (unsigned)__popcll(mn));
-                }
-                bg = __shfl(bg, 0, 64);
-                bn = __shfl(bn, 0, 64);
-                if (g)
-                    plist[bg + (unsigned)__popcll(mg & lt)] = idx;
-                else if (in)
-                    plist[n - 1u - (bn + (unsigned)__popcll(mn & lt))] = idx;
-            }
-        }
-        reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);  // ref :537-542
-    }
-
-    if (threadIdx.x == 0) {
-        rec->mean[0] = sh.mean[0];
-        rec->mean[1] = sh.mean[1];
-        rec->mean[2] = sh.mean[2];
-        rec->normal[0] = sh.normal[0];
-        rec->normal[1] = sh.normal[1];
-        rec->normal[2] = sh.normal[2];
-        rec->sv[0] = sh.sv[0];
-        rec->sv[1] = sh.sv[1];
-        rec->sv[2] = sh.sv[2];
-        rec->d = sh.d;
-        rec->n_points = (int)n;
-        rec->n_ground = (int)sh.cnt_g;
-        rec->n_nonground = (int)(n - sh.cnt_g);
-        rec->decision = 0;
-        rec->valid = 1;
     }
 }
 
@@ -1153,7 +571,9 @@ extern "C" int pwpp_launch_gather_xyz(const PwppFrameDesc *fd, const int *idx, i
 // ------------------------------------------------------------------------------------------
 // host-side launcher used by pwpp_capi.cpp
 // ------------------------------------------------------------------------------------------
-extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev /* 7 events or null */) {
+extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev);
+
+extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev /* PWPP_NUM_KERNELS + 1 events or null */) {
     const PwppBatch &B = *batch;
     const int F = B.num_frames;
     if (F <= 0) return 0;
@@ -1165,12 +585,11 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
     if (ev) (void)hipEventRecord(ev[2], stream);
     if (gx > 0) hipLaunchKernelGGL(k_czm_scatter, dim3(gx, F), dim3(kBlock), 0, stream, B);
-    if (ev) (void)hipEventRecord(ev[3], stream);
-    hipLaunchKernelGGL(k_patch_fit, dim3(B.P.num_bins, F), dim3(kBlock), 0, stream, B);
-    if (ev) (void)hipEventRecord(ev[4], stream);
+    const int frc = pwpp_launch_fit(batch, stream, ev ? ev + 3 : nullptr);  // records ev[3..8]
+    if (frc) return frc;
     hipLaunchKernelGGL(k_gle_tgr, dim3(F), dim3(64), 0, stream, B);
-    if (ev) (void)hipEventRecord(ev[5], stream);
+    if (ev) (void)hipEventRecord(ev[9], stream);
     hipLaunchKernelGGL(k_emit, dim3(NB, F), dim3(kBlock), 0, stream, B);
-    if (ev) (void)hipEventRecord(ev[6], stream);
+    if (ev) (void)hipEventRecord(ev[10], stream);
     return (int)hipGetLastError();
 }
