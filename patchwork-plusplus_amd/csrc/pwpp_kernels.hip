@@ -252,9 +252,11 @@ __global__ __launch_bounds__(kBlock) void k_czm_scatter(PwppBatch Bt) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K5  GLE + A-GLE history + TGR + adaptive thresholds, one workgroup (one wave) per frame.
-// v1: the reference's sequential loop (ref :184-311) executed by lane 0 in the reference's
-// own order, so every double sum has the reference's summation order.
+// K5  GLE + A-GLE history + TGR + adaptive thresholds, one workgroup per frame.
+// k_gle_tgr_seq: the reference's sequential loop (ref :184-311) executed by lane 0 in the
+// reference's own order.  It is the executable specification and the path taken when
+// num_min_pts <= 0 lets empty bins through (they inherit the previous bin's plane, a serial
+// dependence).  k_gle_tgr below computes the same thing with the bins spread over 256 threads.
 // ------------------------------------------------------------------------------------------
 __device__ void mean_stdev(const double *v, int n, double &mean, double &stdev) {  // ref :557-566
     if (n <= 1) return;
@@ -266,7 +268,7 @@ __device__ void mean_stdev(const double *v, int n, double &mean, double &stdev) 
     stdev = sqrt(stdev);
 }
 
-__global__ __launch_bounds__(64) void k_gle_tgr(PwppBatch Bt) {
+__global__ __launch_bounds__(64) void k_gle_tgr_seq(PwppBatch Bt) {
     __shared__ double s_ring_flat[PWPP_MAX_NEAR_BINS];
     __shared__ uint8_t s_dec[PWPP_MAX_BINS];
     const int f = blockIdx.x;
@@ -519,6 +521,394 @@ __global__ __launch_bounds__(64) void k_gle_tgr(PwppBatch Bt) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K5 parallel.  The decisions of ref :217-282 are independent per patch; what the sequential
+// loop adds is ORDER: history pushes in sector order, ring-wise flatness statistics that carry
+// over rings without candidates (ref :292-304), and output lists appended bin by bin with the
+// TGR candidates of a ring appended at its end.  All of that is prefix sums over the bins in
+// traversal order plus a 4-iteration loop over the rings of interest.
+// Every double sum keeps the reference's summation order (sequential over <= one ring).
+// ------------------------------------------------------------------------------------------
+constexpr int kGlePer = PWPP_MAX_BINS / kBlock;  // consecutive bins per thread
+
+template <int K>
+__device__ __forceinline__ void block_excl_scan(unsigned v[K], unsigned (*s_wave)[K], unsigned total[K]) {
+    // v[q]: this thread's sum of quantity q; returns the exclusive prefix over threads in v, block totals in total
+    const int ln = lane_id(), wv = wave_id();
+    unsigned incl[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        incl[q] = v[q];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = (unsigned)__shfl_up((int)incl[q], o, 64);
+            if (ln >= o) incl[q] += t;
+        }
+        if (ln == 63) s_wave[wv][q] = incl[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        unsigned before = 0, all = 0;
+        for (int w = 0; w < kBlock / 64; ++w) {
+            const unsigned t = s_wave[w][q];
+            if (w < wv) before += t;
+            all += t;
+        }
+        v[q] = incl[q] - v[q] + before;
+        total[q] = all;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
+    __shared__ uint8_t s_dec[PWPP_MAX_BINS];
+    __shared__ unsigned s_e[4][PWPP_MAX_BINS + 1];   // exclusive prefixes: gmain, gtail, nmain, ntail
+    __shared__ unsigned s_epush[PWPP_MAX_NEAR_BINS + 1];
+    __shared__ double s_pseq[PWPP_MAX_NEAR_BINS];     // flatness of the pushed patches, in push order
+    __shared__ unsigned s_wave[kBlock / 64][4];
+    __shared__ PwppStateScalar s_st;
+    __shared__ int s_ring_first[PWPP_MAX_ROI + 1];    // first bin of near ring ci; [roi] = end
+    __shared__ unsigned s_ring_cand[PWPP_MAX_ROI];
+    __shared__ double s_ring_mean[PWPP_MAX_ROI], s_ring_std[PWPP_MAX_ROI];
+    __shared__ int s_len0[2][PWPP_MAX_ROI];           // history lengths before this frame
+    const int f = blockIdx.x;
+    const PwppDevParams &P = Bt.P;
+    const int B = P.num_bins, NB = B + 2;
+    const PwppFrameDesc fd = Bt.frames[f];
+    const unsigned *cnt = Bt.bin_count + (size_t)f * NB;
+    PwppPatchRec *recs = Bt.recs + (size_t)f * B;
+    unsigned *dst_a = Bt.dst_a + (size_t)f * NB;
+    unsigned *dst_b = Bt.dst_b + (size_t)f * NB;
+    float *centers = Bt.centers + (size_t)f * B * 3;
+    float *normals = Bt.normals + (size_t)f * B * 3;
+    double *hist_out = Bt.st_hist + (size_t)fd.state_out * 8 * P.hist_cap;
+    const int roi = P.num_rings_of_interest;
+
+    if (threadIdx.x == 0) {
+        PwppStateScalar st;
+        if (fd.state_in >= 0) {
+            st = Bt.st_scalar[fd.state_in];
+        } else {
+            st.sensor_height = P.sensor_height;
+            for (int k = 0; k < 4; ++k) {
+                st.elevation_thr[k] = P.elevation_thr0[k];
+                st.flatness_thr[k] = P.flatness_thr0[k];
+                st.elev_len[k] = 0;
+                st.flat_len[k] = 0;
+            }
+        }
+        s_st = st;
+        for (int k = 0; k < PWPP_MAX_ROI; ++k) {
+            s_len0[0][k] = st.elev_len[k];
+            s_len0[1][k] = st.flat_len[k];
+            s_ring_cand[k] = 0;
+        }
+        // first bin of every ring of interest (they are the first rings in traversal order)
+        int ci = 0, bin = 0;
+        for (int zone = 0; zone < 4 && ci <= roi; ++zone)
+            for (int ring = 0; ring < P.rings[zone] && ci <= roi; ++ring) {
+                if (ci <= PWPP_MAX_ROI) s_ring_first[ci] = bin;
+                bin += P.sectors[zone];
+                ++ci;
+            }
+        for (; ci <= roi; ++ci) s_ring_first[ci] = B;  // fewer rings than rings of interest
+    }
+    __syncthreads();
+    if (fd.state_in >= 0 && fd.state_in != fd.state_out) {  // carry the histories over
+        const double *hist_in = Bt.st_hist + (size_t)fd.state_in * 8 * P.hist_cap;
+        for (int w = 0; w < 8; ++w) {
+            const int len = w < 4 ? s_len0[0][w] : s_len0[1][w - 4];
+            for (int i = threadIdx.x; i < len; i += kBlock) hist_out[w * P.hist_cap + i] = hist_in[w * P.hist_cap + i];
+        }
+    }
+    const int near_end = s_ring_first[roi];  // bins [0, near_end) are "near" (concentric_idx < roi)
+
+    // ---- pass 1: per-bin GLE (ref :217-282) ------------------------------------------------
+    const int b0 = threadIdx.x * kGlePer;
+    unsigned a_patch = 0, a_push = 0;
+    uint8_t dec[kGlePer];
+    int ci_of[kGlePer];
+#pragma unroll
+    for (int j = 0; j < kGlePer; ++j) {
+        const int bin = b0 + j;
+        dec[j] = 0;
+        ci_of[j] = 0;
+        if (bin >= B) continue;
+        const unsigned n = cnt[bin];
+        if ((uint64_t)n < P.min_pts) continue;  // small bin
+        // concentric index of the bin
+        const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
+        int ci = (bin - P.bin_base[zone]) / P.sectors[zone];
+        for (int z = 0; z < zone; ++z) ci += P.rings[z];
+        ci_of[j] = ci;
+        const PwppPatchRec r = recs[bin];
+        const double uprightness = r.normal[2];
+        const double elevation = r.mean[2];
+        float fmin3 = r.sv[0];
+        if (r.sv[1] < fmin3) fmin3 = r.sv[1];
+        if (r.sv[2] < fmin3) fmin3 = r.sv[2];
+        const double flatness = fmin3;
+        double heading = 0.0;
+        for (int i = 0; i < 3; ++i) heading += r.mean[i] * r.normal[i];
+        const bool is_upright = uprightness > P.uprightness_thr;
+        const bool is_near = ci < roi;
+        const bool heading_outside = heading < 0.0;
+        bool not_elevated = false, is_flat = false;
+        if (is_near) {
+            not_elevated = elevation < s_st.elevation_thr[ci];
+            is_flat = flatness < s_st.flatness_thr[ci];
+        }
+        int d;
+        if (!is_upright)
+            d = 1;
+        else if (!is_near)
+            d = 2;
+        else if (!heading_outside)
+            d = 3;
+        else if (not_elevated || is_flat)
+            d = 4;
+        else
+            d = 5;
+        if (is_upright && not_elevated && is_near) d |= 0x80;  // pushes to the A-GLE history (ref :253-259)
+        dec[j] = (uint8_t)d;
+        a_patch += 1;
+        a_push += (d & 0x80) ? 1u : 0u;
+        if ((d & 0x7f) == 5) s_ring_cand[ci] = 1u;  // benign race: all writers store 1
+    }
+    {
+        unsigned v[2] = {a_patch, a_push}, tot[2];
+        block_excl_scan<2>(v, reinterpret_cast<unsigned(*)[2]>(&s_wave[0][0]), tot);
+        unsigned p_patch = v[0], p_push = v[1];
+#pragma unroll
+        for (int j = 0; j < kGlePer; ++j) {
+            const int bin = b0 + j;
+            if (bin < near_end) s_epush[bin] = p_push;
+            if (bin < B) s_dec[bin] = dec[j];
+            if (dec[j] == 0) continue;
+            const PwppPatchRec r = recs[bin];
+            for (int i = 0; i < 3; ++i) {  // ref :211-212
+                centers[p_patch * 3 + i] = r.mean[i];
+                normals[p_patch * 3 + i] = r.normal[i];
+            }
+            ++p_patch;
+            if (dec[j] & 0x80) {
+                float fmin3 = r.sv[0];
+                if (r.sv[1] < fmin3) fmin3 = r.sv[1];
+                if (r.sv[2] < fmin3) fmin3 = r.sv[2];
+                s_pseq[p_push] = (double)fmin3;
+                ++p_push;
+            }
+        }
+        if (threadIdx.x == 0) {
+            s_epush[near_end] = tot[1];
+            Bt.results[f].n_patches = (int)tot[0];
+        }
+    }
+    __syncthreads();
+    // history pushes in sector order (ref :255-256): position inside the ring = prefix difference
+#pragma unroll
+    for (int j = 0; j < kGlePer; ++j) {
+        const int bin = b0 + j;
+        if (!(dec[j] & 0x80)) continue;
+        const int ci = ci_of[j];
+        const int pos = (int)(s_epush[bin] - s_epush[s_ring_first[ci]]);
+        const int e = s_len0[0][ci] + pos, fl = s_len0[1][ci] + pos;
+        const PwppPatchRec r = recs[bin];
+        if (e < P.hist_cap && fl < P.hist_cap) {
+            hist_out[(0 * 4 + ci) * P.hist_cap + e] = (double)r.mean[2];
+            hist_out[(1 * 4 + ci) * P.hist_cap + fl] = s_pseq[s_epush[bin]];
+        } else {
+            Bt.results[f].pad0 = 1;  // slab full (only the un-trimmed case of ref :363-364), flagged
+        }
+    }
+    // ring-wise flatness statistics for TGR: the list is only cleared by a ring that had
+    // candidates (ref :292-304), so it may span several rings
+    if (threadIdx.x == 0) {
+        unsigned begin = 0;
+        for (int ci = 0; ci < roi; ++ci) {
+            const unsigned end = s_epush[s_ring_first[ci + 1]];
+            const int pushed = (int)(end - s_epush[s_ring_first[ci]]);
+            int ne = s_len0[0][ci] + pushed, nf = s_len0[1][ci] + pushed;
+            if (ne > P.hist_cap) ne = P.hist_cap;
+            if (nf > P.hist_cap) nf = P.hist_cap;
+            s_st.elev_len[ci] = ne;
+            s_st.flat_len[ci] = nf;
+            if (s_ring_cand[ci]) {
+                double m = 0.0, sd = 0.0;
+                mean_stdev(s_pseq + begin, (int)(end - begin), m, sd);  // ref :407-408
+                s_ring_mean[ci] = m;
+                s_ring_std[ci] = sd;
+                begin = end;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 2: TGR (ref :416-461) and what each bin appends to which list -----------------
+    unsigned q4[4] = {0, 0, 0, 0};  // gmain, gtail, nmain, ntail of this thread's bins
+    unsigned gm[kGlePer], gt[kGlePer], nm[kGlePer], nt[kGlePer];
+#pragma unroll
+    for (int j = 0; j < kGlePer; ++j) {
+        const int bin = b0 + j;
+        gm[j] = gt[j] = nm[j] = nt[j] = 0;
+        if (bin >= B) continue;
+        const unsigned n = cnt[bin];
+        int d = dec[j] & 0x7f;
+        if (d == 0) {
+            nm[j] = n;  // small bin, whole (ref :193)
+        } else {
+            const PwppPatchRec r = recs[bin];
+            const unsigned ng = (unsigned)r.n_ground;
+            if (d == 5 && P.enable_TGR) {
+                const int ci = ci_of[j];
+                float fmin3 = r.sv[0];
+                if (r.sv[1] < fmin3) fmin3 = r.sv[1];
+                if (r.sv[2] < fmin3) fmin3 = r.sv[2];
+                const double flatness = fmin3;
+                const double line_variable = r.sv[1] != 0 ? (double)(r.sv[0] / r.sv[1]) : DBL_MAX;
+                const double mu = s_ring_mean[ci] + 1.5 * s_ring_std[ci];                  // ref :428
+                double prob_flatness = 1 / (1 + exp((flatness - mu) / (mu / 10)));        // ref :429
+                if (r.n_ground > 1500 && flatness < P.th_dist * P.th_dist) prob_flatness = 1.0;  // ref :431
+                double prob_line = 1.0;
+                if (line_variable > 8.0) prob_line = 0.0;
+                if (prob_line * prob_flatness > 0.5) d = 6;
+            }
+            recs[bin].decision = d;
+            if (d == 1 || d == 3)
+                nm[j] = n;  // candidates then non-ground part, both to the non-ground list (ref :264,272,284)
+            else
+                nm[j] = n - ng;  // ref :284
+            if (d == 2 || d == 4) gm[j] = ng;
+            if (d == 6) gt[j] = ng;
+            if (d == 5) nt[j] = ng;
+        }
+        dec[j] = (uint8_t)d;
+        q4[0] += gm[j];
+        q4[1] += gt[j];
+        q4[2] += nm[j];
+        q4[3] += nt[j];
+    }
+    unsigned tot4[4];
+    block_excl_scan<4>(q4, s_wave, tot4);
+    {
+        unsigned run[4] = {q4[0], q4[1], q4[2], q4[3]};
+#pragma unroll
+        for (int j = 0; j < kGlePer; ++j) {
+            const int bin = b0 + j;
+            if (bin >= B) continue;
+            for (int q = 0; q < 4; ++q) s_e[q][bin] = run[q];
+            run[0] += gm[j];
+            run[1] += gt[j];
+            run[2] += nm[j];
+            run[3] += nt[j];
+        }
+        if (threadIdx.x == 0)
+            for (int q = 0; q < 4; ++q) s_e[q][B] = tot4[q];
+    }
+    __syncthreads();
+    const unsigned total_ground = tot4[0] + tot4[1];
+    const unsigned n_rnr = cnt[B], n_oor = cnt[B + 1];
+    const unsigned ng_base = total_ground + n_rnr + n_oor;  // non-ground list follows the ground list
+#pragma unroll
+    for (int j = 0; j < kGlePer; ++j) {
+        const int bin = b0 + j;
+        if (bin >= B) continue;
+        const int d = dec[j];
+        // ring of this bin: its first bin and the first bin of the next ring
+        const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
+        const int rs = P.bin_base[zone] + ((bin - P.bin_base[zone]) / P.sectors[zone]) * P.sectors[zone];
+        const int re = rs + P.sectors[zone];
+        const unsigned nmain_at = ng_base + s_e[2][bin] + s_e[3][rs];
+        if (d == 0) {
+            dst_a[bin] = nmain_at;
+            dst_b[bin] = 0;
+        } else {
+            const unsigned ng = (unsigned)recs[bin].n_ground;
+            if (d == 1 || d == 3) {
+                dst_a[bin] = nmain_at;
+                dst_b[bin] = nmain_at + ng;
+            } else {
+                dst_b[bin] = nmain_at;
+                if (d == 2 || d == 4)
+                    dst_a[bin] = s_e[0][bin] + s_e[1][rs];
+                else if (d == 6)
+                    dst_a[bin] = s_e[0][re] + s_e[1][bin];  // reverted at the end of its ring (ref :450)
+                else
+                    dst_a[bin] = ng_base + s_e[2][re] + s_e[3][bin];  // rejected at the end of its ring (ref :458)
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        dst_a[B] = total_ground;          // RNR hits first (ref :393) ...
+        dst_a[B + 1] = total_ground + n_rnr;  // ... then the out-of-range points (ref :618)
+        dst_b[B] = dst_b[B + 1] = 0;
+        PwppFrameResult *res = Bt.results + f;
+        res->n_ground = (int)total_ground;
+        res->n_nonground = (int)(n_rnr + n_oor + tot4[2] + tot4[3]);
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- adaptive thresholds for the next frame of this stream (ref :338-375) ---------------
+    // lanes 0..3: elevation history of ring i, lanes 4..7: flatness history; sequential sums
+    __shared__ double s_mean[8], s_std[8];
+    if (threadIdx.x < 8) {
+        const int which = threadIdx.x >> 2, i = threadIdx.x & 3;
+        double m = 0.0, sd = 0.0;
+        const int len = which == 0 ? s_st.elev_len[i] : s_st.flat_len[i];
+        if (i < roi) mean_stdev(hist_out + (which * 4 + i) * P.hist_cap, len, m, sd);
+        s_mean[threadIdx.x] = m;
+        s_std[threadIdx.x] = sd;
+    }
+    __syncthreads();
+    __shared__ int s_shift[8];
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 8; ++i) s_shift[i] = 0;
+        for (int i = 0; i < roi; ++i) {  // update_elevation_thr: "continue" on an empty history
+            const int len = s_st.elev_len[i];
+            if (len == 0) continue;
+            if (i == 0) {
+                s_st.elevation_thr[i] = s_mean[i] + 3 * s_std[i];
+                s_st.sensor_height = -s_mean[i];
+            } else {
+                s_st.elevation_thr[i] = s_mean[i] + 2 * s_std[i];
+            }
+            const int exceed = len - P.max_elev_storage;
+            if (exceed > 0) {
+                s_shift[i] = exceed;
+                s_st.elev_len[i] = len - exceed;
+            }
+        }
+        for (int i = 0; i < roi; ++i) {  // update_flatness_thr: "break" at the first history of <= 1
+            const int len = s_st.flat_len[i];
+            if (len <= 1) break;
+            s_st.flatness_thr[i] = s_mean[4 + i] + s_std[4 + i];
+            const int exceed = len - P.max_flat_storage;
+            if (exceed > 0) {
+                s_shift[4 + i] = exceed;
+                s_st.flat_len[i] = len - exceed;
+            }
+        }
+        Bt.st_scalar[fd.state_out] = s_st;
+    }
+    __syncthreads();
+    for (int w = 0; w < 8; ++w) {  // erase(begin, begin + exceed), ref :354-355,372-373
+        const int sh = s_shift[w];
+        if (sh <= 0) continue;
+        double *h = hist_out + w * P.hist_cap;
+        const int newlen = w < 4 ? s_st.elev_len[w] : s_st.flat_len[w - 4];
+        for (int base = 0; base < newlen; base += kBlock) {
+            const int i = base + threadIdx.x;
+            double v = 0.0;
+            if (i < newlen) v = h[i + sh];
+            __syncthreads();
+            if (i < newlen) h[i] = v;
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K6  write the index lists
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_emit(PwppBatch Bt) {
@@ -587,7 +977,10 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     if (gx > 0) hipLaunchKernelGGL(k_czm_scatter, dim3(gx, F), dim3(kBlock), 0, stream, B);
     const int frc = pwpp_launch_fit(batch, stream, ev ? ev + 3 : nullptr);  // records ev[3..8]
     if (frc) return frc;
-    hipLaunchKernelGGL(k_gle_tgr, dim3(F), dim3(64), 0, stream, B);
+    if (B.P.min_pts == 0)
+        hipLaunchKernelGGL(k_gle_tgr_seq, dim3(F), dim3(64), 0, stream, B);  // empty bins inherit planes: serial
+    else
+        hipLaunchKernelGGL(k_gle_tgr, dim3(F), dim3(kBlock), 0, stream, B);
     if (ev) (void)hipEventRecord(ev[9], stream);
     hipLaunchKernelGGL(k_emit, dim3(NB, F), dim3(kBlock), 0, stream, B);
     if (ev) (void)hipEventRecord(ev[10], stream);
