@@ -181,7 +181,7 @@ typedef struct pwpp_device_view {
 int pwpp_get_device_view(pwpp_handle *h, pwpp_device_view *out);
 
 /* per-kernel GPU time (HIP events on the handle's stream around every launch) */
-#define PWPP_NUM_KERNELS 10
+#define PWPP_NUM_KERNELS 11
 int pwpp_set_profiling(pwpp_handle *h, int enable);
 int pwpp_get_kernel_profile(pwpp_handle *h, double *sum_ms /*[PWPP_NUM_KERNELS]*/, int64_t *launches /*[PWPP_NUM_KERNELS]*/);
 int pwpp_reset_kernel_profile(pwpp_handle *h);

@@ -87,9 +87,8 @@ struct PinnedBuf {
     }
 };
 
-const char *kKernelNames[PWPP_NUM_KERNELS] = {"k_czm_bin", "k_czm_scan", "k_czm_scatter", "k_fit_rows<16>",
-                                              "k_fit_rows<32>", "k_fit_rows<64>", "k_fit_wave",
-                                              "k_fit_stream", "k_gle_tgr", "k_emit"};
+const char *kKernelNames[PWPP_NUM_KERNELS] = {"k_czm_bin", "k_czm_scan", "k_czm_scatter", "k_fit[0]", "k_fit[1]",
+                                              "k_fit[2]", "k_fit[3]", "k_fit[4]", "k_fit_stream", "k_gle_tgr", "k_emit"};
 
 }  // namespace
 
@@ -438,7 +437,7 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     if ((rc = h->d_out.ensure(tp))) return rc;
     if ((rc = h->d_bins.ensure((size_t)frames * NB * 5))) return rc;
     if ((rc = h->d_recs.ensure((size_t)frames * B))) return rc;
-    if ((rc = h->d_cls_start.ensure((size_t)frames * 8))) return rc;
+    if ((rc = h->d_cls_start.ensure((size_t)frames * PWPP_CLS_STRIDE))) return rc;
     if ((rc = h->d_cls_list.ensure((size_t)frames * B))) return rc;
     if ((rc = h->d_centers.ensure((size_t)frames * B * 3))) return rc;
     if ((rc = h->d_normals.ensure((size_t)frames * B * 3))) return rc;

@@ -319,14 +319,21 @@ __device__ __forceinline__ double plane_dist(float nx, float ny, float nz, doubl
     return nx * x + ny * y + nz * z + d;
 }
 
-// patch size classes of the fit kernels
-#define PWPP_NUM_CLASSES 6
-__device__ __forceinline__ int patch_class(unsigned n) {
-    if (n <= 128u) return 0;    // k_fit_rows<16>: 16 lanes per patch, 4 patches per wave, points parked in LDS
-    if (n <= 256u) return 1;    // k_fit_rows<32>
-    if (n <= 512u) return 2;    // k_fit_rows<64>: one wave
-    if (n <= 16384u) return 3;  // k_fit_wave: one wave, points streamed from L2 per stage
-    return 5;                   // k_fit_stream: one workgroup, radix-select LPR (class 4 is unused)
+// Patches are sorted by size into quarter-octave buckets (k_czm_scan); the fit kernels
+// take contiguous bucket ranges, so the rows of one wave have similar point counts.
+// bucket(n) = 4*floor(log2 n) + next two mantissa bits, n >= 1; monotone in n.
+__host__ __device__ __forceinline__ int pwpp_size_bucket(unsigned n) {
+    if (n < 4u) return (int)n;  // 1,2,3 -> 1,2,3 (0 unused)
+    int e = 31;
+    while (!((n >> e) & 1u)) --e;
+    const int b = 4 * e + (int)((n >> (e - 2)) & 3u) - 4;  // n=4 -> 4
+    return b < PWPP_NUM_BUCKETS - 1 ? b : PWPP_NUM_BUCKETS - 1;
+}
+// smallest n that lands in bucket b (b >= 4)
+__host__ __device__ __forceinline__ unsigned pwpp_bucket_floor(int b) {
+    if (b < 4) return (unsigned)(b < 1 ? 1 : b);
+    const int e = (b + 4) / 4, q = (b + 4) % 4;
+    return (1u << e) + ((unsigned)q << (e - 2));
 }
 
 }  // namespace

@@ -10,6 +10,8 @@
 #define PWPP_MAX_NEAR_BINS 1024   // bins inside the rings of interest (default: 96)
 #define PWPP_MAX_LPR 64           // num_lpr upper bound (default 20)
 #define PWPP_MAX_ROI 4            // rings of interest (reference keeps update_*_[4])
+#define PWPP_NUM_BUCKETS 96        // patch size buckets (quarter octaves up to 2^24 points)
+#define PWPP_CLS_STRIDE 104       // uint32 per frame in cls_start (PWPP_NUM_BUCKETS + 1, padded)
 
 // per-point CZM codes written by k_czm_bin (uint16): 0..B-1 real bins, then
 #define PWPP_CODE_RNR(B) ((B))        // reflected-noise hit      (patchworkpp.cpp:391-396)
@@ -84,8 +86,8 @@ struct PwppBatch {
     uint32_t *bin_count;         // [frames][B+2]
     uint32_t *bin_off;           // [frames][B+2] exclusive scan of bin_count
     uint32_t *bin_cursor;        // [frames][B+2]
-    uint32_t *cls_start;         // [frames][8] first entry of each size class in cls_list (7 used)
-    uint16_t *cls_list;          // [frames][B] patch bins grouped by size class
+    uint32_t *cls_start;         // [frames][PWPP_CLS_STRIDE] first entry of each size bucket in cls_list
+    uint16_t *cls_list;          // [frames][B] patch bins sorted by size bucket
     float4 *sorted;              // [total points] {x,y,z,bits(idx)} grouped by bin; bit 31 of w = stripped by R-VPF
     int32_t *plist;              // [total points] per patch: ground candidates from the front, non-ground from the back
     PwppPatchRec *recs;          // [frames][B]

@@ -18,6 +18,7 @@
 //
 // All reductions are integer, so every variant produces bit-identical
 // planes and the same index sets whatever the lane count.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -45,7 +46,7 @@ constexpr int kPPT = 8;  // points per lane held in registers
 
 template <int G>
 struct Row {
-    static_assert(G == 16 || G == 32 || G == 64, "row width");
+    static_assert(G == 8 || G == 16 || G == 32 || G == 64, "row width");
     static constexpr unsigned long long kMask = (G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull);
     __device__ static __forceinline__ int first_lane() { return lane_id() & ~(G - 1); }
 
@@ -54,7 +55,10 @@ struct Row {
         t = PWPP_DPP(x, PWPP_DPP_XOR1); x = (unsigned)t < (unsigned)x ? t : x;
         t = PWPP_DPP(x, PWPP_DPP_XOR2); x = (unsigned)t < (unsigned)x ? t : x;
         t = PWPP_DPP(x, PWPP_DPP_HMIR); x = (unsigned)t < (unsigned)x ? t : x;
-        t = PWPP_DPP(x, PWPP_DPP_MIR); x = (unsigned)t < (unsigned)x ? t : x;
+        if (G >= 16) {
+            t = PWPP_DPP(x, PWPP_DPP_MIR);
+            x = (unsigned)t < (unsigned)x ? t : x;
+        }
         if (G >= 32) {
             t = __builtin_amdgcn_ds_swizzle(x, PWPP_SWZ16);
             x = (unsigned)t < (unsigned)x ? t : x;
@@ -69,7 +73,7 @@ struct Row {
         x += PWPP_DPP(x, PWPP_DPP_XOR1);
         x += PWPP_DPP(x, PWPP_DPP_XOR2);
         x += PWPP_DPP(x, PWPP_DPP_HMIR);
-        x += PWPP_DPP(x, PWPP_DPP_MIR);
+        if (G >= 16) x += PWPP_DPP(x, PWPP_DPP_MIR);
         if (G >= 32) x += __builtin_amdgcn_ds_swizzle(x, PWPP_SWZ16);
         if (G == 64) x = __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 32);
         return x;
@@ -90,7 +94,7 @@ struct Row {
         v = step64(v, 0);
         v = step64(v, 1);
         v = step64(v, 2);
-        v = step64(v, 3);
+        if (G >= 16) v = step64(v, 3);
         if (G >= 32) v = step64(v, 4);
         if (G == 64) {
             const int lo = (int)(unsigned)(unsigned long long)v, hi = (int)((unsigned long long)v >> 32);
@@ -270,15 +274,15 @@ __device__ __forceinline__ unsigned lane_strip(const LanePts &lp, unsigned act, 
 // classes 0-2: G lanes per patch, wave-local
 // ------------------------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(kBlock, 4) void k_fit_rows(PwppBatch Bt, int cls) {
+__global__ __launch_bounds__(kBlock, 4) void k_fit_rows(PwppBatch Bt, int b_lo, int b_hi) {
     // grid = (frames, blocks per frame): the frame is the FAST dimension.  Most blocks of a frame's
     // worst-case grid are empty; with the frame in blockIdx.y the working blocks formed a pattern
     // of period 32 = 8 XCDs x 4 SEs and landed on a quarter of the CUs (3x slower, measured).
     const int f = blockIdx.x;
     const PwppDevParams &P = Bt.P;
     const int NB = P.num_bins + 2;
-    const uint32_t *cs = Bt.cls_start + (size_t)f * 8;
-    const unsigned cbeg = cs[cls], cend = cs[cls + 1];
+    const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
+    const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
     const unsigned tid = blockIdx.y * kBlock + threadIdx.x;
     if (cbeg + (tid & ~63u) / G >= cend) return;  // this wave has no patch
     const unsigned slot = cbeg + tid / G;
@@ -399,18 +403,20 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_rows(PwppBatch Bt, int cls) {
     }
     if ((Bt.debug & 4) && lane_id() == 0) {  // timing probe: wave lifetime in 100 MHz ticks
         const unsigned long long dt = wall_clock64() - t_begin;
-        atomicMax(&Bt.dbg[cls * 4 + 0], dt);
-        atomicAdd(&Bt.dbg[cls * 4 + 1], dt);
-        atomicAdd(&Bt.dbg[cls * 4 + 2], 1ull);
+        const int probe = G == 16 ? 0 : (G == 32 ? 1 : 2);
+        atomicMax(&Bt.dbg[probe * 4 + 0], dt);
+        atomicAdd(&Bt.dbg[probe * 4 + 1], dt);
+        atomicAdd(&Bt.dbg[probe * 4 + 2], 1ull);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// class 3: 512 < n <= 16384 points.  Still ONE WAVE per patch: a workgroup per patch would leave
-// all but one wave idle during the serial eigen-solve (measured: 2.5 + 7.5 ms per 1024 frames
-// for 256- and 1024-thread workgroups), whereas independent waves keep every SIMD issuing.
-// The points do not fit a lane-private LDS slot any more; they are streamed from L2 at every
-// stage in chunks of 512 (8 per lane, 1 KiB per wave load instruction).
+// Streaming rows: G lanes per patch (8, 16 or 64), the points are re-read from L2 at every
+// stage in chunks of 8 per lane.  Fewer lanes per patch = more patches per wave = the serial
+// eigen-solve (the dominant instruction count) is shared by more patches; the price is more
+// points per lane.  Patches of a frame are sorted by size (k_czm_scan), so the rows of one
+// wave have similar trip counts.  A workgroup per big patch was tried and rejected: all but
+// one wave idle during the solve (2.5 + 7.5 ms per 1024 frames vs 2.6 ms for one wave each).
 // ------------------------------------------------------------------------------------------
 struct ChunkPts {
     LanePts lp;
@@ -418,12 +424,14 @@ struct ChunkPts {
     unsigned valid, strip;
 };
 
+template <int G>
 __device__ __forceinline__ void load_chunk(ChunkPts &cp, const float4 *pts, unsigned n, unsigned c) {
     cp.valid = 0;
     cp.strip = 0;
+    const unsigned j = (unsigned)lane_id() & (G - 1);
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
-        const unsigned i = (c << 9) + (unsigned)k * 64u + (unsigned)lane_id();
+        const unsigned i = c * (8u * G) + (unsigned)k * G + j;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n) {
             v = pts[i];
@@ -438,107 +446,117 @@ __device__ __forceinline__ void load_chunk(ChunkPts &cp, const float4 *pts, unsi
     }
 }
 
-// sum of the `take` smallest keys held by the wave (<= 8 sorted keys per lane), ascending order
-__device__ __forceinline__ double tournament_sum64(unsigned key[8], int take, double sum) {
-    for (int r = 0; r < take; ++r) {  // wave-uniform trip count
-        const unsigned head = key[0];
-        const unsigned m = Row<64>::min_u32(head);
-        sum += (double)key_z(m);
-        const int lowest = __ffsll((long long)__ballot(head == m)) - 1;
-        if (lane_id() == lowest) {
-#pragma unroll
-            for (int k = 0; k < 7; ++k) key[k] = key[k + 1];
-            key[7] = 0xFFFFFFFFu;
-        }
-    }
-    return sum;
-}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~Row<64>::min_u32(~v); }
 
-// LPR (ref :84-103) of a streamed patch.  Two light passes: (1) every lane's smallest eligible
-// key; the keff-th smallest of those 64 values, U, bounds the keff-th smallest key overall;
+// LPR (ref :84-103) of streamed rows.  Two light passes: (1) every lane's two smallest eligible
+// keys; the keff-th smallest of those 2G values, U, bounds the keff-th smallest key of the row;
 // (2) the keys below U are gathered (<= 8 per lane, practically 0-2) and summed in ascending
 // order, topped up with copies of U.  If a lane would have to hold more than 8, or fewer than
-// keff lanes own an eligible point, an exact but slower extraction by distinct values runs.
-__device__ double wave_stream_lpr(const float4 *pts, unsigned n, unsigned nchunk, bool use_cutoff, double cutoff,
-                                  int num_lpr) {
-    const int ln = lane_id();
-    unsigned lmin = 0xFFFFFFFFu;
+// keff such candidates exist, an exact but slower extraction by distinct values runs.
+template <int G>
+__device__ double srow_lpr(const float4 *pts, unsigned n, unsigned nchunk_max, bool need, bool use_cutoff, double cutoff,
+                           int num_lpr) {
+    const int j = lane_id() & (G - 1);
+    const unsigned INF = 0xFFFFFFFFu;
+    unsigned m1 = INF, m2 = INF;
     int elig = 0;
-    for (unsigned c = 0; c < nchunk; ++c) {
+    for (unsigned c = 0; c < nchunk_max; ++c) {
         ChunkPts cp;
-        load_chunk(cp, pts, n, c);
+        load_chunk<G>(cp, pts, need ? n : 0u, c);
         const unsigned act = cp.valid & ~cp.strip;
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
             const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
-            const unsigned key = e ? z_key(cp.lp.z[k]) : 0xFFFFFFFFu;
-            lmin = key < lmin ? key : lmin;
+            const unsigned key = e ? z_key(cp.lp.z[k]) : INF;
+            const unsigned hi = key < m1 ? m1 : key;  // the larger of (key, m1)
+            m1 = key < m1 ? key : m1;
+            m2 = hi < m2 ? hi : m2;
             elig += e ? 1 : 0;
         }
     }
-    const int total = Row<64>::sum_i32(elig);
-    const int keff = total < num_lpr ? total : num_lpr;
-    if (keff == 0) return 0.0;  // ref :103
-    const int nl = __popcll(__ballot(lmin != 0xFFFFFFFFu));
-    bool exact_path = nl < keff;
+    const int total = Row<G>::sum_i32(elig);
+    const int keff = total < num_lpr ? total : num_lpr;  // row-uniform
+    const int ncand = Row<G>::sum_i32((m1 != INF ? 1 : 0) + (m2 != INF ? 1 : 0));
+    bool exact_path = need && keff > 0 && ncand < keff;
+    const bool fast = need && keff > 0 && !exact_path;
     double sum = 0.0;
-    if (!exact_path) {
-        // U = keff-th smallest lane minimum
-        unsigned cur = lmin, U = 0;
-        for (int r = 0; r < keff; ++r) {
-            U = Row<64>::min_u32(cur);
-            const int lowest = __ffsll((long long)__ballot(cur == U)) - 1;
-            if (ln == lowest) cur = 0xFFFFFFFFu;
+    unsigned U = 0;
+    if (__any(fast)) {
+        {   // U = keff-th smallest of the lane candidates
+            unsigned k0 = m1, k1 = m2;
+            for (int r = 0; r < num_lpr; ++r) {
+                const bool take = fast && r < keff;
+                if (!__any(take)) break;
+                const unsigned m = Row<G>::min_u32(k0);
+                if (take) U = m;
+                const int lowest = __ffsll((long long)Row<G>::ballot(take && k0 == m)) - 1;
+                if (take && j == lowest) {
+                    k0 = k1;
+                    k1 = INF;
+                }
+            }
         }
         unsigned key[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) key[k] = 0xFFFFFFFFu;
-        int neq = 0;  // keys equal to U (only the existence of >= keff keys <= U is needed; kept for the debug build)
-        (void)neq;
+        for (int q = 0; q < 8; ++q) key[q] = INF;
         bool overflow = false;
-        for (unsigned c = 0; c < nchunk; ++c) {
+        for (unsigned c = 0; c < nchunk_max; ++c) {
             ChunkPts cp;
-            load_chunk(cp, pts, n, c);
+            load_chunk<G>(cp, pts, fast ? n : 0u, c);
             const unsigned act = cp.valid & ~cp.strip;
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) {
                 const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
                 const unsigned kk = z_key(cp.lp.z[k]);
-                neq += (e && kk == U) ? 1 : 0;
                 const bool cand = e && kk < U;
                 if (__any(cand)) {  // sorted insertion; whatever falls off the end must be "none"
-                    unsigned x = cand ? kk : 0xFFFFFFFFu;
+                    unsigned x = cand ? kk : INF;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) ce(key[q], x);
-                    overflow = overflow || (x != 0xFFFFFFFFu);
+                    overflow = overflow || (x != INF);
                 }
             }
         }
-        if (__any(overflow)) {
-            exact_path = true;
-        } else {
-            int nless = 0;
+        const bool row_over = Row<G>::ballot(overflow) != 0ull;
+        exact_path = exact_path || (fast && row_over);
+        const bool ok = fast && !row_over;
+        int nless = 0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) nless += key[q] != 0xFFFFFFFFu ? 1 : 0;
-            const int c_less = Row<64>::sum_i32(nless);
-            const int take = c_less < keff ? c_less : keff;
-            sum = tournament_sum64(key, take, 0.0);
-            const double zu = (double)key_z(U);
-            for (int r = take; r < keff; ++r) sum += zu;  // copies of U (there are at least keff keys <= U)
+        for (int q = 0; q < 8; ++q) nless += key[q] != INF ? 1 : 0;
+        const int c_less = Row<G>::sum_i32(nless);
+        const int take_n = c_less < keff ? c_less : keff;
+        for (int r = 0; r < num_lpr; ++r) {  // the take_n smallest gathered keys, ascending
+            const bool take = ok && r < take_n;
+            if (!__any(take)) break;
+            const unsigned head = key[0];
+            const unsigned m = Row<G>::min_u32(head);
+            if (take) sum += (double)key_z(m);
+            const int lowest = __ffsll((long long)Row<G>::ballot(take && head == m)) - 1;
+            if (take && j == lowest) {
+#pragma unroll
+                for (int q = 0; q < 7; ++q) key[q] = key[q + 1];
+                key[7] = INF;
+            }
+        }
+        const double zu = (double)key_z(U);
+        for (int r = 0; r < num_lpr; ++r) {  // copies of U (at least keff keys are <= U)
+            const bool take = ok && r >= take_n && r < keff;
+            if (take) sum += zu;
         }
     }
-    if (exact_path) {
+    if (__any(exact_path)) {
         // extraction by distinct values, ascending: one pass per distinct value among the keff smallest
-        sum = 0.0;
-        int remaining = keff;
+        double xsum = 0.0;
+        int remaining = exact_path ? keff : 0;
         bool first = true;
         unsigned prev = 0;
-        while (remaining > 0) {
-            unsigned vmin = 0xFFFFFFFFu;
+        for (int guard = 0; guard <= num_lpr; ++guard) {
+            if (!__any(remaining > 0)) break;
+            unsigned vmin = INF;
             int vcnt = 0;
-            for (unsigned c = 0; c < nchunk; ++c) {
+            for (unsigned c = 0; c < nchunk_max; ++c) {
                 ChunkPts cp;
-                load_chunk(cp, pts, n, c);
+                load_chunk<G>(cp, pts, remaining > 0 ? n : 0u, c);
                 const unsigned act = cp.valid & ~cp.strip;
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k) {
@@ -554,29 +572,40 @@ __device__ double wave_stream_lpr(const float4 *pts, unsigned n, unsigned nchunk
                     }
                 }
             }
-            const unsigned v = Row<64>::min_u32(vmin);
-            if (v == 0xFFFFFFFFu) break;  // (only NaN-keyed leftovers)
-            const int mult = Row<64>::sum_i32(vmin == v ? vcnt : 0);
-            const int take = mult < remaining ? mult : remaining;
-            const double zv = (double)key_z(v);
-            for (int r = 0; r < take; ++r) sum += zv;
-            remaining -= take;
-            prev = v;
+            const unsigned v = Row<G>::min_u32(vmin);
+            const int mult = Row<G>::sum_i32(vmin == v ? vcnt : 0);
+            if (remaining > 0) {
+                if (v == INF) {
+                    remaining = 0;  // (only NaN-keyed leftovers)
+                } else {
+                    const int take = mult < remaining ? mult : remaining;
+                    const double zv = (double)key_z(v);
+                    for (int r = 0; r < take; ++r) xsum += zv;
+                    remaining -= take;
+                    prev = v;
+                }
+            }
             first = false;
         }
+        if (exact_path) sum = xsum;
     }
-    return sum / (double)keff;  // ref :103
+    return keff ? sum / (double)keff : 0.0;  // ref :103
 }
 
-__global__ __launch_bounds__(kBlock, 4) void k_fit_wave(PwppBatch Bt) {
+template <int G>
+__global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo, int b_hi) {
     const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
     const PwppDevParams &P = Bt.P;
     const int NB = P.num_bins + 2;
-    const uint32_t *cs = Bt.cls_start + (size_t)f * 8;
-    const unsigned slot = cs[3] + blockIdx.y * kWaves + (unsigned)wave_id();
-    if (slot >= cs[4]) return;  // wave-uniform
-    const int bin = Bt.cls_list[(size_t)f * P.num_bins + slot];
-    const unsigned n = Bt.bin_count[(size_t)f * NB + bin];
+    const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
+    const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
+    const unsigned tid = blockIdx.y * kBlock + threadIdx.x;
+    if (cbeg + (tid & ~63u) / G >= cend) return;  // this wave has no patch
+    const unsigned slot = cbeg + tid / G;
+    const bool alive = slot < cend;  // row-uniform
+    const int j = lane_id() & (G - 1);
+    const int bin = alive ? (int)Bt.cls_list[(size_t)f * P.num_bins + slot] : 0;
+    const unsigned n = alive ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
     const PwppFrameDesc fd = Bt.frames[f];
     const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
     float4 *pts = Bt.sorted + fd.base + off;
@@ -586,8 +615,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_wave(PwppBatch Bt) {
     const double cutoff = P.margin * sensor_height;
     const bool use_cutoff = zone == 0;
     const float qscale = (float)(1 << P.fxp_shift);
-    const unsigned nchunk = (n + 511u) >> 9;
-    const int ln = lane_id();
+    const unsigned nchunk_max = wave_max_u32((n + 8u * G - 1u) / (8u * G));
 
     PlaneFit pl;
     pl.nx = pl.ny = pl.nz = 0.0f;
@@ -596,22 +624,27 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_wave(PwppBatch Bt) {
     pl.d = 0.0;
     double lpr = 0.0;
     bool lpr_valid = false;
-    int kind = (P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED;  // wave-uniform
+    int kind = !alive ? ST_DONE : ((P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED);  // row-uniform
     int it = 0;
 
-    for (int guard = 0; guard < 4 * P.num_iter + 8 && kind != ST_DONE; ++guard) {
-        if ((kind == ST_VPF || kind == ST_SEED) && !lpr_valid) {
-            lpr = wave_stream_lpr(pts, n, nchunk, use_cutoff, cutoff, P.num_lpr);
-            lpr_valid = true;
+    for (int guard = 0; guard < 4 * P.num_iter + 8; ++guard) {
+        if (!__any(kind != ST_DONE)) break;
+        const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
+        if (__any(need_lpr)) {
+            const double l = srow_lpr<G>(pts, n, nchunk_max, need_lpr, use_cutoff, cutoff, P.num_lpr);
+            if (need_lpr) {
+                lpr = l;
+                lpr_valid = true;
+            }
         }
         const double thr_seed = lpr + ((kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds);
         const bool last = kind == ST_ITER && it == P.num_iter - 1;
         Moments m;
         m.clear();
         unsigned run_g = 0, run_n = 0;
-        for (unsigned c = 0; c < nchunk; ++c) {
+        for (unsigned c = 0; c < nchunk_max; ++c) {
             ChunkPts cp;
-            load_chunk(cp, pts, n, c);
+            load_chunk<G>(cp, pts, kind != ST_DONE ? n : 0u, c);
             Moments mc;
             const unsigned gmask = lane_stage_moments(cp.lp, cp.valid & ~cp.strip, kind, thr_seed, P.th_dist, pl, qscale, mc);
             m.n += mc.n;
@@ -619,50 +652,51 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_wave(PwppBatch Bt) {
             for (int k = 0; k < 3; ++k) m.s1[k] += mc.s1[k];
 #pragma unroll
             for (int k = 0; k < 6; ++k) m.s2[k] += mc.s2[k];
-            if (last) {  // the split is written BEFORE the plane is replaced (ref :529-541)
-                const unsigned ngm = cp.valid & ~gmask;
+            if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
+                const unsigned gm = last ? gmask : 0u;
+                const unsigned ngm = last ? (cp.valid & ~gmask) : 0u;
                 unsigned tg, tn;
-                unsigned bg = run_g + Row<64>::excl_scan((unsigned)__popc(gmask), tg);
-                unsigned bn = run_n + Row<64>::excl_scan((unsigned)__popc(ngm), tn);
+                unsigned bg = run_g + Row<G>::excl_scan((unsigned)__popc(gm), tg);
+                unsigned bn = run_n + Row<G>::excl_scan((unsigned)__popc(ngm), tn);
                 run_g += tg;
                 run_n += tn;
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k) {
-                    if (gmask >> k & 1u)
+                    if (gm >> k & 1u)
                         plist[bg++] = (int)cp.w[k];
                     else if (ngm >> k & 1u)
                         plist[n - 1u - (bn++)] = (int)cp.w[k];
                 }
             }
         }
-        const long long cnt = Row<64>::sum_i64(m.n);
+        const long long cnt = Row<G>::sum_i64(m.n);
         {
             long long s1[3];
             __int128 s2[6];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) s1[k] = Row<64>::sum_i64(m.s1[k]);
+            for (int k = 0; k < 3; ++k) s1[k] = Row<G>::sum_i64(m.s1[k]);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) s2[k] = (__int128)Row<64>::sum_i64(m.s2[k]);  // <= 16384 points: fits int64
-            if (cnt > 0) plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);  // empty: ref :49
+            for (int k = 0; k < 6; ++k) s2[k] = (__int128)Row<G>::sum_i64(m.s2[k]);  // <= 65536 points: fits int64
+            if (kind != ST_DONE && cnt > 0) plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);  // empty: ref :49
         }
         if (kind == ST_VPF) {
             const bool vertical = (double)pl.nz < P.uprightness_thr;  // ref :489
-            if (vertical) {
+            if (__any(vertical)) {
                 bool any = false;
-                for (unsigned c = 0; c < nchunk; ++c) {
+                for (unsigned c = 0; c < nchunk_max; ++c) {
                     ChunkPts cp;
-                    load_chunk(cp, pts, n, c);
-                    const unsigned hit = lane_strip(cp.lp, cp.valid & ~cp.strip, true, pl, P.th_dist_v);
+                    load_chunk<G>(cp, pts, vertical ? n : 0u, c);
+                    const unsigned hit = lane_strip(cp.lp, cp.valid & ~cp.strip, vertical, pl, P.th_dist_v);
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k) {
                         if (hit >> k & 1u) {
-                            const unsigned i = (c << 9) + (unsigned)k * 64u + (unsigned)ln;
+                            const unsigned i = c * (8u * G) + (unsigned)k * G + (unsigned)j;
                             reinterpret_cast<unsigned *>(pts)[(size_t)i * 4 + 3] = cp.w[k] | 0x80000000u;
                         }
                     }
                     any = any || hit != 0;
                 }
-                if (__any(any)) lpr_valid = false;  // the working set changed
+                if (Row<G>::ballot(any) != 0ull) lpr_valid = false;  // the working set changed
             }
             ++it;
             if (!vertical || it >= P.num_iter) {
@@ -673,9 +707,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_wave(PwppBatch Bt) {
             kind = (cnt == 0 && P.enable_RVPF != 0 && zone != 0) ? ST_LAZY : ST_ITER;
         } else if (kind == ST_LAZY) {
             kind = ST_ITER;
-        } else {  // ST_ITER
+        } else if (kind == ST_ITER) {
             if (last) {
-                if (ln == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt);
+                if (j == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt);
                 kind = ST_DONE;
             }
             ++it;
@@ -886,14 +920,14 @@ __device__ __forceinline__ double point_to_plane(float nx, float ny, float nz, d
     return nx * p.x + ny * p.y + nz * p.z + d;
 }
 
-__global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt) {
+__global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
     __shared__ FitShared sh;
     const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
     const PwppDevParams &P = Bt.P;
     const int NB = P.num_bins + 2;
-    const uint32_t *cs = Bt.cls_start + (size_t)f * 8;
-    const unsigned slot = cs[5] + blockIdx.y;
-    if (slot >= cs[6]) return;
+    const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
+    const unsigned slot = cs[b_lo] + blockIdx.y;
+    if (slot >= cs[PWPP_NUM_BUCKETS]) return;
     const int bin = Bt.cls_list[(size_t)f * P.num_bins + slot];
     const unsigned n = Bt.bin_count[(size_t)f * NB + bin];
     PwppPatchRec *rec = Bt.recs + (size_t)f * P.num_bins + bin;
@@ -1030,7 +1064,8 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt) {
 
 }  // namespace
 
-// launches of K4; ev (optional) = 6 events recorded around the five launches
+// launches of K4; ev (optional) = 7 events recorded around up to six launches
+#define PWPP_DEFAULT_FIT_PLAN "S16:1023,S64:65535"
 extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev) {
     const PwppBatch &B = *batch;
     const int F = B.num_frames, nb = B.P.num_bins;
@@ -1041,16 +1076,47 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
         if (c > (unsigned)nb) c = (unsigned)nb;
         return c < 1 ? 1u : c;
     };
-    if (ev) (void)hipEventRecord(ev[0], stream);
-    hipLaunchKernelGGL(k_fit_rows<16>, dim3(F, (cap(1) + 15) / 16), dim3(kBlock), 0, stream, B, 0);
-    if (ev) (void)hipEventRecord(ev[1], stream);
-    hipLaunchKernelGGL(k_fit_rows<32>, dim3(F, (cap(129) + 7) / 8), dim3(kBlock), 0, stream, B, 1);
-    if (ev) (void)hipEventRecord(ev[2], stream);
-    hipLaunchKernelGGL(k_fit_rows<64>, dim3(F, (cap(257) + 3) / 4), dim3(kBlock), 0, stream, B, 2);
-    if (ev) (void)hipEventRecord(ev[3], stream);
-    hipLaunchKernelGGL(k_fit_wave, dim3(F, (cap(513) + kWaves - 1) / kWaves), dim3(kBlock), 0, stream, B);
-    if (ev) (void)hipEventRecord(ev[4], stream);
-    hipLaunchKernelGGL(k_fit_stream, dim3(F, cap(16385)), dim3(kBlock), 0, stream, B);
+    // The plan: which kernel handles which size range (ranges = runs of the quarter-octave size
+    // buckets k_czm_scan sorts the patches into).  "L16:127" = LDS-parked rows of 16 lanes for
+    // patches up to 127 points, "S16:1023" = streaming rows of 16 lanes up to 1023 points, ...;
+    // whatever is larger than the last entry goes to the workgroup-per-patch kernel.
+    // PWPP_FIT_PLAN overrides the default for tuning experiments.
+    const char *plan = getenv("PWPP_FIT_PLAN");
+    if (!plan) plan = PWPP_DEFAULT_FIT_PLAN;
+    int k_lo = 0, slot = 0;
+    unsigned n_lo = 1;
+    const char *p = plan;
+    while (*p && slot < 5) {
+        char mode = p[0];
+        int g = 0;
+        unsigned upper = 0;
+        if (sscanf(p + 1, "%d:%u", &g, &upper) != 2) break;
+        if (mode == 'L' && upper > 8u * (unsigned)g - 1u) upper = 8u * (unsigned)g - 1u;  // 8 points per lane in LDS
+        if (upper > 65535u) upper = 65535u;  // int64 second moments hold up to 2^17 points; keep a margin
+        const int k_hi = pwpp_size_bucket(upper + 1u);
+        if (k_hi > k_lo) {
+            if (ev) (void)hipEventRecord(ev[slot], stream);
+            const unsigned patches = cap(n_lo);
+            const dim3 grid(F, (patches * (unsigned)g + kBlock - 1) / kBlock);
+            if (mode == 'L' && g == 16) hipLaunchKernelGGL(k_fit_rows<16>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+            else if (mode == 'L' && g == 32) hipLaunchKernelGGL(k_fit_rows<32>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+            else if (mode == 'L' && g == 64) hipLaunchKernelGGL(k_fit_rows<64>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+            else if (mode == 'S' && g == 8) hipLaunchKernelGGL(k_fit_srows<8>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+            else if (mode == 'S' && g == 16) hipLaunchKernelGGL(k_fit_srows<16>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+            else if (mode == 'S' && g == 32) hipLaunchKernelGGL(k_fit_srows<32>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+            else if (mode == 'S' && g == 64) hipLaunchKernelGGL(k_fit_srows<64>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+            else return (int)hipErrorInvalidValue;
+            ++slot;
+            k_lo = k_hi;
+            n_lo = pwpp_bucket_floor(k_hi);
+        }
+        while (*p && *p != ',') ++p;
+        if (*p == ',') ++p;
+    }
+    for (; slot < 5; ++slot)
+        if (ev) (void)hipEventRecord(ev[slot], stream);
     if (ev) (void)hipEventRecord(ev[5], stream);
+    hipLaunchKernelGGL(k_fit_stream, dim3(F, cap(n_lo)), dim3(kBlock), 0, stream, B, k_lo);
+    if (ev) (void)hipEventRecord(ev[6], stream);
     return (int)hipGetLastError();
 }

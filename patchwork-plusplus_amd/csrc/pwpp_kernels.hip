@@ -167,10 +167,10 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
         Bt.results[f].n_rnr = (int)cnt[Bt.P.num_bins];
         Bt.results[f].n_oor = (int)cnt[Bt.P.num_bins + 1];
     }
-    // patches of this frame grouped by size class (work lists of the K4 kernels)
-    __shared__ unsigned s_cnt[PWPP_NUM_CLASSES], s_start[PWPP_NUM_CLASSES + 1], s_cur[PWPP_NUM_CLASSES];
+    // patches of this frame sorted by size bucket (work lists of the K4 kernels)
+    __shared__ unsigned s_cnt[PWPP_NUM_BUCKETS], s_start[PWPP_NUM_BUCKETS + 1], s_cur[PWPP_NUM_BUCKETS];
     const int B = Bt.P.num_bins;
-    if (threadIdx.x < PWPP_NUM_CLASSES) {
+    if (threadIdx.x < PWPP_NUM_BUCKETS) {
         s_cnt[threadIdx.x] = 0;
         s_cur[threadIdx.x] = 0;
     }
@@ -178,31 +178,31 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     for (int b = threadIdx.x; b < B; b += kBlock) {
         const unsigned n = cnt[b];
         if ((uint64_t)n < Bt.P.min_pts) continue;  // small bin (ref :191-195)
+        PwppPatchRec *rec = Bt.recs + (size_t)f * B + b;
+        rec->valid = 0;
         if (n == 0) {  // only with num_min_pts <= 0: no fit runs (ref :49); K5 inherits the previous plane
-            PwppPatchRec *rec = Bt.recs + (size_t)f * B + b;
-            rec->valid = 0;
             rec->n_points = 0;
             rec->n_ground = 0;
             rec->n_nonground = 0;
             continue;
         }
-        atomicAdd(&s_cnt[patch_class(n)], 1u);
+        atomicAdd(&s_cnt[pwpp_size_bucket(n)], 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned run = 0;
-        for (int c = 0; c < PWPP_NUM_CLASSES; ++c) {
+        for (int c = 0; c < PWPP_NUM_BUCKETS; ++c) {
             s_start[c] = run;
             run += s_cnt[c];
         }
-        s_start[PWPP_NUM_CLASSES] = run;
-        for (int c = 0; c <= PWPP_NUM_CLASSES; ++c) Bt.cls_start[(size_t)f * 8 + c] = s_start[c];
+        s_start[PWPP_NUM_BUCKETS] = run;
     }
     __syncthreads();
+    for (int c = threadIdx.x; c <= PWPP_NUM_BUCKETS; c += kBlock) Bt.cls_start[(size_t)f * PWPP_CLS_STRIDE + c] = s_start[c];
     for (int b = threadIdx.x; b < B; b += kBlock) {
         const unsigned n = cnt[b];
         if ((uint64_t)n < Bt.P.min_pts || n == 0) continue;
-        const int c = patch_class(n);
+        const int c = pwpp_size_bucket(n);
         Bt.cls_list[(size_t)f * B + s_start[c] + atomicAdd(&s_cur[c], 1u)] = (uint16_t)b;
     }
 }
@@ -975,14 +975,14 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
     if (ev) (void)hipEventRecord(ev[2], stream);
     if (gx > 0) hipLaunchKernelGGL(k_czm_scatter, dim3(gx, F), dim3(kBlock), 0, stream, B);
-    const int frc = pwpp_launch_fit(batch, stream, ev ? ev + 3 : nullptr);  // records ev[3..8]
+    const int frc = pwpp_launch_fit(batch, stream, ev ? ev + 3 : nullptr);  // records ev[3..9]
     if (frc) return frc;
     if (B.P.min_pts == 0)
         hipLaunchKernelGGL(k_gle_tgr_seq, dim3(F), dim3(64), 0, stream, B);  // empty bins inherit planes: serial
     else
         hipLaunchKernelGGL(k_gle_tgr, dim3(F), dim3(kBlock), 0, stream, B);
-    if (ev) (void)hipEventRecord(ev[9], stream);
-    hipLaunchKernelGGL(k_emit, dim3(NB, F), dim3(kBlock), 0, stream, B);
     if (ev) (void)hipEventRecord(ev[10], stream);
+    hipLaunchKernelGGL(k_emit, dim3(NB, F), dim3(kBlock), 0, stream, B);
+    if (ev) (void)hipEventRecord(ev[11], stream);
     return (int)hipGetLastError();
 }

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libpwpp_hip.so")
 LAYOUT_ROW_MAJOR, LAYOUT_COL_MAJOR = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 MODE_FRESH, MODE_STREAMS = 0, 1
-NUM_KERNELS = 10
+NUM_KERNELS = 11
 
 DEC_NAMES = {1: "not_upright", 2: "far_ground", 3: "heading", 4: "ground", 5: "tgr_reject", 6: "tgr_revert"}
 
