@@ -126,7 +126,7 @@ def test_synthetic_with_edge_cases(oracle, seed):
 
 
 PARAM_VARIANTS = [
-    dict(enable_RNR=0), dict(enable_RVPF=0), dict(enable_TGR=0),
+    dict(enable_RNR=0), dict(enable_RVPF=0), dict(enable_TGR=0), dict(num_min_pts=0),
     dict(num_iter=1), dict(num_iter=5), dict(num_lpr=1), dict(num_lpr=64), dict(num_min_pts=1), dict(num_min_pts=200),
     dict(th_dist=0.2, th_seeds=0.3), dict(uprightness_thr=0.9), dict(max_range=50.0, min_range=1.0),
     dict(sensor_height=2.0), dict(num_rings_of_interest=2), dict(adaptive_seed_selection_margin=-0.9),
@@ -257,3 +257,55 @@ def test_pybind_module_end_to_end(kitti, golden):
         assert abs(pw.getHeight() - golden["f32/seq/%d/state" % k][0]) < 1e-4
         assert pw.getTimeTaken() > 0
     pw.estimateGround(np.asfortranarray(kitti[0]).astype(np.float64))  # any array convertible to float32
+
+
+def test_points_on_bin_boundaries(oracle):
+    """The float fast path of the CZM binning must hand every point near a ring / sector / zone /
+    range boundary to the exact double computation: clouds made of points within a few float
+    ulps of the boundaries, compared bin by bin (patch point counts) with the oracle."""
+    rng = np.random.default_rng(42)
+    p = pwpp_hip.default_params()
+    mn, mx = p.min_range, p.max_range
+    z2, z3, z4 = (7 * mn + mx) / 8.0, (3 * mn + mx) / 4.0, (mn + mx) / 2.0
+    mins = [mn, z2, z3, z4, mx]
+    radii = []
+    for k in range(4):
+        for r in range(p.num_rings_each_zone[k] + 1):
+            radii.append(mins[k] + (mins[k + 1] - mins[k]) * r / p.num_rings_each_zone[k])
+    radii = np.array(radii)
+    pts = []
+    for k in range(4):
+        ns = p.num_sectors_each_zone[k]
+        for s in range(ns + 1):
+            th = 2 * np.pi * s / ns
+            for r in rng.uniform(mins[k], mins[k + 1], 40):
+                for d in (-3e-7, -1e-7, 0.0, 1e-7, 3e-7):
+                    pts.append([r * np.cos(th + d), r * np.sin(th + d)])
+    for r in radii:
+        for th in rng.uniform(0, 2 * np.pi, 60):
+            for d in (-2e-6, -5e-7, 0.0, 5e-7, 2e-6):
+                pts.append([(r * (1 + d)) * np.cos(th), (r * (1 + d)) * np.sin(th)])
+    xy = np.array(pts)
+    cloud = np.zeros((len(xy), 4), np.float32)
+    cloud[:, :2] = xy
+    cloud[:, 2] = -1.7 + rng.normal(0, 0.03, len(xy))
+    cloud[:, 3] = 0.5
+    filler = pwpp_synth.make_cloud(21, beams=32, azimuth_steps=1200)
+    cloud = np.concatenate([cloud, filler])
+    h = pwpp_hip.Handle()
+    h.estimate_ground(cloud)
+    ref = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(cloud)
+    assert_frame_equal(h, 0, ref, cloud.shape[0], state_index=0)
+
+
+@pytest.mark.parametrize("plan", ["L16:127,L32:255,L64:511,S64:65535", "S8:63,S16:255,S32:1023,S64:4095", "S8:65535", "S64:65535"])
+def test_every_fit_kernel_variant(kitti, oracle, plan, monkeypatch):
+    """All fit kernels (LDS-parked rows, streaming rows of every width, the workgroup kernel for
+    whatever exceeds the plan) produce the same bit-exact result: the integer plane-fit sums do
+    not depend on how many lanes share a patch."""
+    monkeypatch.setenv("PWPP_FIT_PLAN", plan)
+    h = pwpp_hip.Handle()
+    syn = pwpp_synth.add_edge_cases(pwpp_synth.make_cloud(8), 8)
+    h.estimate_ground_batch([kitti[0], syn, kitti[5]], mode=pwpp_hip.MODE_FRESH)
+    for k, pts in enumerate((kitti[0], syn, kitti[5])):
+        assert_frame_equal(h, k, ol.Estimator(oracle, arith=ol.ARITH_FXP).run(pts), pts.shape[0])
