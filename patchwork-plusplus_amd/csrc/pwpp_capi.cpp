@@ -87,8 +87,8 @@ struct PinnedBuf {
     }
 };
 
-const char *kKernelNames[PWPP_NUM_KERNELS] = {"k_czm_bin", "k_czm_scan", "k_czm_scatter", "k_fit[0]", "k_fit[1]",
-                                              "k_fit[2]", "k_fit[3]", "k_fit[4]", "k_fit_stream", "k_gle_tgr", "k_emit"};
+const char *kKernelNames[PWPP_NUM_KERNELS] = {"k_czm_bin", "k_czm_scan", "k_czm_scatter", "k_fit_w64", "k_fit_srows<64>",
+                                              "k_fit[2]", "k_fit[3]", "k_fit[4]", "k_fit_stream", "k_gle_tgr", "k_emit"};  // fit slots: default PWPP_FIT_PLAN
 
 }  // namespace
 
@@ -125,6 +125,7 @@ struct pwpp_handle {
     DevBuf<uint32_t> d_cls_start;  // frames * 8
     DevBuf<uint16_t> d_cls_list;   // frames * B
     DevBuf<PwppPatchRec> d_recs;
+    DevBuf<PwppFitState> d_fit;
     DevBuf<float> d_centers, d_normals;
     DevBuf<PwppFrameResult> d_results;
     PinnedBuf<PwppFrameResult> h_results;
@@ -378,6 +379,7 @@ int pwpp_destroy(pwpp_handle *h) {
     h->d_out.release();
     h->d_bins.release();
     h->d_recs.release();
+    h->d_fit.release();
     h->d_cls_start.release();
     h->d_cls_list.release();
     h->d_centers.release();
@@ -437,6 +439,7 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     if ((rc = h->d_out.ensure(tp))) return rc;
     if ((rc = h->d_bins.ensure((size_t)frames * NB * 5))) return rc;
     if ((rc = h->d_recs.ensure((size_t)frames * B))) return rc;
+    if ((rc = h->d_fit.ensure((size_t)frames * B))) return rc;
     if ((rc = h->d_cls_start.ensure((size_t)frames * PWPP_CLS_STRIDE))) return rc;
     if ((rc = h->d_cls_list.ensure((size_t)frames * B))) return rc;
     if ((rc = h->d_centers.ensure((size_t)frames * B * 3))) return rc;
@@ -513,6 +516,7 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     bt.sorted = h->d_sorted.p;
     bt.plist = h->d_plist.p;
     bt.recs = h->d_recs.p;
+    bt.fit = h->d_fit.p;
     bt.out_idx = h->d_out.p;
     bt.centers = h->d_centers.p;
     bt.normals = h->d_normals.p;

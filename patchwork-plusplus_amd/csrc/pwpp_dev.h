@@ -68,6 +68,17 @@ struct PwppPatchRec {  // one per (frame, bin); written by k_patch_fit, finished
     int32_t valid;  // 0: no fit ran in this bin (empty bin let through by num_min_pts <= 0)
 };
 
+struct PwppFitState {  // per (frame, bin): the fit chain of a patch between the phase kernels
+    long long mom[10];  // integer moments left by the points phase: n, S1[3], S2[6]
+    double lpr;
+    double d;
+    float nx, ny, nz;
+    float mean[3];
+    float sv[3];
+    int32_t kind, it, lpr_valid, need_strip;
+    int32_t pad_;
+};
+
 struct PwppFrameResult {
     int32_t n_ground, n_nonground, n_patches, n_rnr, n_oor, n_dropped, pad0, pad1;
 };
@@ -91,6 +102,7 @@ struct PwppBatch {
     float4 *sorted;              // [total points] {x,y,z,bits(idx)} grouped by bin; bit 31 of w = stripped by R-VPF
     int32_t *plist;              // [total points] per patch: ground candidates from the front, non-ground from the back
     PwppPatchRec *recs;          // [frames][B]
+    PwppFitState *fit;           // [frames][B]
     uint32_t *dst_a;             // [frames][B+2] output offset of sub-list A (candidates / whole bin)
     uint32_t *dst_b;             // [frames][B+2] output offset of sub-list B (regionwise non-ground)
     int32_t *out_idx;            // [total points] per frame: ground list then non-ground list

@@ -720,6 +720,448 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
 // ------------------------------------------------------------------------------------------
 // class 5: bins too large for registers, streamed from L2/HBM on every pass
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// k_fit_w64: one wave = 64 patches.  The VALU profile of the row kernels showed the serial
+// eigen-solve (~3800 instructions, executed once per wave for only 1-4 patches) to be ~75 %
+// of all issue cycles of the fit stage.  Here a wave owns up to 64 patches of a frame:
+//   * points phases run 4 patches at a time in rows of 16 lanes (points streamed from L2) and
+//     leave the ten integer moments of every patch in LDS;
+//   * the solve phase runs ONCE per stage with lane p solving patch p -- 64 different 3x3
+//     problems per instruction stream instead of 1-4;
+//   * lane p ("owner") carries patch p's state machine (stage, LPR, plane) in registers and
+//     publishes what the rows need (plane, thresholds) through LDS.
+// Patches are handed to the waves of a frame round-robin over the size-sorted list, so every
+// wave gets a similar mix and the 4 rows of a points phase have similar trip counts.
+// Waves are independent: no workgroup barrier anywhere.
+// ------------------------------------------------------------------------------------------
+struct W64Patch {
+    unsigned off, n;
+    int kind;        // stage of the coming points phase; ST_DONE = nothing to do
+    int flags;       // bit0: last R-GPF round (write the split), bit1: zone-0 cut-off applies
+    float nx, ny, nz, pad_;
+    double d;
+    double thr_seed;
+};
+struct W64Shared {
+    W64Patch p[64];
+    long long mom[64][10];
+    double lpr[64];
+    int stripped[64];
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, int b_hi) {
+    __shared__ W64Shared sh_all[kWaves];
+    W64Shared &sh = sh_all[wave_id()];
+    constexpr int G = 16;
+    const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
+    const PwppDevParams &P = Bt.P;
+    const int NB = P.num_bins + 2;
+    const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
+    const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
+    const unsigned npatch = cend - cbeg;
+    const unsigned nwaves = (npatch + 63u) / 64u;
+    const unsigned w = blockIdx.y * kWaves + (unsigned)wave_id();
+    if (w >= nwaves) return;  // wave-uniform
+    const int ln = lane_id();
+    const int j = ln & (G - 1), row = ln >> 4;
+    const PwppFrameDesc fd = Bt.frames[f];
+    float4 *frame_pts = Bt.sorted + fd.base;
+    int *frame_plist = Bt.plist + fd.base;
+    const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
+    const double cutoff = P.margin * sensor_height;  // ref :90
+    const float qscale = (float)(1 << P.fxp_shift);
+
+    // ---- owner lane: patch `ln` of this wave
+    const unsigned slot = cbeg + w + (unsigned)ln * nwaves;
+    const bool alive = slot < cend;
+    const int bin = alive ? (int)Bt.cls_list[(size_t)f * P.num_bins + slot] : 0;
+    const unsigned n = alive ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
+    const unsigned off = alive ? Bt.bin_off[(size_t)f * NB + bin] : 0u;
+    const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
+    PlaneFit pl;
+    pl.nx = pl.ny = pl.nz = 0.0f;
+    pl.mean[0] = pl.mean[1] = pl.mean[2] = 0.0f;
+    pl.sv[0] = pl.sv[1] = pl.sv[2] = 0.0f;
+    pl.d = 0.0;
+    double lpr = 0.0;
+    bool lpr_valid = false;
+    int kind = !alive ? ST_DONE : ((P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED);
+    int it = 0;
+    sh.p[ln].off = off;
+    sh.p[ln].n = n;
+    sh.p[ln].kind = ST_DONE;
+    sh.p[ln].flags = zone == 0 ? 2 : 0;
+    sh.stripped[ln] = 0;
+    wave_lds_sync();
+
+    for (int guard = 0; guard < 4 * P.num_iter + 8; ++guard) {
+        if (!__any(kind != ST_DONE)) break;
+
+        // ---- A. lowest-point representative (ref :84-103) for the patches whose working set is new
+        const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
+        const unsigned long long lpr_mask = __ballot(need_lpr);
+        if (lpr_mask) {
+            for (int sb = 0; sb < 16; ++sb) {
+                if (((lpr_mask >> (4 * sb)) & 0xFull) == 0ull) continue;
+                const int q = 4 * sb + row;
+                const bool need_row = (lpr_mask >> q) & 1ull;
+                const unsigned qn = sh.p[q].n, qoff = sh.p[q].off;
+                const bool use_cutoff = (sh.p[q].flags & 2) != 0;
+                const unsigned nchunk_max = wave_max_u32(need_row ? (qn + 8u * G - 1u) / (8u * G) : 0u);
+                const double l = srow_lpr<G>(frame_pts + qoff, qn, nchunk_max, need_row, use_cutoff, cutoff, P.num_lpr);
+                if (need_row && j == 0) sh.lpr[q] = l;
+            }
+            wave_lds_sync();
+            if (need_lpr) {
+                lpr = sh.lpr[ln];
+                lpr_valid = true;
+            }
+        }
+
+        // ---- B. publish the stage of every patch
+        {
+            const bool last = kind == ST_ITER && it == P.num_iter - 1;
+            sh.p[ln].kind = kind;
+            sh.p[ln].flags = (zone == 0 ? 2 : 0) | (last ? 1 : 0);
+            sh.p[ln].nx = pl.nx;
+            sh.p[ln].ny = pl.ny;
+            sh.p[ln].nz = pl.nz;
+            sh.p[ln].d = pl.d;
+            sh.p[ln].thr_seed = lpr + ((kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds);
+        }
+        wave_lds_sync();
+
+        // ---- C. points phase: 4 patches at a time, 16 lanes each
+        const unsigned long long act_mask = __ballot(kind != ST_DONE);
+        for (int sb = 0; sb < 16; ++sb) {
+            if (((act_mask >> (4 * sb)) & 0xFull) == 0ull) continue;
+            const int q = 4 * sb + row;
+            const W64Patch pp = sh.p[q];
+            const bool on = pp.kind != ST_DONE;
+            const bool last = on && (pp.flags & 1);
+            PlaneFit qpl;
+            qpl.nx = pp.nx;
+            qpl.ny = pp.ny;
+            qpl.nz = pp.nz;
+            qpl.d = pp.d;
+            float4 *pts = frame_pts + pp.off;
+            int *plist = frame_plist + pp.off;
+            const unsigned qn = on ? pp.n : 0u;
+            const unsigned nchunk_max = wave_max_u32((qn + 8u * G - 1u) / (8u * G));
+            Moments m;
+            m.clear();
+            unsigned run_g = 0, run_n = 0;
+            for (unsigned c = 0; c < nchunk_max; ++c) {
+                ChunkPts cp;
+                load_chunk<G>(cp, pts, qn, c);
+                Moments mc;
+                const unsigned gmask = lane_stage_moments(cp.lp, cp.valid & ~cp.strip, pp.kind, pp.thr_seed, P.th_dist, qpl, qscale, mc);
+                m.n += mc.n;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) m.s1[k] += mc.s1[k];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) m.s2[k] += mc.s2[k];
+                if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
+                    const unsigned gm = last ? gmask : 0u;
+                    const unsigned ngm = last ? (cp.valid & ~gmask) : 0u;
+                    unsigned tg, tn;
+                    unsigned bg = run_g + Row<G>::excl_scan((unsigned)__popc(gm), tg);
+                    unsigned bn = run_n + Row<G>::excl_scan((unsigned)__popc(ngm), tn);
+                    run_g += tg;
+                    run_n += tn;
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k) {
+                        if (gm >> k & 1u)
+                            plist[bg++] = (int)cp.w[k];
+                        else if (ngm >> k & 1u)
+                            plist[qn - 1u - (bn++)] = (int)cp.w[k];
+                    }
+                }
+            }
+            long long v[10];
+            v[0] = Row<G>::sum_i64(m.n);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[1 + k] = Row<G>::sum_i64(m.s1[k]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v[4 + k] = Row<G>::sum_i64(m.s2[k]);
+            if (on && j < 10) {  // lane j of the row stores moment j
+                long long mine = v[0];
+#pragma unroll
+                for (int k = 1; k < 10; ++k) mine = j == k ? v[k] : mine;
+                sh.mom[q][j] = mine;
+            }
+        }
+        wave_lds_sync();
+
+        // ---- D. solve phase: lane p fits patch p (ref :47-75)
+        long long cnt = 0;
+        if (kind != ST_DONE) {
+            cnt = sh.mom[ln][0];
+            if (cnt > 0) {  // empty set: the previous plane stays (ref :49)
+                const long long s1[3] = {sh.mom[ln][1], sh.mom[ln][2], sh.mom[ln][3]};
+                __int128 s2[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) s2[k] = (__int128)sh.mom[ln][4 + k];  // <= 65535 points: fits int64
+                plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);
+            }
+        }
+
+        // ---- E. R-VPF strip (ref :489-505) for the zone-0 patches whose plane came out vertical
+        const bool vertical = kind == ST_VPF && (double)pl.nz < P.uprightness_thr;
+        const unsigned long long v_mask = __ballot(vertical);
+        if (v_mask) {
+            sh.p[ln].nx = pl.nx;
+            sh.p[ln].ny = pl.ny;
+            sh.p[ln].nz = pl.nz;
+            sh.p[ln].d = pl.d;
+            sh.stripped[ln] = 0;
+            wave_lds_sync();
+            for (int sb = 0; sb < 16; ++sb) {
+                if (((v_mask >> (4 * sb)) & 0xFull) == 0ull) continue;
+                const int q = 4 * sb + row;
+                const bool vrow = (v_mask >> q) & 1ull;
+                const W64Patch pp = sh.p[q];
+                PlaneFit qpl;
+                qpl.nx = pp.nx;
+                qpl.ny = pp.ny;
+                qpl.nz = pp.nz;
+                qpl.d = pp.d;
+                float4 *pts = frame_pts + pp.off;
+                const unsigned qn = vrow ? pp.n : 0u;
+                const unsigned nchunk_max = wave_max_u32((qn + 8u * G - 1u) / (8u * G));
+                bool any = false;
+                for (unsigned c = 0; c < nchunk_max; ++c) {
+                    ChunkPts cp;
+                    load_chunk<G>(cp, pts, qn, c);
+                    const unsigned hit = lane_strip(cp.lp, cp.valid & ~cp.strip, vrow, qpl, P.th_dist_v);
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k) {
+                        if (hit >> k & 1u) {
+                            const unsigned i = c * (8u * G) + (unsigned)k * G + (unsigned)j;
+                            reinterpret_cast<unsigned *>(pts)[(size_t)i * 4 + 3] = cp.w[k] | 0x80000000u;
+                        }
+                    }
+                    any = any || hit != 0;
+                }
+                if (Row<G>::ballot(any) != 0ull && j == 0) sh.stripped[q] = 1;
+            }
+            wave_lds_sync();
+            if (vertical && sh.stripped[ln]) lpr_valid = false;  // the working set changed
+        }
+
+        // ---- what comes next for the patch of this lane
+        if (kind == ST_VPF) {
+            ++it;
+            if (!vertical || it >= P.num_iter) {  // ref :506 / loop end
+                kind = ST_SEED;
+                it = 0;
+            }
+        } else if (kind == ST_SEED) {
+            kind = (cnt == 0 && P.enable_RVPF != 0 && zone != 0) ? ST_LAZY : ST_ITER;
+        } else if (kind == ST_LAZY) {
+            kind = ST_ITER;
+        } else if (kind == ST_ITER) {
+            if (it == P.num_iter - 1) {
+                write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt);
+                kind = ST_DONE;
+            }
+            ++it;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Phase kernels ("P" plan): the fit chain cut at every plane fit.
+//   k_ph_rows   rows of 16 lanes: [R-VPF strip] -> [LPR] -> points phase -> ten integer moments
+//               per patch to global memory.  No eigen-solve in this kernel: few registers,
+//               eight waves per SIMD to hide the L2 latency of the streamed points.
+//   k_ph_solve  ONE LANE PER PATCH: plane from the moments + the state transition.  64 different
+//               3x3 problems per wave instruction stream instead of 1-4: the solve, ~75 % of the
+//               issue cycles of the row kernels, shrinks to a few percent.
+// A batch runs 2*num_iter + 2 rounds of (rows, solve); patches that are finished exit at once.
+// ------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kBlock, 5) void k_ph_rows(PwppBatch Bt, int b_lo, int b_hi) {
+    const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
+    const PwppDevParams &P = Bt.P;
+    const int NB = P.num_bins + 2;
+    const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
+    const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
+    const unsigned tid = blockIdx.y * kBlock + threadIdx.x;
+    if (cbeg + (tid & ~63u) / G >= cend) return;  // this wave has no patch
+    const unsigned slot = cbeg + tid / G;
+    const bool alive = slot < cend;  // row-uniform
+    const int j = lane_id() & (G - 1);
+    const int bin = alive ? (int)Bt.cls_list[(size_t)f * P.num_bins + slot] : 0;
+    PwppFitState *st = Bt.fit + (size_t)f * P.num_bins + bin;
+    const int kind = alive ? st->kind : ST_DONE;
+    if (!__any(kind != ST_DONE)) return;
+    const unsigned n = kind != ST_DONE ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
+    const PwppFrameDesc fd = Bt.frames[f];
+    const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
+    float4 *pts = Bt.sorted + fd.base + off;
+    int *plist = Bt.plist + fd.base + off;
+    const bool use_cutoff = bin < P.bin_base[1];  // zone 0
+    const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
+    const double cutoff = P.margin * sensor_height;  // ref :90
+    const float qscale = (float)(1 << P.fxp_shift);
+    const unsigned nchunk_max = wave_max_u32((n + 8u * G - 1u) / (8u * G));
+    PlaneFit pl;
+    pl.nx = st->nx;
+    pl.ny = st->ny;
+    pl.nz = st->nz;
+    pl.d = st->d;
+    bool lpr_valid = kind != ST_DONE && st->lpr_valid != 0;
+    double lpr = st->lpr;
+
+    // ---- R-VPF strip decided by the previous solve (ref :489-505)
+    const bool strip = kind != ST_DONE && st->need_strip != 0;
+    if (__any(strip)) {
+        bool any = false;
+        for (unsigned c = 0; c < nchunk_max; ++c) {
+            ChunkPts cp;
+            load_chunk<G>(cp, pts, strip ? n : 0u, c);
+            const unsigned hit = lane_strip(cp.lp, cp.valid & ~cp.strip, strip, pl, P.th_dist_v);
+#pragma unroll
+            for (int k = 0; k < kPPT; ++k) {
+                if (hit >> k & 1u) {
+                    const unsigned i = c * (8u * G) + (unsigned)k * G + (unsigned)j;
+                    reinterpret_cast<unsigned *>(pts)[(size_t)i * 4 + 3] = cp.w[k] | 0x80000000u;
+                }
+            }
+            any = any || hit != 0;
+        }
+        if (strip && Row<G>::ballot(any) != 0ull) lpr_valid = false;  // the working set changed
+        if (strip && j == 0) st->need_strip = 0;
+    }
+    // ---- lowest-point representative (ref :84-103)
+    const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
+    if (__any(need_lpr)) {
+        const double l = srow_lpr<G>(pts, n, nchunk_max, need_lpr, use_cutoff, cutoff, P.num_lpr);
+        if (need_lpr) {
+            lpr = l;
+            if (j == 0) {
+                st->lpr = l;
+                st->lpr_valid = 1;
+            }
+        }
+    }
+    // ---- points phase
+    const double thr_seed = lpr + ((kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds);
+    const bool last = kind == ST_ITER && st->it == P.num_iter - 1;
+    Moments m;
+    m.clear();
+    unsigned run_g = 0, run_n = 0;
+    for (unsigned c = 0; c < nchunk_max; ++c) {
+        ChunkPts cp;
+        load_chunk<G>(cp, pts, n, c);
+        Moments mc;
+        const unsigned gmask = lane_stage_moments(cp.lp, cp.valid & ~cp.strip, kind, thr_seed, P.th_dist, pl, qscale, mc);
+        m.n += mc.n;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) m.s1[k] += mc.s1[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) m.s2[k] += mc.s2[k];
+        if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
+            const unsigned gm = last ? gmask : 0u;
+            const unsigned ngm = last ? (cp.valid & ~gmask) : 0u;
+            unsigned tg, tn;
+            unsigned bg = run_g + Row<G>::excl_scan((unsigned)__popc(gm), tg);
+            unsigned bn = run_n + Row<G>::excl_scan((unsigned)__popc(ngm), tn);
+            run_g += tg;
+            run_n += tn;
+#pragma unroll
+            for (int k = 0; k < kPPT; ++k) {
+                if (gm >> k & 1u)
+                    plist[bg++] = (int)cp.w[k];
+                else if (ngm >> k & 1u)
+                    plist[n - 1u - (bn++)] = (int)cp.w[k];
+            }
+        }
+    }
+    long long v[10];
+    v[0] = Row<G>::sum_i64(m.n);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[1 + k] = Row<G>::sum_i64(m.s1[k]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[4 + k] = Row<G>::sum_i64(m.s2[k]);
+    if (kind != ST_DONE && j < 10) {  // lane j of the row stores moment j
+        long long mine = v[0];
+#pragma unroll
+        for (int k = 1; k < 10; ++k) mine = j == k ? v[k] : mine;
+        st->mom[j] = mine;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ph_solve(PwppBatch Bt, int b_lo, int b_hi) {
+    const int f = blockIdx.x;
+    const PwppDevParams &P = Bt.P;
+    const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
+    const unsigned slot = cs[b_lo] + blockIdx.y * kBlock + threadIdx.x;
+    if (slot >= cs[b_hi]) return;
+    const int bin = Bt.cls_list[(size_t)f * P.num_bins + slot];
+    PwppFitState *st = Bt.fit + (size_t)f * P.num_bins + bin;
+    int kind = st->kind;
+    if (kind == ST_DONE) return;
+    int it = st->it;
+    const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
+    PlaneFit pl;
+    pl.nx = st->nx;
+    pl.ny = st->ny;
+    pl.nz = st->nz;
+    pl.d = st->d;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        pl.mean[k] = st->mean[k];
+        pl.sv[k] = st->sv[k];
+    }
+    const long long cnt = st->mom[0];
+    if (cnt > 0) {  // empty set: the previous plane stays (ref :49)
+        const long long s1[3] = {st->mom[1], st->mom[2], st->mom[3]};
+        __int128 s2[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s2[k] = (__int128)st->mom[4 + k];  // <= 65535 points: fits int64
+        plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);
+        st->nx = pl.nx;
+        st->ny = pl.ny;
+        st->nz = pl.nz;
+        st->d = pl.d;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            st->mean[k] = pl.mean[k];
+            st->sv[k] = pl.sv[k];
+        }
+    }
+    if (kind == ST_VPF) {
+        const bool vertical = (double)pl.nz < P.uprightness_thr;  // ref :489
+        if (vertical) st->need_strip = 1;
+        ++it;
+        if (!vertical || it >= P.num_iter) {  // ref :506 / loop end
+            kind = ST_SEED;
+            it = 0;
+        }
+    } else if (kind == ST_SEED) {
+        kind = (cnt == 0 && P.enable_RVPF != 0 && zone != 0) ? ST_LAZY : ST_ITER;
+    } else if (kind == ST_LAZY) {
+        kind = ST_ITER;
+    } else if (kind == ST_ITER) {
+        if (it == P.num_iter - 1) {
+            const unsigned n = Bt.bin_count[(size_t)f * (P.num_bins + 2) + bin];
+            write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt);
+            kind = ST_DONE;
+        }
+        ++it;
+    }
+    st->kind = kind;
+    st->it = it;
+}
+
 struct FitShared {
     long long part[kWaves][16];
     float normal[3];
@@ -1065,7 +1507,9 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
 }  // namespace
 
 // launches of K4; ev (optional) = 7 events recorded around up to six launches
-#define PWPP_DEFAULT_FIT_PLAN "S16:1023,S64:65535"
+#define PWPP_DEFAULT_FIT_PLAN "W16:1023,S64:65535"
+#define PWPP_LATENCY_FIT_PLAN "S64:511"
+#define PWPP_LATENCY_PLAN_MAX_FRAMES 4
 extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev) {
     const PwppBatch &B = *batch;
     const int F = B.num_frames, nb = B.P.num_bins;
@@ -1082,7 +1526,9 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     // whatever is larger than the last entry goes to the workgroup-per-patch kernel.
     // PWPP_FIT_PLAN overrides the default for tuning experiments.
     const char *plan = getenv("PWPP_FIT_PLAN");
-    if (!plan) plan = PWPP_DEFAULT_FIT_PLAN;
+    // throughput plan for batches; for a handful of frames the chain latency of a patch is what
+    // counts, so big patches get a whole workgroup (k_fit_stream) and the rest one wave each
+    if (!plan) plan = F <= PWPP_LATENCY_PLAN_MAX_FRAMES ? PWPP_LATENCY_FIT_PLAN : PWPP_DEFAULT_FIT_PLAN;
     int k_lo = 0, slot = 0;
     unsigned n_lo = 1;
     const char *p = plan;
@@ -1105,6 +1551,15 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
             else if (mode == 'S' && g == 16) hipLaunchKernelGGL(k_fit_srows<16>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
             else if (mode == 'S' && g == 32) hipLaunchKernelGGL(k_fit_srows<32>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
             else if (mode == 'S' && g == 64) hipLaunchKernelGGL(k_fit_srows<64>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+            else if (mode == 'W') hipLaunchKernelGGL(k_fit_w64, dim3(F, (patches + 255) / 256), dim3(kBlock), 0, stream, B, k_lo, k_hi);
+            else if (mode == 'P') {
+                const int rounds = 2 * B.P.num_iter + 2;
+                for (int r = 0; r < rounds; ++r) {
+                    if (g == 64) hipLaunchKernelGGL(k_ph_rows<64>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+                    else hipLaunchKernelGGL(k_ph_rows<16>, dim3(F, (patches * 16u + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, B, k_lo, k_hi);
+                    hipLaunchKernelGGL(k_ph_solve, dim3(F, (patches + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, B, k_lo, k_hi);
+                }
+            }
             else return (int)hipErrorInvalidValue;
             ++slot;
             k_lo = k_hi;

@@ -187,6 +187,18 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
             continue;
         }
         atomicAdd(&s_cnt[pwpp_size_bucket(n)], 1u);
+        {   // start of the fit chain (phase kernels): R-VPF for zone 0, else the R-GPF seeds
+            PwppFitState *st = Bt.fit + (size_t)f * B + b;
+            st->kind = (Bt.P.enable_RVPF != 0 && b < Bt.P.bin_base[1]) ? 0 /*ST_VPF*/ : 1 /*ST_SEED*/;
+            st->it = 0;
+            st->lpr_valid = 0;
+            st->need_strip = 0;
+            st->lpr = 0.0;
+            st->d = 0.0;
+            st->nx = st->ny = st->nz = 0.0f;
+            st->mean[0] = st->mean[1] = st->mean[2] = 0.0f;
+            st->sv[0] = st->sv[1] = st->sv[2] = 0.0f;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
