@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round profile (run on the GPU box through gpurun): kernel-trace stats of the default bench
+# command, then the HBM counters in their own passes (FETCH_SIZE and WRITE_SIZE cannot share a pass).
+R=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --skip-latency > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile-events --skip-latency > /dev/null 2> $OUT/fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile-events --skip-latency > /dev/null 2> $OUT/write.log
+python3 - "$OUT" <<'PY'
+import csv,sys,glob,collections,json
+out=sys.argv[1]
+def pmc(d,name):
+    f=glob.glob(out+'/'+d+'/**/*counter_collection.csv',recursive=True)[0]
+    acc=collections.defaultdict(float); cnt=collections.defaultdict(set); grid={}
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name']!=name: continue
+        k=r['Kernel_Name']
+        if int(r['Grid_Size_Y'] if 'Grid_Size_Y' in r else 0)==1 and 'czm_scan' not in k and 'gle' not in k: pass
+        acc[k]+=float(r['Counter_Value']); cnt[k].add(r['Dispatch_Id'])
+    return {k:acc[k]/len(cnt[k]) for k in acc}
+fe=pmc('fetch','FETCH_SIZE'); wr=pmc('write','WRITE_SIZE')
+res={}
+for k in sorted(set(fe)|set(wr)):
+    if 'k_' not in k: continue
+    short=k.split('::')[-1].split('(')[0]
+    # rocprofv3 reports KB; gfx950: FETCH_SIZE counts 64 B per 128 B request for wide streaming reads -> x2 (MI355X_MICROARCH.md, HBM)
+    res[short]={"fetch_kb_raw":fe.get(k,0.0),"write_kb_raw":wr.get(k,0.0),"hbm_bytes_corrected":(2*fe.get(k,0.0)+wr.get(k,0.0))*1024}
+json.dump(res,open(out+'/hbm_traffic_raw.json','w'),indent=1)
+print(json.dumps(res,indent=1))
+st=glob.glob(out+'/stats/**/*kernel_stats.csv',recursive=True)
+print(open(st[0]).read() if st else "no stats csv")
+PY
