@@ -209,6 +209,15 @@ int build_dev_params(const pwpp_params &p, PwppDevParams &d) {
     d.uprightness_thr = p.uprightness_thr;
     d.margin = p.adaptive_seed_selection_margin;
     d.fxp_shift = fxp_shift_for(p.max_range);
+    d.f_min_range = (float)p.min_range;
+    d.f_max_range = (float)p.max_range;
+    d.f_margin_r = (float)(p.max_range * 1.5e-6 + 5e-5);  // metres; ~5x the float error budget of the radius
+    d.f_margin_t = 8e-6f;                                  // radians; ~13x the error of the float angle
+    for (int k = 0; k < 4; ++k) {
+        d.f_zone[k] = (float)d.min_ranges[k];
+        d.f_inv_ring[k] = (float)(1.0 / d.ring_sizes[k]);
+        d.f_inv_sector[k] = (float)(1.0 / d.sector_sizes[k]);
+    }
     d.max_elev_storage = p.max_elevation_storage;
     d.max_flat_storage = p.max_flatness_storage;
     for (int k = 0; k < 4; ++k) {

@@ -207,14 +207,11 @@ __device__ void jacobi_svd3(const float a[9], float u[9], float sv[3]) {
     }
 }
 
-// Q(v)
+// Q(v) = clamp(rint(v * 2^s), +-(2^23 - 1)), Q(NaN) = 0.
+// Branch-free: v_rndne_f32, v_cvt_i32_f32 (saturating; NaN -> 0), v_med3_i32.
 __device__ __forceinline__ int fxp_quantise(float v, float scale) {
-    float t = v * scale;
-    if (!(t == t)) return 0;
-    t = rintf(t);
-    if (t > 8388607.0f) t = 8388607.0f;
-    if (t < -8388607.0f) t = -8388607.0f;
-    return (int)t;
+    const int q = __float2int_rn(v * scale);
+    return min(max(q, -8388607), 8388607);
 }
 
 // order-preserving map float -> uint32 (for the lowest-point selection)
@@ -257,6 +254,42 @@ struct Moments {  // per-lane partial sums of the quantised coordinates
 // then Eigen's JacobiSVD on the float covariance, normal = U.col(2) flipped to z >= 0 (:66-68),
 // d = -(normal . mean) as a float dot product widened to double (:74).
 // ------------------------------------------------------------------------------------------
+// Moments of at most 8 points per lane (one chunk), accumulated with double FMAs: the products
+// of 24-bit integers (< 2^46) and their sum over 8 points (< 2^49) are exact in double, and a
+// v_fma_f64 costs half of the quarter-rate 64-bit integer multiply-add.  Flushed into the int64
+// totals after every chunk, so the totals stay exact integers.
+struct ChunkMoments {
+    int n, s1[3];
+    double s2[6];
+    __device__ __forceinline__ void clear() {
+        n = 0;
+        s1[0] = s1[1] = s1[2] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s2[k] = 0.0;
+    }
+    __device__ __forceinline__ void add(float x, float y, float z, float scale) {
+        const int qx = fxp_quantise(x, scale), qy = fxp_quantise(y, scale), qz = fxp_quantise(z, scale);
+        const double dx = (double)qx, dy = (double)qy, dz = (double)qz;
+        n += 1;
+        s1[0] += qx;
+        s1[1] += qy;
+        s1[2] += qz;
+        s2[0] = __builtin_fma(dx, dx, s2[0]);
+        s2[1] = __builtin_fma(dx, dy, s2[1]);
+        s2[2] = __builtin_fma(dx, dz, s2[2]);
+        s2[3] = __builtin_fma(dy, dy, s2[3]);
+        s2[4] = __builtin_fma(dy, dz, s2[4]);
+        s2[5] = __builtin_fma(dz, dz, s2[5]);
+    }
+    __device__ __forceinline__ void flush_into(Moments &m) const {
+        m.n += n;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) m.s1[k] += s1[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) m.s2[k] += (long long)s2[k];
+    }
+};
+
 struct PlaneFit {
     float nx, ny, nz;
     float mean[3];

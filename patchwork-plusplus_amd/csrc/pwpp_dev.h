@@ -35,6 +35,9 @@ struct PwppDevParams {
     int32_t hist_cap;     // doubles per (state, which, ring) history slab
     int32_t near_bins;    // bins with concentric_idx < num_rings_of_interest
     double elevation_thr0[4], flatness_thr0[4];  // initial thresholds (fresh state)
+    // float mirrors for the fast path of k_czm_bin (never decide a point near a boundary)
+    float f_min_range, f_max_range, f_margin_r, f_margin_t;
+    float f_zone[4], f_inv_ring[4], f_inv_sector[4];
 };
 
 struct PwppFrameDesc {

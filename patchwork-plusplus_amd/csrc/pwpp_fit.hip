@@ -235,7 +235,8 @@ __device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &
 // per-lane part of one stage: which points enter the fit (and, for ST_ITER, which are ground)
 __device__ __forceinline__ unsigned lane_stage_moments(const LanePts &lp, unsigned act, int kind, double thr_seed,
                                                        double th_dist, const PlaneFit &pl, float qscale, Moments &m) {
-    m.clear();
+    ChunkMoments cm;
+    cm.clear();
     unsigned gmask = 0;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
@@ -248,12 +249,13 @@ __device__ __forceinline__ unsigned lane_stage_moments(const LanePts &lp, unsign
                 inc = (double)lp.z[k] < thr_seed;  // ref :108,145
             }
         }
-        if (inc) {
+        if (inc) {  // (a branch on purpose: seed passes include only ~10 % of the points)
             gmask |= 1u << k;
-            m.add(lp.x[k], lp.y[k], lp.z[k], qscale);
+            cm.add(lp.x[k], lp.y[k], lp.z[k], qscale);
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the 8 unrolled points sequential: register pressure
     }
+    m.clear();
+    cm.flush_into(m);
     return gmask;
 }
 
@@ -742,11 +744,12 @@ struct W64Patch {
     double d;
     double thr_seed;
 };
+template <int PW>
 struct W64Shared {
-    W64Patch p[64];
-    long long mom[64][10];
-    double lpr[64];
-    int stripped[64];
+    W64Patch p[PW];
+    long long mom[PW][10];
+    double lpr[PW];
+    int stripped[PW];
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -755,21 +758,26 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// G = lanes per patch in the points phases (16: four patches at a time; 64: one at a time, for
+// big bins), PW = patches owned by the wave = lanes active in the solve phase.
+template <int G, int PW>
 __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, int b_hi) {
-    __shared__ W64Shared sh_all[kWaves];
-    W64Shared &sh = sh_all[wave_id()];
-    constexpr int G = 16;
+    __shared__ W64Shared<PW> sh_all[kWaves];
+    W64Shared<PW> &sh = sh_all[wave_id()];
+    constexpr int R = 64 / G;      // patches per points-phase sub-batch
+    constexpr int NSB = PW / R;    // sub-batches
+    static_assert(PW % R == 0 && PW <= 64, "patches per wave");
     const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
     const PwppDevParams &P = Bt.P;
     const int NB = P.num_bins + 2;
     const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
     const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
     const unsigned npatch = cend - cbeg;
-    const unsigned nwaves = (npatch + 63u) / 64u;
+    const unsigned nwaves = (npatch + PW - 1u) / PW;
     const unsigned w = blockIdx.y * kWaves + (unsigned)wave_id();
     if (w >= nwaves) return;  // wave-uniform
     const int ln = lane_id();
-    const int j = ln & (G - 1), row = ln >> 4;
+    const int j = ln & (G - 1), row = ln / G;
     const PwppFrameDesc fd = Bt.frames[f];
     float4 *frame_pts = Bt.sorted + fd.base;
     int *frame_plist = Bt.plist + fd.base;
@@ -777,9 +785,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
     const double cutoff = P.margin * sensor_height;  // ref :90
     const float qscale = (float)(1 << P.fxp_shift);
 
-    // ---- owner lane: patch `ln` of this wave
+    // ---- owner lane: patch `ln` of this wave (lanes >= PW own nothing)
     const unsigned slot = cbeg + w + (unsigned)ln * nwaves;
-    const bool alive = slot < cend;
+    const bool alive = ln < PW && slot < cend;
     const int bin = alive ? (int)Bt.cls_list[(size_t)f * P.num_bins + slot] : 0;
     const unsigned n = alive ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
     const unsigned off = alive ? Bt.bin_off[(size_t)f * NB + bin] : 0u;
@@ -793,11 +801,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
     bool lpr_valid = false;
     int kind = !alive ? ST_DONE : ((P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED);
     int it = 0;
-    sh.p[ln].off = off;
-    sh.p[ln].n = n;
-    sh.p[ln].kind = ST_DONE;
-    sh.p[ln].flags = zone == 0 ? 2 : 0;
-    sh.stripped[ln] = 0;
+    if (ln < PW) {
+        sh.p[ln].off = off;
+        sh.p[ln].n = n;
+        sh.p[ln].kind = ST_DONE;
+        sh.p[ln].flags = zone == 0 ? 2 : 0;
+        sh.stripped[ln] = 0;
+    }
     wave_lds_sync();
 
     for (int guard = 0; guard < 4 * P.num_iter + 8; ++guard) {
@@ -807,9 +817,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
         const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
         const unsigned long long lpr_mask = __ballot(need_lpr);
         if (lpr_mask) {
-            for (int sb = 0; sb < 16; ++sb) {
-                if (((lpr_mask >> (4 * sb)) & 0xFull) == 0ull) continue;
-                const int q = 4 * sb + row;
+            for (int sb = 0; sb < NSB; ++sb) {
+                if (((lpr_mask >> (R * sb)) & ((1ull << R) - 1ull)) == 0ull) continue;
+                const int q = R * sb + row;
                 const bool need_row = (lpr_mask >> q) & 1ull;
                 const unsigned qn = sh.p[q].n, qoff = sh.p[q].off;
                 const bool use_cutoff = (sh.p[q].flags & 2) != 0;
@@ -825,7 +835,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
         }
 
         // ---- B. publish the stage of every patch
-        {
+        if (ln < PW) {
             const bool last = kind == ST_ITER && it == P.num_iter - 1;
             sh.p[ln].kind = kind;
             sh.p[ln].flags = (zone == 0 ? 2 : 0) | (last ? 1 : 0);
@@ -837,11 +847,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
         }
         wave_lds_sync();
 
-        // ---- C. points phase: 4 patches at a time, 16 lanes each
+        // ---- C. points phase: R patches at a time, G lanes each
         const unsigned long long act_mask = __ballot(kind != ST_DONE);
-        for (int sb = 0; sb < 16; ++sb) {
-            if (((act_mask >> (4 * sb)) & 0xFull) == 0ull) continue;
-            const int q = 4 * sb + row;
+        for (int sb = 0; sb < NSB; ++sb) {
+            if (((act_mask >> (R * sb)) & ((1ull << R) - 1ull)) == 0ull) continue;
+            const int q = R * sb + row;
             const W64Patch pp = sh.p[q];
             const bool on = pp.kind != ST_DONE;
             const bool last = on && (pp.flags & 1);
@@ -916,15 +926,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
         const bool vertical = kind == ST_VPF && (double)pl.nz < P.uprightness_thr;
         const unsigned long long v_mask = __ballot(vertical);
         if (v_mask) {
-            sh.p[ln].nx = pl.nx;
-            sh.p[ln].ny = pl.ny;
-            sh.p[ln].nz = pl.nz;
-            sh.p[ln].d = pl.d;
-            sh.stripped[ln] = 0;
+            if (ln < PW) {
+                sh.p[ln].nx = pl.nx;
+                sh.p[ln].ny = pl.ny;
+                sh.p[ln].nz = pl.nz;
+                sh.p[ln].d = pl.d;
+                sh.stripped[ln] = 0;
+            }
             wave_lds_sync();
-            for (int sb = 0; sb < 16; ++sb) {
-                if (((v_mask >> (4 * sb)) & 0xFull) == 0ull) continue;
-                const int q = 4 * sb + row;
+            for (int sb = 0; sb < NSB; ++sb) {
+                if (((v_mask >> (R * sb)) & ((1ull << R) - 1ull)) == 0ull) continue;
+                const int q = R * sb + row;
                 const bool vrow = (v_mask >> q) & 1ull;
                 const W64Patch pp = sh.p[q];
                 PlaneFit qpl;
@@ -1534,9 +1546,12 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     const char *p = plan;
     while (*p && slot < 5) {
         char mode = p[0];
-        int g = 0;
+        int g = 0, pw = 0;
         unsigned upper = 0;
-        if (sscanf(p + 1, "%d:%u", &g, &upper) != 2) break;
+        if (sscanf(p + 1, "%d.%d:%u", &g, &pw, &upper) != 3) {
+            pw = 0;
+            if (sscanf(p + 1, "%d:%u", &g, &upper) != 2) break;
+        }
         if (mode == 'L' && upper > 8u * (unsigned)g - 1u) upper = 8u * (unsigned)g - 1u;  // 8 points per lane in LDS
         if (upper > 65535u) upper = 65535u;  // int64 second moments hold up to 2^17 points; keep a margin
         const int k_hi = pwpp_size_bucket(upper + 1u);
@@ -1551,7 +1566,18 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
             else if (mode == 'S' && g == 16) hipLaunchKernelGGL(k_fit_srows<16>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
             else if (mode == 'S' && g == 32) hipLaunchKernelGGL(k_fit_srows<32>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
             else if (mode == 'S' && g == 64) hipLaunchKernelGGL(k_fit_srows<64>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-            else if (mode == 'W') hipLaunchKernelGGL(k_fit_w64, dim3(F, (patches + 255) / 256), dim3(kBlock), 0, stream, B, k_lo, k_hi);
+            else if (mode == 'W') {  // "W<lanes per patch>.<patches per wave>"
+                if (pw == 0) pw = 64;
+                const dim3 wgrid(F, (patches + (unsigned)pw * kWaves - 1) / ((unsigned)pw * kWaves));
+                if (g == 16 && pw == 64) hipLaunchKernelGGL((k_fit_w64<16, 64>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+                else if (g == 16 && pw == 32) hipLaunchKernelGGL((k_fit_w64<16, 32>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+                else if (g == 16 && pw == 16) hipLaunchKernelGGL((k_fit_w64<16, 16>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+                else if (g == 64 && pw == 32) hipLaunchKernelGGL((k_fit_w64<64, 32>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+                else if (g == 64 && pw == 16) hipLaunchKernelGGL((k_fit_w64<64, 16>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+                else if (g == 64 && pw == 8) hipLaunchKernelGGL((k_fit_w64<64, 8>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+                else if (g == 64 && pw == 4) hipLaunchKernelGGL((k_fit_w64<64, 4>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+                else return (int)hipErrorInvalidValue;
+            }
             else if (mode == 'P') {
                 const int rounds = 2 * B.P.num_iter + 2;
                 for (int r = 0; r < rounds; ++r) {

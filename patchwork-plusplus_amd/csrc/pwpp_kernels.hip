@@ -53,25 +53,34 @@ __device__ __forceinline__ double czm_atan2(double y, double x) {
     return atan2(y, x);
 }
 
+// Consecutive points of a scan mostly fall into the same bin, so a wave's LDS atomics pile up
+// on one address (PMC: 78 % of the LDS cycles of k_czm_bin were bank-conflict cycles).  Lanes
+// are grouped into runs of equal code; only the first lane of a run touches the LDS counter,
+// with the run length.  Returns the old counter value for the run (valid in every lane of the
+// run) and this lane's position inside the run.
+__device__ __forceinline__ unsigned wave_run_add(unsigned *counters, unsigned code, bool active, unsigned &pos_in_run) {
+    const int ln = lane_id();
+    const unsigned key = active ? code : (0x80000000u | (unsigned)ln);  // inactive lanes never join a run
+    const unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
+    const bool head = ln == 0 || key != prev;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long le = (ln == 63) ? ~0ull : ((1ull << (ln + 1)) - 1ull);
+    const int h = 63 - __clzll((long long)(heads & le));            // first lane of my run
+    const unsigned long long above = (h == 63) ? 0ull : (heads >> (h + 1));
+    const int len = above ? (__ffsll((long long)above)) : (64 - h);  // distance to the next head
+    unsigned old = 0;
+    if (head && active) old = atomicAdd(&counters[code], (unsigned)len);
+    old = (unsigned)__shfl((int)old, h, 64);
+    pos_in_run = (unsigned)(ln - h);
+    return old;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1  RNR + CZM code + histogram
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned czm_code(const PwppDevParams &P, float x, float y, float z, float inten,
-                                             bool has_intensity, double sensor_height) {
+// pc2czm, ref :593-615, exactly as the reference evaluates it: all double
+__device__ __forceinline__ unsigned bin_code_exact(const PwppDevParams &P, float x, float y) {
     const unsigned B = (unsigned)P.num_bins;
-    // Reflected Noise Removal, ref :385-396.  r is FLOAT there (:387), the rest double.
-    if (P.enable_RNR && has_intensity) {
-        const double zd = z;
-        // the three conjuncts of :391 are pure; evaluate the cheap two first
-        if (zd < -sensor_height - 0.8 && inten < P.RNR_intensity_thr) {
-            const float rf = sqrtf(x * x + y * y);
-            const double r = rf;
-            const double ver_angle_in_deg = atan2(zd, r) * 180 / 3.14159265358979323846;
-            if (ver_angle_in_deg < P.RNR_ver_angle_thr) return PWPP_CODE_RNR(B);
-        }
-    }
-    if (z == FLT_MIN) return PWPP_CODE_DROP;  // ref :591 (tombstone value in the input itself)
-    // pc2czm, ref :593-615, all double
     const double xd = x, yd = y;
     const double r = sqrt(xd * xd + yd * yd);
     if (!((r <= P.max_range) && (r > P.min_range))) return PWPP_CODE_OOR(B);
@@ -91,6 +100,87 @@ __device__ __forceinline__ unsigned czm_code(const PwppDevParams &P, float x, fl
     return (unsigned)(P.bin_base[k] + ring * P.sectors[k] + sector);
 }
 
+// The same bin in ~60 float instructions, for the points that are provably not near any
+// decision boundary of the double computation (>99.9 % of a scan).  The exact path costs ~220
+// mostly double instructions per point and made k_czm_bin VALU-bound at twice its HBM time.
+//   radius: v_sqrt_f32 of a float sum of squares, relative error < 3e-7 (1.6e-5 m at 80 m);
+//   angle : octant reduction + a degree-13 odd polynomial for atan on [0,1] (max error 3.3e-7 rad
+//           in float arithmetic, coefficients fitted for this file) + v_rcp_f32, < 1e-6 rad in all.
+// A point further than f_margin_r (>= 5x the radius error) from every range / zone / ring boundary
+// and further than f_margin_t (>= 8x the angle error) from every sector boundary lands in the same
+// bin in double.  Everything else -- and the exact directions of czm_atan2 -- returns false and
+// takes bin_code_exact.
+__device__ __forceinline__ bool bin_code_fast(const PwppDevParams &P, float x, float y, unsigned &code) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    if (!(ax > 0.0f) || !(ay > 0.0f) || ax == ay) return false;  // axes, diagonals, NaN
+    const float rf = __builtin_amdgcn_sqrtf(__builtin_fmaf(x, x, y * y));
+    const float lo = P.f_min_range, hi = P.f_max_range, mr = P.f_margin_r;
+    if (!(rf > lo) || !(rf <= hi)) {
+        code = PWPP_CODE_OOR((unsigned)P.num_bins);
+        return (rf <= lo - mr) || (rf >= hi + mr);  // NaN: not sure
+    }
+    const int k = (rf >= P.f_zone[1] ? 1 : 0) + (rf >= P.f_zone[2] ? 1 : 0) + (rf >= P.f_zone[3] ? 1 : 0);
+    const float zmin = k == 0 ? P.f_zone[0] : (k == 1 ? P.f_zone[1] : (k == 2 ? P.f_zone[2] : P.f_zone[3]));
+    const float inv_ring = k == 0 ? P.f_inv_ring[0] : (k == 1 ? P.f_inv_ring[1] : (k == 2 ? P.f_inv_ring[2] : P.f_inv_ring[3]));
+    const float inv_sec = k == 0 ? P.f_inv_sector[0] : (k == 1 ? P.f_inv_sector[1] : (k == 2 ? P.f_inv_sector[2] : P.f_inv_sector[3]));
+    const int nring = k == 0 ? P.rings[0] : (k == 1 ? P.rings[1] : (k == 2 ? P.rings[2] : P.rings[3]));
+    const int nsec = k == 0 ? P.sectors[0] : (k == 1 ? P.sectors[1] : (k == 2 ? P.sectors[2] : P.sectors[3]));
+    const int base = k == 0 ? P.bin_base[0] : (k == 1 ? P.bin_base[1] : (k == 2 ? P.bin_base[2] : P.bin_base[3]));
+    // ring (zone and range boundaries are ring boundaries too)
+    const float rq = (rf - zmin) * inv_ring;
+    const float rfl = floorf(rq);
+    const float rfrac = rq - rfl;
+    const float eps_r = mr * inv_ring;
+    bool unsure = rfrac < eps_r || rfrac > 1.0f - eps_r;
+    // angle in (0, 2 pi)
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const float t2 = t * t;
+    float pz = 0.006811772007495165f;
+    pz = __builtin_fmaf(pz, t2, -0.03360415995121002f);
+    pz = __builtin_fmaf(pz, t2, 0.07962360978126526f);
+    pz = __builtin_fmaf(pz, t2, -0.13233338296413422f);
+    pz = __builtin_fmaf(pz, t2, 0.19807815551757812f);
+    pz = __builtin_fmaf(pz, t2, -0.3331736922264099f);
+    pz = __builtin_fmaf(pz, t2, 0.9999961256980896f);
+    float a = pz * t;                                   // atan(mn / mx) in [0, pi/4]
+    a = ay > ax ? 1.57079632679489661923f - a : a;      // first quadrant
+    a = x < 0.0f ? 3.14159265358979323846f - a : a;     // upper half plane
+    a = y < 0.0f ? 6.28318530717958647692f - a : a;     // ref :570: negative atan2 + 2 pi
+    const float sq = a * inv_sec;
+    const float sfl = floorf(sq);
+    const float sfrac = sq - sfl;
+    const float eps_s = __builtin_fmaf(sq, 2.5e-7f, P.f_margin_t * inv_sec);
+    unsure = unsure || sfrac < eps_s || sfrac > 1.0f - eps_s;
+    const int ring = min((int)rfl, nring - 1);
+    const int sector = min((int)sfl, nsec - 1);
+    code = (unsigned)(base + ring * nsec + sector);
+    return !unsure;
+}
+
+__device__ __forceinline__ unsigned czm_code(const PwppDevParams &P, float x, float y, float z, float inten,
+                                             bool has_intensity, double sensor_height, float rnr_z_guard, bool exact_only,
+                                             bool never_exact = false) {
+    const unsigned B = (unsigned)P.num_bins;
+    // Reflected Noise Removal, ref :385-396.  r is FLOAT there (:387), the rest double.
+    // rnr_z_guard = float(-sensor_height - 0.8) + 1e-3: a float pre-test that can only say "no"
+    if (P.enable_RNR && has_intensity && z < rnr_z_guard) {
+        const double zd = z;
+        // the three conjuncts of :391 are pure; evaluate the cheap two first
+        if (zd < -sensor_height - 0.8 && inten < P.RNR_intensity_thr) {
+            const float rf = sqrtf(x * x + y * y);
+            const double r = rf;
+            const double ver_angle_in_deg = atan2(zd, r) * 180 / 3.14159265358979323846;
+            if (ver_angle_in_deg < P.RNR_ver_angle_thr) return PWPP_CODE_RNR(B);
+        }
+    }
+    if (z == FLT_MIN) return PWPP_CODE_DROP;  // ref :591 (tombstone value in the input itself)
+    unsigned code = 0;
+    if (!exact_only && bin_code_fast(P, x, y, code)) return code;
+    if (never_exact) return code;  // timing ablation only (PWPP_DEBUG_FLAGS & 128)
+    return bin_code_exact(P, x, y);
+}
+
 __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
     __shared__ unsigned s_hist[PWPP_MAX_BINS + 2];
     const int f = blockIdx.y;
@@ -102,21 +192,27 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
     for (int b = threadIdx.x; b < NB; b += kBlock) s_hist[b] = 0;
     __syncthreads();
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
+    const float rnr_z_guard = (float)(-sensor_height - 0.8) + 1e-3f;
     uint16_t *codes = Bt.codes + fd.base;
     unsigned dropped = 0;
+    unsigned pcode[kPtsPerBlock / kBlock];
 #pragma unroll
     for (int j = 0; j < kPtsPerBlock / kBlock; ++j) {
         const int i = first + j * kBlock + threadIdx.x;
+        pcode[j] = PWPP_CODE_DROP;
         if (i < fd.n) {
             float x, y, z, w;
             load_point(fd, i, x, y, z, w);
-            const unsigned code = czm_code(P, x, y, z, w, fd.cols >= 4, sensor_height);
+            const unsigned code = czm_code(P, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0, (Bt.debug & 128) != 0);
             codes[i] = (uint16_t)code;
-            if (code == PWPP_CODE_DROP)
-                ++dropped;
-            else
-                atomicAdd(&s_hist[code], 1u);
+            if (code == PWPP_CODE_DROP) ++dropped;
+            pcode[j] = code;
         }
+    }
+#pragma unroll
+    for (int j = 0; j < kPtsPerBlock / kBlock; ++j) {
+        unsigned pos;
+        (void)wave_run_add(s_hist, pcode[j], pcode[j] != PWPP_CODE_DROP, pos);
     }
     __syncthreads();
     unsigned *gcount = Bt.bin_count + (size_t)f * NB;
