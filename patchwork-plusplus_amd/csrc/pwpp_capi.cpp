@@ -18,7 +18,8 @@
 #include "../../include/pwpp.h"
 #include "pwpp_dev.h"
 
-extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev);
+extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
+                                    hipEvent_t aux_fork, hipEvent_t aux_join);
 extern "C" int pwpp_launch_gather_xyz(const PwppFrameDesc *fd, const int *idx, int count, float *out, hipStream_t stream);
 
 static_assert(sizeof(pwpp_state) == sizeof(PwppStateScalar), "pwpp_state must mirror PwppStateScalar");
@@ -97,6 +98,8 @@ struct pwpp_handle {
     PwppDevParams dp;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;  // second stream for the latency plan (few frames)
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     hipEvent_t ev_k[PWPP_NUM_KERNELS + 1] = {};
     bool profiling = false;
@@ -357,6 +360,9 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
     h->stream_hist_cap = storage + max_near_sectors + 1024;
     h->fresh_hist_cap = max_near_sectors + 2;
     hipError_t se = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipEventCreateWithFlags(&h->aux_fork, hipEventDisableTiming);
+    if (se == hipSuccess) se = hipEventCreateWithFlags(&h->aux_join, hipEventDisableTiming);
     if (se == hipSuccess) se = hipEventCreate(&h->ev_begin);
     if (se == hipSuccess) se = hipEventCreate(&h->ev_end);
     for (int k = 0; k <= PWPP_NUM_KERNELS && se == hipSuccess; ++k) se = hipEventCreate(&h->ev_k[k]);
@@ -405,6 +411,9 @@ int pwpp_destroy(pwpp_handle *h) {
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     for (int k = 0; k <= PWPP_NUM_KERNELS; ++k)
         if (h->ev_k[k]) (void)hipEventDestroy(h->ev_k[k]);
+    if (h->aux_fork) (void)hipEventDestroy(h->aux_fork);
+    if (h->aux_join) (void)hipEventDestroy(h->aux_join);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PWPP_OK;
@@ -538,7 +547,7 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     HIPCHK(hipMemsetAsync(bt.bin_cursor, 0, slab * sizeof(uint32_t), h->stream));
     HIPCHK(hipMemsetAsync(bt.results, 0, (size_t)frames * sizeof(PwppFrameResult), h->stream));
     if (bt.debug & 4) HIPCHK(hipMemsetAsync(bt.dbg, 0, 64 * sizeof(unsigned long long), h->stream));
-    const int lrc = pwpp_launch_pipeline(&bt, h->stream, h->profiling ? h->ev_k : nullptr);
+    const int lrc = pwpp_launch_pipeline(&bt, h->stream, h->profiling ? h->ev_k : nullptr, h->aux_stream, h->aux_fork, h->aux_join);
     if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
     HIPCHK(hipMemcpyAsync(h->h_results.p, h->d_results.p, (size_t)frames * sizeof(PwppFrameResult), hipMemcpyDeviceToHost, h->stream));

@@ -1522,7 +1522,11 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
 #define PWPP_DEFAULT_FIT_PLAN "W16:1023,S64:65535"
 #define PWPP_LATENCY_FIT_PLAN "S64:511"
 #define PWPP_LATENCY_PLAN_MAX_FRAMES 4
-extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev) {
+// `aux` (optional): a second stream + two events.  For a handful of frames the fit kernels are
+// latency-bound chains; the workgroup kernel for the big bins then runs CONCURRENTLY with the
+// row kernels (fork after K3, join before K5) instead of after them.
+extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
+                               hipEvent_t aux_fork, hipEvent_t aux_join) {
     const PwppBatch &B = *batch;
     const int F = B.num_frames, nb = B.P.num_bins;
     const unsigned min_pts = B.P.min_pts < 1 ? 1u : (unsigned)(B.P.min_pts > 0xffffffffull ? 0xffffffffu : B.P.min_pts);
@@ -1543,6 +1547,11 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     if (!plan) plan = F <= PWPP_LATENCY_PLAN_MAX_FRAMES ? PWPP_LATENCY_FIT_PLAN : PWPP_DEFAULT_FIT_PLAN;
     int k_lo = 0, slot = 0;
     unsigned n_lo = 1;
+    const bool fork = aux != nullptr && !ev && F <= PWPP_LATENCY_PLAN_MAX_FRAMES && !getenv("PWPP_FIT_PLAN");
+    if (fork) {  // the big-bin kernel only depends on K3; its bucket range starts where the latency plan ends
+        (void)hipEventRecord(aux_fork, stream);
+        (void)hipStreamWaitEvent(aux, aux_fork, 0);
+    }
     const char *p = plan;
     while (*p && slot < 5) {
         char mode = p[0];
@@ -1597,7 +1606,13 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     for (; slot < 5; ++slot)
         if (ev) (void)hipEventRecord(ev[slot], stream);
     if (ev) (void)hipEventRecord(ev[5], stream);
-    hipLaunchKernelGGL(k_fit_stream, dim3(F, cap(n_lo)), dim3(kBlock), 0, stream, B, k_lo);
+    if (fork) {
+        hipLaunchKernelGGL(k_fit_stream, dim3(F, cap(n_lo)), dim3(kBlock), 0, aux, B, k_lo);
+        (void)hipEventRecord(aux_join, aux);
+        (void)hipStreamWaitEvent(stream, aux_join, 0);
+    } else {
+        hipLaunchKernelGGL(k_fit_stream, dim3(F, cap(n_lo)), dim3(kBlock), 0, stream, B, k_lo);
+    }
     if (ev) (void)hipEventRecord(ev[6], stream);
     return (int)hipGetLastError();
 }

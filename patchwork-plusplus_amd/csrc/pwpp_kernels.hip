@@ -1038,12 +1038,23 @@ __global__ __launch_bounds__(kBlock) void k_emit(PwppBatch Bt) {
     const int *src = Bt.plist + fd.base + off;
     const unsigned ng = (unsigned)Bt.recs[(size_t)f * B + seg].n_ground;
     const unsigned db = Bt.dst_b[(size_t)f * NB + seg];
-    for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-        const int v = src[i];
-        if (i < ng)
-            out[da + i] = v;
-        else
-            out[db + (i - ng)] = v;
+    for (unsigned i0 = threadIdx.x; i0 < n; i0 += 4 * kBlock) {  // four loads in flight per thread
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = i0 + u * kBlock;
+            v[u] = i < n ? src[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = i0 + u * kBlock;
+            if (i < n) {
+                if (i < ng)
+                    out[da + i] = v[u];
+                else
+                    out[db + (i - ng)] = v[u];
+            }
+        }
     }
 }
 
@@ -1069,9 +1080,11 @@ extern "C" int pwpp_launch_gather_xyz(const PwppFrameDesc *fd, const int *idx, i
 // ------------------------------------------------------------------------------------------
 // host-side launcher used by pwpp_capi.cpp
 // ------------------------------------------------------------------------------------------
-extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev);
+extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
+                               hipEvent_t aux_fork, hipEvent_t aux_join);
 
-extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev /* PWPP_NUM_KERNELS + 1 events or null */) {
+extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev /* PWPP_NUM_KERNELS + 1 events or null */,
+                                    hipStream_t aux, hipEvent_t aux_fork, hipEvent_t aux_join) {
     const PwppBatch &B = *batch;
     const int F = B.num_frames;
     if (F <= 0) return 0;
@@ -1083,7 +1096,7 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
     if (ev) (void)hipEventRecord(ev[2], stream);
     if (gx > 0) hipLaunchKernelGGL(k_czm_scatter, dim3(gx, F), dim3(kBlock), 0, stream, B);
-    const int frc = pwpp_launch_fit(batch, stream, ev ? ev + 3 : nullptr);  // records ev[3..9]
+    const int frc = pwpp_launch_fit(batch, stream, ev ? ev + 3 : nullptr, aux, aux_fork, aux_join);  // records ev[3..9]
     if (frc) return frc;
     if (B.P.min_pts == 0)
         hipLaunchKernelGGL(k_gle_tgr_seq, dim3(F), dim3(64), 0, stream, B);  // empty bins inherit planes: serial
