@@ -170,6 +170,18 @@ int pwpp_get_history(pwpp_handle *h, int index, int which /*0 elevation, 1 flatn
 /* overwrite the scalars of a stream state (histories are cleared) */
 int pwpp_set_state(pwpp_handle *h, int stream, const pwpp_state *in);
 
+/* ---- ingest ----------------------------------------------------------------- */
+/* Page-locked host memory: frames handed over in such buffers are DMA'd straight to the device
+ * (pageable memory is staged by the runtime at a fraction of the PCIe rate), and result copies
+ * into them do not block. */
+int pwpp_host_alloc(void **out, uint64_t bytes);
+int pwpp_host_free(void *p);
+/* All index lists of the last batch in ONE device-to-host copy: out[frame_base[f] .. +n_ground)
+ * is frame f's ground list, followed by its non-ground list; frame_base (frames+1 entries) and
+ * counts (frames x 8 int32, see pwpp_device_view) are filled if not NULL.  `out` must hold the
+ * total number of points of the batch. */
+int pwpp_get_all_indices(pwpp_handle *h, int32_t *out, int64_t *frame_base, int32_t *counts);
+
 /* ---- device-side views and measurement --------------------------------------------------- */
 typedef struct pwpp_device_view {
     const int32_t *indices;      /* all frames: [frame_base[f] .. +n_ground) ground, then nonground */

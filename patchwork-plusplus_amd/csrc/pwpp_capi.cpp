@@ -735,6 +735,32 @@ int pwpp_get_device_view(pwpp_handle *h, pwpp_device_view *out) {
     return PWPP_OK;
 }
 
+int pwpp_host_alloc(void **out, uint64_t bytes) {
+    if (!out) return fail(PWPP_E_ARG, "null argument");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, (size_t)(bytes ? bytes : 1), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(PWPP_E_NOMEM, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return PWPP_OK;
+}
+int pwpp_host_free(void *p) {
+    if (p) HIPCHK(hipHostFree(p));
+    return PWPP_OK;
+}
+
+int pwpp_get_all_indices(pwpp_handle *h, int32_t *out, int64_t *frame_base, int32_t *counts) {
+    int rc = check_frame(h, 0);
+    if (rc) return rc;
+    if (!out) return fail(PWPP_E_ARG, "null output");
+    const int64_t total = h->h_base.p[h->frames];
+    if (total > 0) {
+        HIPCHK(hipMemcpyAsync(out, h->d_out.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if (frame_base) std::memcpy(frame_base, h->h_base.p, ((size_t)h->frames + 1) * sizeof(int64_t));
+    if (counts) std::memcpy(counts, h->h_results.p, (size_t)h->frames * sizeof(PwppFrameResult));
+    return PWPP_OK;
+}
+
 int pwpp_set_profiling(pwpp_handle *h, int enable) {
     if (!h) return fail(PWPP_E_ARG, "null handle");
     int rc = use_device(h);

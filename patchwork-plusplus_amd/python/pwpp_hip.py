@@ -90,12 +90,37 @@ def load():
         L.pwpp_set_state.argtypes = [vp, ci, ctypes.POINTER(State)]
         L.pwpp_get_device_view.argtypes = [vp, ctypes.POINTER(DeviceView)]
         L.pwpp_set_profiling.argtypes = [vp, ci]
+        L.pwpp_host_alloc.argtypes = [ctypes.POINTER(vp), ctypes.c_uint64]
+        L.pwpp_host_free.argtypes = [vp]
+        L.pwpp_get_all_indices.argtypes = [vp, vp, vp, vp]
         L.pwpp_get_kernel_profile.argtypes = [vp, vp, vp]
         L.pwpp_reset_kernel_profile.argtypes = [vp]
         L.pwpp_get_fxp_shift.argtypes = [vp]
         L.pwpp_kernel_name.argtypes = [ci]
         _lib = L
     return _lib
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """A page-locked numpy array (pwpp_host_alloc); keep it alive while the GPU may touch it."""
+    L = load()
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = ctypes.c_void_p()
+    if L.pwpp_host_alloc(ctypes.byref(p), n) < 0:
+        raise PwppError(L.pwpp_last_error().decode())
+    buf = (ctypes.c_char * max(n, 1)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    _pinned_keep[arr.ctypes.data] = (p, buf)
+    return arr
+
+
+def pinned_free(arr):
+    ent = _pinned_keep.pop(arr.ctypes.data, None)
+    if ent:
+        load().pwpp_host_free(ent[0])
+
+
+_pinned_keep = {}
 
 
 def default_params():
@@ -248,6 +273,20 @@ class Handle:
         v = DeviceView()
         self._check(self._L.pwpp_get_device_view(self._h, ctypes.byref(v)))
         return v
+
+    def all_indices(self, out=None):
+        """Every frame's ground + non-ground list in one device-to-host copy.
+
+        Returns (indices, frame_base, counts): frame f's ground list is
+        indices[frame_base[f] : frame_base[f] + counts[f, 0]], its non-ground list follows."""
+        v = self.device_view()
+        base = np.zeros(v.frames + 1, np.int64)
+        counts = np.zeros((v.frames, 8), np.int32)
+        total = int(np.ctypeslib.as_array(v.frame_base, shape=(v.frames + 1,))[-1])
+        if out is None:
+            out = np.empty(max(total, 1), np.int32)
+        self._check(self._L.pwpp_get_all_indices(self._h, _vp(out), _vp(base), _vp(counts)))
+        return out[:total], base, counts
 
     def all_counts(self):
         """(frames, 8) int32 array of per-frame counters of the last call."""

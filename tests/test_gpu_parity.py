@@ -310,3 +310,26 @@ def test_every_fit_kernel_variant(kitti, oracle, plan, monkeypatch):
     h.estimate_ground_batch([kitti[0], syn, kitti[5]], mode=pwpp_hip.MODE_FRESH)
     for k, pts in enumerate((kitti[0], syn, kitti[5])):
         assert_frame_equal(h, k, ol.Estimator(oracle, arith=ol.ARITH_FXP).run(pts), pts.shape[0])
+
+
+def test_ingest_pinned_buffers_and_bulk_index_copy(kitti):
+    """frames handed over in page-locked buffers, every index list of the batch
+    fetched with one device-to-host copy; same content as the per-frame getters."""
+    frames = []
+    for k in range(4):
+        a = pwpp_hip.pinned_empty(kitti[k].shape)
+        a[:] = kitti[k]
+        frames.append(a)
+    h = pwpp_hip.Handle()
+    h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+    out = pwpp_hip.pinned_empty((sum(f.shape[0] for f in frames),), np.int32)
+    idx, base, counts = h.all_indices(out)
+    assert base[-1] == sum(f.shape[0] for f in frames)
+    for k in range(4):
+        ng, nn = counts[k, 0], counts[k, 1]
+        assert (ng, nn) == h.counts(k)[:2]
+        assert np.array_equal(idx[base[k]:base[k] + ng], h.ground_indices(k))
+        assert np.array_equal(idx[base[k] + ng:base[k] + ng + nn], h.nonground_indices(k))
+    for a in frames:
+        pwpp_hip.pinned_free(a)
+    pwpp_hip.pinned_free(out)
