@@ -233,10 +233,12 @@ __device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &
 }
 
 // per-lane part of one stage: which points enter the fit (and, for ST_ITER, which are ground)
-__device__ __forceinline__ unsigned lane_stage_moments(const LanePts &lp, unsigned act, int kind, double thr_seed,
-                                                       double th_dist, const PlaneFit &pl, float qscale, Moments &m) {
-    ChunkMoments cm;
-    cm.clear();
+// Adds the points of one chunk that enter this stage's fit to `cm` and returns their mask.
+// `cm` holds exact integers in doubles (ChunkMoments); the caller flushes it into the int64
+// totals at least every kFlushChunks chunks (15 * 8 points * 2^46 < 2^53).
+constexpr unsigned kFlushChunks = 15;
+__device__ __forceinline__ unsigned lane_stage_accum(const LanePts &lp, unsigned act, int kind, double thr_seed,
+                                                     double th_dist, const PlaneFit &pl, float qscale, ChunkMoments &cm) {
     unsigned gmask = 0;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
@@ -254,6 +256,13 @@ __device__ __forceinline__ unsigned lane_stage_moments(const LanePts &lp, unsign
             cm.add(lp.x[k], lp.y[k], lp.z[k], qscale);
         }
     }
+    return gmask;
+}
+__device__ __forceinline__ unsigned lane_stage_moments(const LanePts &lp, unsigned act, int kind, double thr_seed,
+                                                       double th_dist, const PlaneFit &pl, float qscale, Moments &m) {
+    ChunkMoments cm;
+    cm.clear();
+    const unsigned gmask = lane_stage_accum(lp, act, kind, thr_seed, th_dist, pl, qscale, cm);
     m.clear();
     cm.flush_into(m);
     return gmask;
@@ -643,17 +652,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
         const bool last = kind == ST_ITER && it == P.num_iter - 1;
         Moments m;
         m.clear();
+        ChunkMoments cm;
+        cm.clear();
         unsigned run_g = 0, run_n = 0;
         for (unsigned c = 0; c < nchunk_max; ++c) {
             ChunkPts cp;
             load_chunk<G>(cp, pts, kind != ST_DONE ? n : 0u, c);
-            Moments mc;
-            const unsigned gmask = lane_stage_moments(cp.lp, cp.valid & ~cp.strip, kind, thr_seed, P.th_dist, pl, qscale, mc);
-            m.n += mc.n;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) m.s1[k] += mc.s1[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) m.s2[k] += mc.s2[k];
+            const unsigned gmask = lane_stage_accum(cp.lp, cp.valid & ~cp.strip, kind, thr_seed, P.th_dist, pl, qscale, cm);
+            if ((c + 1u) % kFlushChunks == 0u) {
+                cm.flush_into(m);
+                cm.clear();
+            }
             if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                 const unsigned gm = last ? gmask : 0u;
                 const unsigned ngm = last ? (cp.valid & ~gmask) : 0u;
@@ -671,6 +680,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
                 }
             }
         }
+        cm.flush_into(m);
         const long long cnt = Row<G>::sum_i64(m.n);
         {
             long long s1[3];
@@ -866,17 +876,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
             const unsigned nchunk_max = wave_max_u32((qn + 8u * G - 1u) / (8u * G));
             Moments m;
             m.clear();
+            ChunkMoments cm;
+            cm.clear();
             unsigned run_g = 0, run_n = 0;
             for (unsigned c = 0; c < nchunk_max; ++c) {
                 ChunkPts cp;
                 load_chunk<G>(cp, pts, qn, c);
-                Moments mc;
-                const unsigned gmask = lane_stage_moments(cp.lp, cp.valid & ~cp.strip, pp.kind, pp.thr_seed, P.th_dist, qpl, qscale, mc);
-                m.n += mc.n;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) m.s1[k] += mc.s1[k];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) m.s2[k] += mc.s2[k];
+                const unsigned gmask = lane_stage_accum(cp.lp, cp.valid & ~cp.strip, pp.kind, pp.thr_seed, P.th_dist, qpl, qscale, cm);
+                if ((c + 1u) % kFlushChunks == 0u) {
+                    cm.flush_into(m);
+                    cm.clear();
+                }
                 if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                     const unsigned gm = last ? gmask : 0u;
                     const unsigned ngm = last ? (cp.valid & ~gmask) : 0u;
@@ -894,6 +904,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
                     }
                 }
             }
+            cm.flush_into(m);
             long long v[10];
             v[0] = Row<G>::sum_i64(m.n);
 #pragma unroll
