@@ -106,3 +106,14 @@ def test_product_never_touches_the_oracle():
                 assert "oracle_lib" not in txt and "liboracle" not in txt and "pwo_" not in txt, fn
     out = subprocess.run(["ldd", pwpp_hip.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_cpp_demo_builds_against_the_class_mirror():
+    """The demo program compiles and links against the C++ header + libpwpp_hip.so (no GPU needed)."""
+    exe = os.path.join(ROOT, "patchwork-plusplus_amd", "examples", "demo_sequential")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "patchwork-plusplus_amd"), "examples/demo_sequential"], check=True,
+                   stdout=subprocess.DEVNULL)
+    assert os.path.exists(exe)
+    if not _has_gpu():
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 1 and "no CPU path" in r.stdout

@@ -333,3 +333,31 @@ def test_ingest_pinned_buffers_and_bulk_index_copy(kitti):
     for a in frames:
         pwpp_hip.pinned_free(a)
     pwpp_hip.pinned_free(out)
+
+
+def test_cpp_class_demo_program(kitti, golden, tmp_path):
+    """The C++ mirror of patchwork::PatchWorkpp through a compiled program that follows the
+    reference's demo_sequential.cpp: one object over frames 0..2, counts and sensor height as the
+    reference produces them (golden: reference build, sequence mode)."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "patchwork-plusplus_amd", "examples", "demo_sequential")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "patchwork-plusplus_amd"), "examples/demo_sequential"], check=True)
+    paths = []
+    for k in range(3):
+        p = tmp_path / ("%06d.bin" % k)
+        kitti[k].tofile(p)
+        paths.append(str(p))
+    out = subprocess.run([exe] + paths, capture_output=True, text=True, check=True).stdout
+    lines = [l for l in out.splitlines() if "Ground Points" in l]
+    assert len(lines) == 3, out
+    for k, line in enumerate(lines):
+        ng = int(re.search(r"Ground Points #: (\d+)", line).group(1))
+        nn = int(re.search(r"Nonground Points #: (\d+)", line).group(1))
+        npat = int(re.search(r"patches: (\d+)", line).group(1))
+        height = float(re.search(r"height: ([-0-9.]+)", line).group(1))
+        assert [ng, nn, npat] == list(golden["f32/seq/%d/counts" % k])
+        assert abs(height - golden["f32/seq/%d/state" % k][0]) < 1e-4
