@@ -239,18 +239,18 @@ __device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &
 constexpr unsigned kFlushChunks = 15;
 __device__ __forceinline__ unsigned lane_stage_accum(const LanePts &lp, unsigned act, int kind, double thr_seed,
                                                      double th_dist, const PlaneFit &pl, float qscale, ChunkMoments &cm) {
+    // One test for every stage: a seed pass (ref :108,145, "z < lpr + th_seeds") is the plane test
+    // of ref :525 with normal (0,0,1), d = 0: 0*x + 0*y + 1*z + 0.0 == z for the finite x, y that
+    // binning lets through, so the per-point code has no branch on the stage.
+    const bool iter = kind == ST_ITER;
+    const float tx = iter ? pl.nx : 0.0f, ty = iter ? pl.ny : 0.0f, tz = iter ? pl.nz : 1.0f;
+    const double td = iter ? pl.d : 0.0;
+    const double thr = iter ? th_dist : thr_seed;
+    if (kind == ST_DONE) act = 0u;
     unsigned gmask = 0;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
-        bool inc = false;
-        if (act >> k & 1u) {
-            if (kind == ST_ITER) {
-                const double dist = plane_dist(pl.nx, pl.ny, pl.nz, pl.d, lp.x[k], lp.y[k], lp.z[k]);
-                inc = dist < th_dist;  // ref :525,529 (one-sided)
-            } else if (kind != ST_DONE) {
-                inc = (double)lp.z[k] < thr_seed;  // ref :108,145
-            }
-        }
+        const bool inc = (act >> k & 1u) && plane_dist(tx, ty, tz, td, lp.x[k], lp.y[k], lp.z[k]) < thr;  // one-sided
         if (inc) {  // (a branch on purpose: seed passes include only ~10 % of the points)
             gmask |= 1u << k;
             cm.add(lp.x[k], lp.y[k], lp.z[k], qscale);
