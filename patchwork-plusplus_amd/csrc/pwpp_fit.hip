@@ -459,17 +459,19 @@ __device__ __forceinline__ void load_chunk(ChunkPts &cp, const float4 *pts, unsi
 
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~Row<64>::min_u32(~v); }
 
-// LPR (ref :84-103) of streamed rows.  Two light passes: (1) every lane's two smallest eligible
-// keys; the keff-th smallest of those 2G values, U, bounds the keff-th smallest key of the row;
-// (2) the keys below U are gathered (<= 8 per lane, practically 0-2) and summed in ascending
-// order, topped up with copies of U.  If a lane would have to hold more than 8, or fewer than
-// keff such candidates exist, an exact but slower extraction by distinct values runs.
+// LPR (ref :84-103) of streamed rows, normally in ONE pass over the points: every lane keeps its
+// four smallest eligible keys and the smallest key it had to drop.  The keff smallest of the
+// 4G kept keys are extracted in ascending order; they are the keff smallest of the row unless
+// some lane dropped a key below the largest one taken (T).  Only then (a lane held five or more
+// of the row's lowest points: ~1e-3 of the rows for G = 64, a few % for G = 16) a second pass
+// gathers every key below T (<= 8 per lane) and sums those, topped up with copies of T; if even
+// that overflows, an exact but slow extraction by distinct values runs.
 template <int G>
 __device__ double srow_lpr(const float4 *pts, unsigned n, unsigned nchunk_max, bool need, bool use_cutoff, double cutoff,
                            int num_lpr) {
     const int j = lane_id() & (G - 1);
     const unsigned INF = 0xFFFFFFFFu;
-    unsigned m1 = INF, m2 = INF;
+    unsigned k0 = INF, k1 = INF, k2 = INF, k3 = INF, dropped = INF;
     int elig = 0;
     for (unsigned c = 0; c < nchunk_max; ++c) {
         ChunkPts cp;
@@ -478,35 +480,39 @@ __device__ double srow_lpr(const float4 *pts, unsigned n, unsigned nchunk_max, b
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
             const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
-            const unsigned key = e ? z_key(cp.lp.z[k]) : INF;
-            const unsigned hi = key < m1 ? m1 : key;  // the larger of (key, m1)
-            m1 = key < m1 ? key : m1;
-            m2 = hi < m2 ? hi : m2;
+            unsigned x = e ? z_key(cp.lp.z[k]) : INF;
+            ce(k0, x);
+            ce(k1, x);
+            ce(k2, x);
+            ce(k3, x);
+            dropped = x < dropped ? x : dropped;
             elig += e ? 1 : 0;
         }
     }
     const int total = Row<G>::sum_i32(elig);
     const int keff = total < num_lpr ? total : num_lpr;  // row-uniform
-    const int ncand = Row<G>::sum_i32((m1 != INF ? 1 : 0) + (m2 != INF ? 1 : 0));
-    bool exact_path = need && keff > 0 && ncand < keff;
-    const bool fast = need && keff > 0 && !exact_path;
     double sum = 0.0;
-    unsigned U = 0;
-    if (__any(fast)) {
-        {   // U = keff-th smallest of the lane candidates
-            unsigned k0 = m1, k1 = m2;
-            for (int r = 0; r < num_lpr; ++r) {
-                const bool take = fast && r < keff;
-                if (!__any(take)) break;
-                const unsigned m = Row<G>::min_u32(k0);
-                if (take) U = m;
-                const int lowest = __ffsll((long long)Row<G>::ballot(take && k0 == m)) - 1;
-                if (take && j == lowest) {
-                    k0 = k1;
-                    k1 = INF;
-                }
-            }
+    unsigned T = 0;
+    for (int r = 0; r < num_lpr; ++r) {  // the keff smallest kept keys, ascending
+        const bool take = need && r < keff;
+        if (!__any(take)) break;
+        const unsigned m = Row<G>::min_u32(k0);
+        if (take) {
+            sum += (double)key_z(m);
+            T = m;
         }
+        const int lowest = __ffsll((long long)Row<G>::ballot(take && k0 == m)) - 1;
+        if (take && j == lowest) {
+            k0 = k1;
+            k1 = k2;
+            k2 = k3;
+            k3 = INF;
+        }
+    }
+    const bool fast = need && keff > 0 && Row<G>::min_u32(dropped) < T;  // second pass needed (row-uniform)
+    bool exact_path = false;
+    if (__any(fast)) {
+        const unsigned U = T;  // an upper bound of the keff-th smallest key of the row
         unsigned key[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) key[q] = INF;
@@ -519,7 +525,7 @@ __device__ double srow_lpr(const float4 *pts, unsigned n, unsigned nchunk_max, b
             for (int k = 0; k < kPPT; ++k) {
                 const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
                 const unsigned kk = z_key(cp.lp.z[k]);
-                const bool cand = e && kk < U;
+                const bool cand = fast && e && kk < U;
                 if (__any(cand)) {  // sorted insertion; whatever falls off the end must be "none"
                     unsigned x = cand ? kk : INF;
 #pragma unroll
@@ -529,19 +535,20 @@ __device__ double srow_lpr(const float4 *pts, unsigned n, unsigned nchunk_max, b
             }
         }
         const bool row_over = Row<G>::ballot(overflow) != 0ull;
-        exact_path = exact_path || (fast && row_over);
+        exact_path = fast && row_over;
         const bool ok = fast && !row_over;
         int nless = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) nless += key[q] != INF ? 1 : 0;
         const int c_less = Row<G>::sum_i32(nless);
         const int take_n = c_less < keff ? c_less : keff;
+        double sum2 = 0.0;
         for (int r = 0; r < num_lpr; ++r) {  // the take_n smallest gathered keys, ascending
             const bool take = ok && r < take_n;
             if (!__any(take)) break;
             const unsigned head = key[0];
             const unsigned m = Row<G>::min_u32(head);
-            if (take) sum += (double)key_z(m);
+            if (take) sum2 += (double)key_z(m);
             const int lowest = __ffsll((long long)Row<G>::ballot(take && head == m)) - 1;
             if (take && j == lowest) {
 #pragma unroll
@@ -552,8 +559,9 @@ __device__ double srow_lpr(const float4 *pts, unsigned n, unsigned nchunk_max, b
         const double zu = (double)key_z(U);
         for (int r = 0; r < num_lpr; ++r) {  // copies of U (at least keff keys are <= U)
             const bool take = ok && r >= take_n && r < keff;
-            if (take) sum += zu;
+            if (take) sum2 += zu;
         }
+        if (ok) sum = sum2;
     }
     if (__any(exact_path)) {
         // extraction by distinct values, ascending: one pass per distinct value among the keff smallest
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
         if (!__any(kind != ST_DONE)) break;
         const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
         if (__any(need_lpr)) {
-            const double l = srow_lpr<G>(pts, n, nchunk_max, need_lpr, use_cutoff, cutoff, P.num_lpr);
+            const double l = (Bt.debug & 512) ? -1.7 : srow_lpr<G>(pts, n, nchunk_max, need_lpr, use_cutoff, cutoff, P.num_lpr);
             if (need_lpr) {
                 lpr = l;
                 lpr_valid = true;
@@ -689,7 +697,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
             for (int k = 0; k < 3; ++k) s1[k] = Row<G>::sum_i64(m.s1[k]);
 #pragma unroll
             for (int k = 0; k < 6; ++k) s2[k] = (__int128)Row<G>::sum_i64(m.s2[k]);  // <= 65536 points: fits int64
-            if (kind != ST_DONE && cnt > 0) plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);  // empty: ref :49
+            if (Bt.debug & 256) {  // timing ablation only: no solve at all
+                pl.nx = 0.01f; pl.ny = 0.02f; pl.nz = 0.999f; pl.d = 1.7 + 1e-9 * (double)s1[0];
+            } else if (kind != ST_DONE && cnt > 0) plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);  // empty: ref :49
         }
         if (kind == ST_VPF) {
             const bool vertical = (double)pl.nz < P.uprightness_thr;  // ref :489
