@@ -121,7 +121,8 @@ struct pwpp_handle {
     PinnedBuf<int64_t> h_base;
     DevBuf<float> d_in;  // staging for host inputs
     DevBuf<uint16_t> d_codes;
-    DevBuf<float4> d_sorted;
+    DevBuf<PwppXyz> d_sorted_xyz;
+    DevBuf<int> d_sorted_idx;
     DevBuf<int32_t> d_plist;
     DevBuf<int32_t> d_out;
     DevBuf<uint32_t> d_bins;  // 5 slabs of frames*(B+2): count, off, cursor, dst_a, dst_b
@@ -389,7 +390,8 @@ int pwpp_destroy(pwpp_handle *h) {
     h->h_base.release();
     h->d_in.release();
     h->d_codes.release();
-    h->d_sorted.release();
+    h->d_sorted_xyz.release();
+    h->d_sorted_idx.release();
     h->d_plist.release();
     h->d_out.release();
     h->d_bins.release();
@@ -452,7 +454,8 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     if ((rc = h->h_frames.ensure((size_t)frames))) return rc;
     if ((rc = h->h_base.ensure((size_t)frames + 1))) return rc;
     if ((rc = h->d_codes.ensure(tp))) return rc;
-    if ((rc = h->d_sorted.ensure(tp))) return rc;
+    if ((rc = h->d_sorted_xyz.ensure(tp))) return rc;
+    if ((rc = h->d_sorted_idx.ensure(tp))) return rc;
     if ((rc = h->d_plist.ensure(tp))) return rc;
     if ((rc = h->d_out.ensure(tp))) return rc;
     if ((rc = h->d_bins.ensure((size_t)frames * NB * 5))) return rc;
@@ -531,7 +534,8 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     bt.dst_b = h->d_bins.p + 4 * slab;
     bt.cls_start = h->d_cls_start.p;
     bt.cls_list = h->d_cls_list.p;
-    bt.sorted = h->d_sorted.p;
+    bt.sorted_xyz = h->d_sorted_xyz.p;
+    bt.sorted_idx = h->d_sorted_idx.p;
     bt.plist = h->d_plist.p;
     bt.recs = h->d_recs.p;
     bt.fit = h->d_fit.p;

@@ -87,6 +87,12 @@ struct PwppFrameResult {
 };
 
 // everything a launch needs, by value in the kernarg segment
+// The fit passes re-read a patch 5-6 times and are bound by that traffic: the records they stream
+// hold the coordinates only (12 B), the cloud index lives in its own array.
+struct __attribute__((aligned(4))) PwppXyz {
+    float x, y, z;
+};
+
 struct PwppBatch {
     PwppDevParams P;
     const PwppFrameDesc *frames;
@@ -102,7 +108,8 @@ struct PwppBatch {
     uint32_t *bin_cursor;        // [frames][B+2]
     uint32_t *cls_start;         // [frames][PWPP_CLS_STRIDE] first entry of each size bucket in cls_list
     uint16_t *cls_list;          // [frames][B] patch bins sorted by size bucket
-    float4 *sorted;              // [total points] {x,y,z,bits(idx)} grouped by bin; bit 31 of w = stripped by R-VPF
+    PwppXyz *sorted_xyz;         // [total points] 12-byte {x,y,z} records grouped by bin; x = NaN: stripped by R-VPF
+    int *sorted_idx;             // [total points] cloud index of the record (read by the last fit pass and K6 only)
     int32_t *plist;              // [total points] per patch: ground candidates from the front, non-ground from the back
     PwppPatchRec *recs;          // [frames][B]
     PwppFitState *fit;           // [frames][B]

@@ -303,7 +303,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_rows(PwppBatch Bt, int b_lo, 
     const unsigned n = alive ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
     const PwppFrameDesc fd = Bt.frames[f];
     const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    const float4 *pts = Bt.sorted + fd.base + off;
+    const PwppXyz *pts = Bt.sorted_xyz + fd.base + off;
+    const int *pidx = Bt.sorted_idx + fd.base + off;
     int *plist = Bt.plist + fd.base + off;
     const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
@@ -319,7 +320,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_rows(PwppBatch Bt, int b_lo, 
     for (int k = 0; k < kPPT; ++k) {
         const unsigned i = (unsigned)j + (unsigned)k * G;
         if (i < n) {
-            s_pts[k][threadIdx.x] = pts[i];
+            const PwppXyz v = pts[i];
+            s_pts[k][threadIdx.x] = make_float4(v.x, v.y, v.z, __int_as_float(pidx[i]));
             valid |= 1u << k;
         }
     }
@@ -431,29 +433,52 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_rows(PwppBatch Bt, int b_lo, 
 // ------------------------------------------------------------------------------------------
 struct ChunkPts {
     LanePts lp;
-    unsigned w[kPPT];
     unsigned valid, strip;
 };
 
+// a patch in the bin-ordered buffers: 12-byte coordinate records + their cloud indices
+struct PatchRef {
+    PwppXyz *xyz;
+    const int *idx;
+};
+__device__ __forceinline__ PatchRef patch_ref(const PwppBatch &Bt, size_t first) {
+    PatchRef r;
+    r.xyz = Bt.sorted_xyz + first;
+    r.idx = Bt.sorted_idx + first;
+    return r;
+}
+// R-VPF removes a point from the patch's working set (ref :495-503) by overwriting its x with NaN:
+// a binned point never has a NaN x, and the coordinates of a removed point are not needed again.
+__device__ __forceinline__ void strip_point(const PatchRef &pr, unsigned i) { pr.xyz[i].x = __uint_as_float(0x7fc00000u); }
+
 template <int G>
-__device__ __forceinline__ void load_chunk(ChunkPts &cp, const float4 *pts, unsigned n, unsigned c) {
+__device__ __forceinline__ void load_chunk(ChunkPts &cp, const PatchRef &pr, unsigned n, unsigned c) {
     cp.valid = 0;
     cp.strip = 0;
     const unsigned j = (unsigned)lane_id() & (G - 1);
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
         const unsigned i = c * (8u * G) + (unsigned)k * G + j;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        PwppXyz v;
+        v.x = v.y = v.z = 0.0f;
         if (i < n) {
-            v = pts[i];
+            v = pr.xyz[i];
             cp.valid |= 1u << k;
         }
-        const unsigned wb = __float_as_uint(v.w);
         cp.lp.x[k] = v.x;
         cp.lp.y[k] = v.y;
         cp.lp.z[k] = v.z;
-        cp.w[k] = wb & 0x7fffffffu;
-        if (wb & 0x80000000u) cp.strip |= 1u << k;  // removed by R-VPF earlier (flag lives in the bin record)
+        if (v.x != v.x) cp.strip |= 1u << k;  // removed by R-VPF earlier
+    }
+}
+// the cloud indices of a chunk (only the pass that writes the split needs them)
+template <int G>
+__device__ __forceinline__ void load_chunk_idx(int w[kPPT], const PatchRef &pr, unsigned n, unsigned c) {
+    const unsigned j = (unsigned)lane_id() & (G - 1);
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        const unsigned i = c * (8u * G) + (unsigned)k * G + j;
+        w[k] = i < n ? pr.idx[i] : 0;
     }
 }
 
@@ -467,7 +492,7 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~Row<64>::
 // gathers every key below T (<= 8 per lane) and sums those, topped up with copies of T; if even
 // that overflows, an exact but slow extraction by distinct values runs.
 template <int G>
-__device__ double srow_lpr(const float4 *pts, unsigned n, unsigned nchunk_max, bool need, bool use_cutoff, double cutoff,
+__device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max, bool need, bool use_cutoff, double cutoff,
                            int num_lpr) {
     const int j = lane_id() & (G - 1);
     const unsigned INF = 0xFFFFFFFFu;
@@ -627,7 +652,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
     const unsigned n = alive ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
     const PwppFrameDesc fd = Bt.frames[f];
     const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    float4 *pts = Bt.sorted + fd.base + off;
+    const PatchRef pts = patch_ref(Bt, (size_t)fd.base + off);
     int *plist = Bt.plist + fd.base + off;
     const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
@@ -666,6 +691,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
         for (unsigned c = 0; c < nchunk_max; ++c) {
             ChunkPts cp;
             load_chunk<G>(cp, pts, kind != ST_DONE ? n : 0u, c);
+            int w[kPPT];
+            if (__any(last)) load_chunk_idx<G>(w, pts, last ? n : 0u, c);
             const unsigned gmask = lane_stage_accum(cp.lp, cp.valid & ~cp.strip, kind, thr_seed, P.th_dist, pl, qscale, cm);
             if ((c + 1u) % kFlushChunks == 0u) {
                 cm.flush_into(m);
@@ -682,9 +709,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k) {
                     if (gm >> k & 1u)
-                        plist[bg++] = (int)cp.w[k];
+                        plist[bg++] = w[k];
                     else if (ngm >> k & 1u)
-                        plist[n - 1u - (bn++)] = (int)cp.w[k];
+                        plist[n - 1u - (bn++)] = w[k];
                 }
             }
         }
@@ -713,7 +740,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
                     for (int k = 0; k < kPPT; ++k) {
                         if (hit >> k & 1u) {
                             const unsigned i = c * (8u * G) + (unsigned)k * G + (unsigned)j;
-                            reinterpret_cast<unsigned *>(pts)[(size_t)i * 4 + 3] = cp.w[k] | 0x80000000u;
+                            strip_point(pts, i);
                         }
                     }
                     any = any || hit != 0;
@@ -799,7 +826,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
     const int ln = lane_id();
     const int j = ln & (G - 1), row = ln / G;
     const PwppFrameDesc fd = Bt.frames[f];
-    float4 *frame_pts = Bt.sorted + fd.base;
     int *frame_plist = Bt.plist + fd.base;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;  // ref :90
@@ -844,7 +870,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
                 const unsigned qn = sh.p[q].n, qoff = sh.p[q].off;
                 const bool use_cutoff = (sh.p[q].flags & 2) != 0;
                 const unsigned nchunk_max = wave_max_u32(need_row ? (qn + 8u * G - 1u) / (8u * G) : 0u);
-                const double l = srow_lpr<G>(frame_pts + qoff, qn, nchunk_max, need_row, use_cutoff, cutoff, P.num_lpr);
+                const double l = srow_lpr<G>(patch_ref(Bt, (size_t)fd.base + qoff), qn, nchunk_max, need_row, use_cutoff, cutoff, P.num_lpr);
                 if (need_row && j == 0) sh.lpr[q] = l;
             }
             wave_lds_sync();
@@ -880,7 +906,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
             qpl.ny = pp.ny;
             qpl.nz = pp.nz;
             qpl.d = pp.d;
-            float4 *pts = frame_pts + pp.off;
+            const PatchRef pts = patch_ref(Bt, (size_t)fd.base + pp.off);
             int *plist = frame_plist + pp.off;
             const unsigned qn = on ? pp.n : 0u;
             const unsigned nchunk_max = wave_max_u32((qn + 8u * G - 1u) / (8u * G));
@@ -892,6 +918,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
             for (unsigned c = 0; c < nchunk_max; ++c) {
                 ChunkPts cp;
                 load_chunk<G>(cp, pts, qn, c);
+                int w[kPPT];
+                if (__any(last)) load_chunk_idx<G>(w, pts, last ? qn : 0u, c);
                 const unsigned gmask = lane_stage_accum(cp.lp, cp.valid & ~cp.strip, pp.kind, pp.thr_seed, P.th_dist, qpl, qscale, cm);
                 if ((c + 1u) % kFlushChunks == 0u) {
                     cm.flush_into(m);
@@ -908,9 +936,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k) {
                         if (gm >> k & 1u)
-                            plist[bg++] = (int)cp.w[k];
+                            plist[bg++] = w[k];
                         else if (ngm >> k & 1u)
-                            plist[qn - 1u - (bn++)] = (int)cp.w[k];
+                            plist[qn - 1u - (bn++)] = w[k];
                     }
                 }
             }
@@ -965,7 +993,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
                 qpl.ny = pp.ny;
                 qpl.nz = pp.nz;
                 qpl.d = pp.d;
-                float4 *pts = frame_pts + pp.off;
+                const PatchRef pts = patch_ref(Bt, (size_t)fd.base + pp.off);
                 const unsigned qn = vrow ? pp.n : 0u;
                 const unsigned nchunk_max = wave_max_u32((qn + 8u * G - 1u) / (8u * G));
                 bool any = false;
@@ -977,7 +1005,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
                     for (int k = 0; k < kPPT; ++k) {
                         if (hit >> k & 1u) {
                             const unsigned i = c * (8u * G) + (unsigned)k * G + (unsigned)j;
-                            reinterpret_cast<unsigned *>(pts)[(size_t)i * 4 + 3] = cp.w[k] | 0x80000000u;
+                            strip_point(pts, i);
                         }
                     }
                     any = any || hit != 0;
@@ -1038,7 +1066,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_ph_rows(PwppBatch Bt, int b_lo, i
     const unsigned n = kind != ST_DONE ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
     const PwppFrameDesc fd = Bt.frames[f];
     const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    float4 *pts = Bt.sorted + fd.base + off;
+    const PatchRef pts = patch_ref(Bt, (size_t)fd.base + off);
     int *plist = Bt.plist + fd.base + off;
     const bool use_cutoff = bin < P.bin_base[1];  // zone 0
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
@@ -1065,7 +1093,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_ph_rows(PwppBatch Bt, int b_lo, i
             for (int k = 0; k < kPPT; ++k) {
                 if (hit >> k & 1u) {
                     const unsigned i = c * (8u * G) + (unsigned)k * G + (unsigned)j;
-                    reinterpret_cast<unsigned *>(pts)[(size_t)i * 4 + 3] = cp.w[k] | 0x80000000u;
+                    strip_point(pts, i);
                 }
             }
             any = any || hit != 0;
@@ -1094,6 +1122,8 @@ __global__ __launch_bounds__(kBlock, 5) void k_ph_rows(PwppBatch Bt, int b_lo, i
     for (unsigned c = 0; c < nchunk_max; ++c) {
         ChunkPts cp;
         load_chunk<G>(cp, pts, n, c);
+        int w[kPPT];
+        if (__any(last)) load_chunk_idx<G>(w, pts, last ? n : 0u, c);
         Moments mc;
         const unsigned gmask = lane_stage_moments(cp.lp, cp.valid & ~cp.strip, kind, thr_seed, P.th_dist, pl, qscale, mc);
         m.n += mc.n;
@@ -1112,9 +1142,9 @@ __global__ __launch_bounds__(kBlock, 5) void k_ph_rows(PwppBatch Bt, int b_lo, i
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) {
                 if (gm >> k & 1u)
-                    plist[bg++] = (int)cp.w[k];
+                    plist[bg++] = w[k];
                 else if (ngm >> k & 1u)
-                    plist[n - 1u - (bn++)] = (int)cp.w[k];
+                    plist[n - 1u - (bn++)] = w[k];
             }
         }
     }
@@ -1280,13 +1310,19 @@ __device__ void reduce_and_fit(FitShared &sh, const Moments &m, bool wide, int s
 }
 
 __device__ __forceinline__ bool pt_stripped(const float4 &p) { return (__float_as_uint(p.w) & 0x80000000u) != 0; }
+// the workgroup kernel keeps the 16-byte view {x, y, z, bits(idx) | stripped << 31} of a record
+__device__ __forceinline__ float4 load_pt4(const PatchRef &pr, unsigned i) {
+    const PwppXyz v = pr.xyz[i];
+    const unsigned w = (unsigned)pr.idx[i] | (v.x != v.x ? 0x80000000u : 0u);
+    return make_float4(v.x, v.y, v.z, __uint_as_float(w));
+}
 
 // Lowest-point representative height, ref :84-103, without sorting the bin: the reference
 // needs (a) how many points lie below the adaptive cut-off (zone 0 only, :88-96), (b) the
 // num_lpr smallest z among the others, summed in ascending order in double (:99-102).
 // A 4-pass 8-bit radix select finds the k-th smallest key; the elements below its 24-bit
 // prefix are gathered in the last pass, the rest is implied by the last histogram.
-__device__ double block_lpr(FitShared &sh, const float4 *pts, unsigned n, bool use_cutoff, double cutoff, int num_lpr) {
+__device__ double block_lpr(FitShared &sh, const PatchRef &pts, unsigned n, bool use_cutoff, double cutoff, int num_lpr) {
     const int ln = lane_id(), wv = wave_id();
     unsigned prefix = 0;
     for (int pass = 0; pass < 4; ++pass) {
@@ -1295,7 +1331,7 @@ __device__ double block_lpr(FitShared &sh, const float4 *pts, unsigned n, bool u
         if (threadIdx.x == 0 && pass == 3) sh.sel_count = 0;
         __syncthreads();
         for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-            const float4 p = pts[i];
+            const float4 p = load_pt4(pts, i);
             if (pt_stripped(p)) continue;
             if (use_cutoff && (double)p.z < cutoff) continue;  // init_idx prefix, ref :88-96
             const unsigned key = z_key(p.z);
@@ -1408,7 +1444,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
     PwppPatchRec *rec = Bt.recs + (size_t)f * P.num_bins + bin;
     const PwppFrameDesc fd = Bt.frames[f];
     const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    float4 *pts = Bt.sorted + fd.base + off;
+    const PatchRef pts = patch_ref(Bt, (size_t)fd.base + off);
     int *plist = Bt.plist + fd.base + off;
     const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
@@ -1441,7 +1477,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
             const double thr = lpr + P.th_seeds_v;  // ref :108
             m.clear();
             for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-                const float4 p = pts[i];
+                const float4 p = load_pt4(pts, i);
                 if (!pt_stripped(p) && (double)p.z < thr) m.add(p.x, p.y, p.z, qscale);
             }
             reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);
@@ -1450,11 +1486,11 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
             if (zone == 0 && (double)nz < P.uprightness_thr) {  // ref :489
                 int any = 0;
                 for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-                    float4 p = pts[i];
+                    float4 p = load_pt4(pts, i);
                     if (pt_stripped(p)) continue;
                     const double dist = point_to_plane(nx, ny, nz, d, p);
                     if (fabs(dist) < P.th_dist_v) {  // ref :499 -> non_ground_dst
-                        reinterpret_cast<unsigned *>(pts)[(size_t)i * 4 + 3] = __float_as_uint(p.w) | 0x80000000u;
+                        strip_point(pts, i);
                         any = 1;
                     }
                 }
@@ -1471,7 +1507,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
         const double thr = lpr + P.th_seeds;  // ref :145
         m.clear();
         for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-            const float4 p = pts[i];
+            const float4 p = load_pt4(pts, i);
             if (!pt_stripped(p) && (double)p.z < thr) m.add(p.x, p.y, p.z, qscale);
         }
         reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);
@@ -1486,7 +1522,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
             const unsigned i = i0 + threadIdx.x;
             const bool in = i < n;
             float4 p = make_float4(0, 0, 0, 0);
-            if (in) p = pts[i];
+            if (in) p = load_pt4(pts, i);
             const bool stripped = in && pt_stripped(p);
             const bool active = in && !stripped;
             bool g = false;
@@ -1606,6 +1642,7 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
                 else if (g == 64 && pw == 16) hipLaunchKernelGGL((k_fit_w64<64, 16>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
                 else if (g == 64 && pw == 8) hipLaunchKernelGGL((k_fit_w64<64, 8>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
                 else if (g == 64 && pw == 4) hipLaunchKernelGGL((k_fit_w64<64, 4>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+                else if (g == 64 && pw == 2) hipLaunchKernelGGL((k_fit_w64<64, 2>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
                 else return (int)hipErrorInvalidValue;
             }
             else if (mode == 'P') {

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_scatter(PwppBatch Bt) {
     const uint16_t *codes = Bt.codes + fd.base;
     constexpr int kPer = kPtsPerBlock / kBlock;
     unsigned code[kPer], rank[kPer];
-    float4 pt[kPer];
+    PwppXyz pt[kPer];
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const int i = first + j * kBlock + threadIdx.x;
@@ -340,7 +340,9 @@ __global__ __launch_bounds__(kBlock) void k_czm_scatter(PwppBatch Bt) {
             code[j] = codes[i];
             float x, y, z, w;
             load_point(fd, i, x, y, z, w);
-            pt[j] = make_float4(x, y, z, __int_as_float(i));
+            pt[j].x = x;
+            pt[j].y = y;
+            pt[j].z = z;
             if (code[j] != PWPP_CODE_DROP) rank[j] = atomicAdd(&s_cnt[code[j]], 1u);
         }
     }
@@ -352,10 +354,15 @@ __global__ __launch_bounds__(kBlock) void k_czm_scatter(PwppBatch Bt) {
     }
     __syncthreads();
     const unsigned *off = Bt.bin_off + (size_t)f * NB;
-    float4 *sorted = Bt.sorted + fd.base;
+    PwppXyz *sorted_xyz = Bt.sorted_xyz + fd.base;
+    int *sorted_idx = Bt.sorted_idx + fd.base;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
-        if (code[j] != PWPP_CODE_DROP) sorted[off[code[j]] + s_base[code[j]] + rank[j]] = pt[j];
+        if (code[j] != PWPP_CODE_DROP) {
+            const unsigned slot = off[code[j]] + s_base[code[j]] + rank[j];
+            sorted_xyz[slot] = pt[j];
+            sorted_idx[slot] = first + j * kBlock + (int)threadIdx.x;
+        }
     }
 }
 
@@ -1031,8 +1038,8 @@ __global__ __launch_bounds__(kBlock) void k_emit(PwppBatch Bt) {
     const unsigned da = Bt.dst_a[(size_t)f * NB + seg];
     const bool whole = seg >= B || (uint64_t)n < P.min_pts;
     if (whole) {
-        const float4 *src = Bt.sorted + fd.base + off;
-        for (unsigned i = threadIdx.x; i < n; i += kBlock) out[da + i] = (int)(__float_as_uint(src[i].w) & 0x7fffffffu);
+        const int *src = Bt.sorted_idx + fd.base + off;
+        for (unsigned i = threadIdx.x; i < n; i += kBlock) out[da + i] = src[i];
         return;
     }
     const int *src = Bt.plist + fd.base + off;
