@@ -88,7 +88,7 @@ struct PinnedBuf {
     }
 };
 
-const char *kKernelNames[PWPP_NUM_KERNELS] = {"k_czm_bin", "k_czm_scan", "k_czm_scatter", "k_fit_w64", "k_fit_srows<64>",
+const char *kKernelNames[PWPP_NUM_KERNELS] = {"k_czm_bin", "k_czm_scan", "k_czm_scatter", "k_fit_w64<16,64>", "k_fit_w64<64,2>",
                                               "k_fit[2]", "k_fit[3]", "k_fit[4]", "k_fit_stream", "k_gle_tgr", "k_emit"};  // fit slots: default PWPP_FIT_PLAN
 
 }  // namespace
@@ -454,7 +454,7 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     if ((rc = h->h_frames.ensure((size_t)frames))) return rc;
     if ((rc = h->h_base.ensure((size_t)frames + 1))) return rc;
     if ((rc = h->d_codes.ensure(tp))) return rc;
-    if ((rc = h->d_sorted_xyz.ensure(tp))) return rc;
+    if ((rc = h->d_sorted_xyz.ensure(tp + 16))) return rc;  // slack: load_chunk reads record 0 of a patch beyond its end
     if ((rc = h->d_sorted_idx.ensure(tp))) return rc;
     if ((rc = h->d_plist.ensure(tp))) return rc;
     if ((rc = h->d_out.ensure(tp))) return rc;

@@ -433,8 +433,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_rows(PwppBatch Bt, int b_lo, 
 // ------------------------------------------------------------------------------------------
 struct ChunkPts {
     LanePts lp;
-    unsigned valid, strip;
+    unsigned valid;
 };
+// the points of a chunk that are still in the patch's working set (not removed by R-VPF); evaluated
+// where the chunk is consumed, so that a chunk loaded ahead does not have to land early
+__device__ __forceinline__ unsigned chunk_act(const ChunkPts &cp) {
+    unsigned strip = 0;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k)
+        if (cp.lp.x[k] != cp.lp.x[k]) strip |= 1u << k;
+    return cp.valid & ~strip;
+}
 
 // a patch in the bin-ordered buffers: 12-byte coordinate records + their cloud indices
 struct PatchRef {
@@ -454,21 +463,18 @@ __device__ __forceinline__ void strip_point(const PatchRef &pr, unsigned i) { pr
 template <int G>
 __device__ __forceinline__ void load_chunk(ChunkPts &cp, const PatchRef &pr, unsigned n, unsigned c) {
     cp.valid = 0;
-    cp.strip = 0;
     const unsigned j = (unsigned)lane_id() & (G - 1);
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
+        // unconditional loads (record 0 of the patch stands in beyond the end; the buffers carry a
+        // few records of slack): the compiler can then keep a whole chunk in flight behind the
+        // arithmetic of the previous one and wait with a counted s_waitcnt
         const unsigned i = c * (8u * G) + (unsigned)k * G + j;
-        PwppXyz v;
-        v.x = v.y = v.z = 0.0f;
-        if (i < n) {
-            v = pr.xyz[i];
-            cp.valid |= 1u << k;
-        }
+        const PwppXyz v = pr.xyz[i < n ? i : 0u];
+        if (i < n) cp.valid |= 1u << k;
         cp.lp.x[k] = v.x;
         cp.lp.y[k] = v.y;
         cp.lp.z[k] = v.z;
-        if (v.x != v.x) cp.strip |= 1u << k;  // removed by R-VPF earlier
     }
 }
 // the cloud indices of a chunk (only the pass that writes the split needs them)
@@ -501,7 +507,7 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
     for (unsigned c = 0; c < nchunk_max; ++c) {
         ChunkPts cp;
         load_chunk<G>(cp, pts, need ? n : 0u, c);
-        const unsigned act = cp.valid & ~cp.strip;
+        const unsigned act = chunk_act(cp);
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
             const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
@@ -545,7 +551,7 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
         for (unsigned c = 0; c < nchunk_max; ++c) {
             ChunkPts cp;
             load_chunk<G>(cp, pts, fast ? n : 0u, c);
-            const unsigned act = cp.valid & ~cp.strip;
+            const unsigned act = chunk_act(cp);
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) {
                 const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
@@ -601,7 +607,7 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
             for (unsigned c = 0; c < nchunk_max; ++c) {
                 ChunkPts cp;
                 load_chunk<G>(cp, pts, remaining > 0 ? n : 0u, c);
-                const unsigned act = cp.valid & ~cp.strip;
+                const unsigned act = chunk_act(cp);
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k) {
                     const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
@@ -637,7 +643,7 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
 }
 
 template <int G>
-__global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo, int b_hi) {
+__global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo, int b_hi) {
     const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
     const PwppDevParams &P = Bt.P;
     const int NB = P.num_bins + 2;
@@ -645,8 +651,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
     const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
     const unsigned tid = blockIdx.y * kBlock + threadIdx.x;
     if (cbeg + (tid & ~63u) / G >= cend) return;  // this wave has no patch
-    const unsigned slot = cbeg + tid / G;
-    const bool alive = slot < cend;  // row-uniform
+    const bool alive = cbeg + tid / G < cend;  // row-uniform
+    // largest patches first: the list is sorted by size, a wave's run time grows with its patch,
+    // and the last waves to start should be the short ones
+    const unsigned slot = cend - 1u - tid / G;
     const int j = lane_id() & (G - 1);
     const int bin = alive ? (int)Bt.cls_list[(size_t)f * P.num_bins + slot] : 0;
     const unsigned n = alive ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
@@ -688,12 +696,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
         ChunkMoments cm;
         cm.clear();
         unsigned run_g = 0, run_n = 0;
+        ChunkPts cp;
+        load_chunk<G>(cp, pts, kind != ST_DONE ? n : 0u, 0u);
         for (unsigned c = 0; c < nchunk_max; ++c) {
-            ChunkPts cp;
-            load_chunk<G>(cp, pts, kind != ST_DONE ? n : 0u, c);
+            ChunkPts nx;  // the next chunk is in flight while this one is accumulated
+            load_chunk<G>(nx, pts, kind != ST_DONE ? n : 0u, c + 1u);
             int w[kPPT];
             if (__any(last)) load_chunk_idx<G>(w, pts, last ? n : 0u, c);
-            const unsigned gmask = lane_stage_accum(cp.lp, cp.valid & ~cp.strip, kind, thr_seed, P.th_dist, pl, qscale, cm);
+            const unsigned gmask = lane_stage_accum(cp.lp, chunk_act(cp), kind, thr_seed, P.th_dist, pl, qscale, cm);
             if ((c + 1u) % kFlushChunks == 0u) {
                 cm.flush_into(m);
                 cm.clear();
@@ -714,6 +724,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
                         plist[n - 1u - (bn++)] = w[k];
                 }
             }
+            cp = nx;
         }
         cm.flush_into(m);
         const long long cnt = Row<G>::sum_i64(m.n);
@@ -735,7 +746,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
                 for (unsigned c = 0; c < nchunk_max; ++c) {
                     ChunkPts cp;
                     load_chunk<G>(cp, pts, vertical ? n : 0u, c);
-                    const unsigned hit = lane_strip(cp.lp, cp.valid & ~cp.strip, vertical, pl, P.th_dist_v);
+                    const unsigned hit = lane_strip(cp.lp, chunk_act(cp), vertical, pl, P.th_dist_v);
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k) {
                         if (hit >> k & 1u) {
@@ -786,15 +797,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_srows(PwppBatch Bt, int b_lo,
 struct W64Patch {
     unsigned off, n;
     int kind;        // stage of the coming points phase; ST_DONE = nothing to do
-    int flags;       // bit0: last R-GPF round (write the split), bit1: zone-0 cut-off applies
+    int flags;       // bit0: last R-GPF round (write the split), bit1: zone-0 cut-off applies, bit2: dual seed pass
     float nx, ny, nz, pad_;
     double d;
     double thr_seed;
+    double thr_band;  // dual seed pass: upper end of the band [thr_seed, thr_band)
 };
-template <int PW>
+template <int PW, bool DUAL>
 struct W64Shared {
     W64Patch p[PW];
     long long mom[PW][10];
+    long long mom2[DUAL ? PW : 1][10];  // dual seed pass: moments of the band; then the stashed seed totals of the R-GPF stage
     double lpr[PW];
     int stripped[PW];
 };
@@ -808,9 +821,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 // G = lanes per patch in the points phases (16: four patches at a time; 64: one at a time, for
 // big bins), PW = patches owned by the wave = lanes active in the solve phase.
 template <int G, int PW>
-__global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, int b_hi) {
-    __shared__ W64Shared<PW> sh_all[kWaves];
-    W64Shared<PW> &sh = sh_all[wave_id()];
+__global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, int b_lo, int b_hi) {
+    __shared__ W64Shared<PW, G == 64> sh_all[kWaves];
+    W64Shared<PW, G == 64> &sh = sh_all[wave_id()];
     constexpr int R = 64 / G;      // patches per points-phase sub-batch
     constexpr int NSB = PW / R;    // sub-batches
     static_assert(PW % R == 0 && PW <= 64, "patches per wave");
@@ -847,6 +860,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
     bool lpr_valid = false;
     int kind = !alive ? ST_DONE : ((P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED);
     int it = 0;
+    // Dual seed pass (big bins, G == 64): the R-VPF round and the R-GPF seed stage of a zone-0 patch
+    // select seeds from the same working set with the same lowest-point representative and two
+    // thresholds (th_seeds_v / th_seeds, ref :480,:511).  The R-VPF pass therefore accumulates the
+    // moments below the smaller threshold and those of the band up to the larger one; the sums are
+    // exact integers, so one set is A and the other A + B.  If R-VPF removes nothing, the R-GPF seed
+    // stage takes its totals from the stash instead of streaming the patch again.
+    constexpr bool DUAL = G == 64;
+    const bool v_is_hi = P.th_seeds_v >= P.th_seeds;
+    bool stash_valid = false, dual_now = false;
     if (ln < PW) {
         sh.p[ln].off = off;
         sh.p[ln].n = n;
@@ -881,20 +903,25 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
         }
 
         // ---- B. publish the stage of every patch
+        dual_now = DUAL && kind == ST_VPF;                      // this round's pass also fills the stash
+        const bool from_stash = DUAL && kind == ST_SEED && stash_valid;  // no pass: totals come from the stash
+        const int pub_kind = from_stash ? ST_DONE : kind;
         if (ln < PW) {
             const bool last = kind == ST_ITER && it == P.num_iter - 1;
-            sh.p[ln].kind = kind;
-            sh.p[ln].flags = (zone == 0 ? 2 : 0) | (last ? 1 : 0);
+            sh.p[ln].kind = pub_kind;
+            sh.p[ln].flags = (zone == 0 ? 2 : 0) | (last ? 1 : 0) | (dual_now ? 4 : 0);
             sh.p[ln].nx = pl.nx;
             sh.p[ln].ny = pl.ny;
             sh.p[ln].nz = pl.nz;
             sh.p[ln].d = pl.d;
-            sh.p[ln].thr_seed = lpr + ((kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds);
+            const double th = (kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds;
+            sh.p[ln].thr_seed = lpr + (dual_now ? (v_is_hi ? P.th_seeds : P.th_seeds_v) : th);
+            sh.p[ln].thr_band = lpr + (v_is_hi ? P.th_seeds_v : P.th_seeds);
         }
         wave_lds_sync();
 
         // ---- C. points phase: R patches at a time, G lanes each
-        const unsigned long long act_mask = __ballot(kind != ST_DONE);
+        const unsigned long long act_mask = __ballot(pub_kind != ST_DONE);
         for (int sb = 0; sb < NSB; ++sb) {
             if (((act_mask >> (R * sb)) & ((1ull << R) - 1ull)) == 0ull) continue;
             const int q = R * sb + row;
@@ -910,8 +937,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
             int *plist = frame_plist + pp.off;
             const unsigned qn = on ? pp.n : 0u;
             const unsigned nchunk_max = wave_max_u32((qn + 8u * G - 1u) / (8u * G));
-            Moments m;
+            const bool dual = DUAL && on && (pp.flags & 4);
+            Moments m, m2;
             m.clear();
+            m2.clear();
             ChunkMoments cm;
             cm.clear();
             unsigned run_g = 0, run_n = 0;
@@ -920,10 +949,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
                 load_chunk<G>(cp, pts, qn, c);
                 int w[kPPT];
                 if (__any(last)) load_chunk_idx<G>(w, pts, last ? qn : 0u, c);
-                const unsigned gmask = lane_stage_accum(cp.lp, cp.valid & ~cp.strip, pp.kind, pp.thr_seed, P.th_dist, qpl, qscale, cm);
+                const unsigned act = chunk_act(cp);
+                const unsigned gmask = lane_stage_accum(cp.lp, act, pp.kind, pp.thr_seed, P.th_dist, qpl, qscale, cm);
                 if ((c + 1u) % kFlushChunks == 0u) {
                     cm.flush_into(m);
                     cm.clear();
+                }
+                if (DUAL && __any(dual)) {  // the band [thr_seed, thr_band) of a dual seed pass
+                    const unsigned rest = dual ? (act & ~gmask) : 0u;
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k)
+                        if ((rest >> k & 1u) && (double)cp.lp.z[k] < pp.thr_band) m2.add(cp.lp.x[k], cp.lp.y[k], cp.lp.z[k], qscale);
                 }
                 if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                     const unsigned gm = last ? gmask : 0u;
@@ -955,18 +991,43 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
                 for (int k = 1; k < 10; ++k) mine = j == k ? v[k] : mine;
                 sh.mom[q][j] = mine;
             }
+            if (DUAL && __any(dual)) {
+                v[0] = Row<G>::sum_i64(m2.n);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[1 + k] = Row<G>::sum_i64(m2.s1[k]);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) v[4 + k] = Row<G>::sum_i64(m2.s2[k]);
+                if (dual && j < 10) {
+                    long long mine = v[0];
+#pragma unroll
+                    for (int k = 1; k < 10; ++k) mine = j == k ? v[k] : mine;
+                    sh.mom2[DUAL ? q : 0][j] = mine;
+                }
+            }
         }
         wave_lds_sync();
 
         // ---- D. solve phase: lane p fits patch p (ref :47-75)
         long long cnt = 0;
         if (kind != ST_DONE) {
-            cnt = sh.mom[ln][0];
+            long long tot[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) tot[k] = from_stash ? sh.mom2[DUAL ? ln : 0][k] : sh.mom[ln][k];
+            if (dual_now) {  // mom = below the smaller threshold (A), mom2 = the band (B)
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    const long long a = tot[k], ab = a + sh.mom2[DUAL ? ln : 0][k];
+                    tot[k] = v_is_hi ? ab : a;            // this round: the R-VPF seeds (th_seeds_v)
+                    sh.mom2[DUAL ? ln : 0][k] = v_is_hi ? a : ab;    // stash: the R-GPF seeds (th_seeds)
+                }
+                stash_valid = true;
+            }
+            cnt = tot[0];
             if (cnt > 0) {  // empty set: the previous plane stays (ref :49)
-                const long long s1[3] = {sh.mom[ln][1], sh.mom[ln][2], sh.mom[ln][3]};
+                const long long s1[3] = {tot[1], tot[2], tot[3]};
                 __int128 s2[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) s2[k] = (__int128)sh.mom[ln][4 + k];  // <= 65535 points: fits int64
+                for (int k = 0; k < 6; ++k) s2[k] = (__int128)tot[4 + k];  // <= 65535 points: fits int64
                 plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);
             }
         }
@@ -1000,7 +1061,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
                 for (unsigned c = 0; c < nchunk_max; ++c) {
                     ChunkPts cp;
                     load_chunk<G>(cp, pts, qn, c);
-                    const unsigned hit = lane_strip(cp.lp, cp.valid & ~cp.strip, vrow, qpl, P.th_dist_v);
+                    const unsigned hit = lane_strip(cp.lp, chunk_act(cp), vrow, qpl, P.th_dist_v);
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k) {
                         if (hit >> k & 1u) {
@@ -1013,7 +1074,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_w64(PwppBatch Bt, int b_lo, i
                 if (Row<G>::ballot(any) != 0ull && j == 0) sh.stripped[q] = 1;
             }
             wave_lds_sync();
-            if (vertical && sh.stripped[ln]) lpr_valid = false;  // the working set changed
+            if (vertical && sh.stripped[ln]) {  // the working set changed
+                lpr_valid = false;
+                stash_valid = false;
+            }
         }
 
         // ---- what comes next for the patch of this lane
@@ -1088,7 +1152,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_ph_rows(PwppBatch Bt, int b_lo, i
         for (unsigned c = 0; c < nchunk_max; ++c) {
             ChunkPts cp;
             load_chunk<G>(cp, pts, strip ? n : 0u, c);
-            const unsigned hit = lane_strip(cp.lp, cp.valid & ~cp.strip, strip, pl, P.th_dist_v);
+            const unsigned hit = lane_strip(cp.lp, chunk_act(cp), strip, pl, P.th_dist_v);
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) {
                 if (hit >> k & 1u) {
@@ -1125,7 +1189,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_ph_rows(PwppBatch Bt, int b_lo, i
         int w[kPPT];
         if (__any(last)) load_chunk_idx<G>(w, pts, last ? n : 0u, c);
         Moments mc;
-        const unsigned gmask = lane_stage_moments(cp.lp, cp.valid & ~cp.strip, kind, thr_seed, P.th_dist, pl, qscale, mc);
+        const unsigned gmask = lane_stage_moments(cp.lp, chunk_act(cp), kind, thr_seed, P.th_dist, pl, qscale, mc);
         m.n += mc.n;
 #pragma unroll
         for (int k = 0; k < 3; ++k) m.s1[k] += mc.s1[k];
@@ -1576,7 +1640,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
 }  // namespace
 
 // launches of K4; ev (optional) = 7 events recorded around up to six launches
-#define PWPP_DEFAULT_FIT_PLAN "W16:1023,S64:65535"
+#define PWPP_DEFAULT_FIT_PLAN "W16:1023,W64.2:65535"
 #define PWPP_LATENCY_FIT_PLAN "S64:511"
 #define PWPP_LATENCY_PLAN_MAX_FRAMES 4
 // `aux` (optional): a second stream + two events.  For a handful of frames the fit kernels are
