@@ -159,6 +159,7 @@ int build_dev_params(const pwpp_params &p, PwppDevParams &d) {
     if (p.num_rings_of_interest < 0 || p.num_rings_of_interest > PWPP_MAX_ROI)
         return fail(PWPP_E_ARG, "num_rings_of_interest=%d: the reference keeps update_*_[4] (patchworkpp.h:174-175)", p.num_rings_of_interest);
     if (!(p.max_range > p.min_range)) return fail(PWPP_E_ARG, "max_range must exceed min_range");
+    if (!(p.max_range <= 8388607.0)) return fail(PWPP_E_UNSUPPORTED, "max_range=%g: the fixed-point plane-fit sums hold coordinates up to 2^23 - 1 m", p.max_range);
     if (p.max_flatness_storage < 0 || p.max_elevation_storage < 0) return fail(PWPP_E_ARG, "negative history storage");
     std::memset(&d, 0, sizeof(d));
     int bins = 0, total_rings = 0, near = 0, max_near_sectors = 0;

@@ -259,21 +259,27 @@ struct Moments {  // per-lane partial sums of the quantised coordinates
 // v_fma_f64 costs half of the quarter-rate 64-bit integer multiply-add.  Flushed into the int64
 // totals after every chunk, so the totals stay exact integers.
 struct ChunkMoments {
-    int n, s1[3];
+    int n, s1z;
+    double s1x, s1y;
     double s2[6];
     __device__ __forceinline__ void clear() {
         n = 0;
-        s1[0] = s1[1] = s1[2] = 0;
+        s1z = 0;
+        s1x = s1y = 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) s2[k] = 0.0;
     }
+    // x and y of a binned point lie within max_range, and max_range * 2^s <= 2^23 - 1 (validated at
+    // create time), so their clamp can never act and the rounded product is converted float ->
+    // double directly (v_rndne_f32, v_cvt_f64_f32); z is unbounded and may be NaN: integer path.
     __device__ __forceinline__ void add(float x, float y, float z, float scale) {
-        const int qx = fxp_quantise(x, scale), qy = fxp_quantise(y, scale), qz = fxp_quantise(z, scale);
-        const double dx = (double)qx, dy = (double)qy, dz = (double)qz;
+        const double dx = (double)__builtin_rintf(x * scale), dy = (double)__builtin_rintf(y * scale);
+        const int qz = fxp_quantise(z, scale);
+        const double dz = (double)qz;
         n += 1;
-        s1[0] += qx;
-        s1[1] += qy;
-        s1[2] += qz;
+        s1x += dx;
+        s1y += dy;
+        s1z += qz;
         s2[0] = __builtin_fma(dx, dx, s2[0]);
         s2[1] = __builtin_fma(dx, dy, s2[1]);
         s2[2] = __builtin_fma(dx, dz, s2[2]);
@@ -283,8 +289,9 @@ struct ChunkMoments {
     }
     __device__ __forceinline__ void flush_into(Moments &m) const {
         m.n += n;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) m.s1[k] += s1[k];
+        m.s1[0] += (long long)s1x;
+        m.s1[1] += (long long)s1y;
+        m.s1[2] += s1z;
 #pragma unroll
         for (int k = 0; k < 6; ++k) m.s2[k] += (long long)s2[k];
     }
