@@ -1026,7 +1026,10 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
 // ------------------------------------------------------------------------------------------
 // K6  write the index lists
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_emit(PwppBatch Bt) {
+// One WAVE per bin: a frame has ~500 bins of ~250 points, and with four-wave blocks three of four
+// waves were launched only to find nothing to do (2 M waves per batch; the kernel was bound by wave launches).
+constexpr int kEmitBlock = 64;
+__global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt) {
     const int f = blockIdx.y, seg = blockIdx.x;
     const PwppDevParams &P = Bt.P;
     const int B = P.num_bins, NB = B + 2;
@@ -1039,22 +1042,22 @@ __global__ __launch_bounds__(kBlock) void k_emit(PwppBatch Bt) {
     const bool whole = seg >= B || (uint64_t)n < P.min_pts;
     if (whole) {
         const int *src = Bt.sorted_idx + fd.base + off;
-        for (unsigned i = threadIdx.x; i < n; i += kBlock) out[da + i] = src[i];
+        for (unsigned i = threadIdx.x; i < n; i += kEmitBlock) out[da + i] = src[i];
         return;
     }
     const int *src = Bt.plist + fd.base + off;
     const unsigned ng = (unsigned)Bt.recs[(size_t)f * B + seg].n_ground;
     const unsigned db = Bt.dst_b[(size_t)f * NB + seg];
-    for (unsigned i0 = threadIdx.x; i0 < n; i0 += 4 * kBlock) {  // four loads in flight per thread
+    for (unsigned i0 = threadIdx.x; i0 < n; i0 += 4 * kEmitBlock) {  // four loads in flight per thread
         int v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const unsigned i = i0 + u * kBlock;
+            const unsigned i = i0 + u * kEmitBlock;
             v[u] = i < n ? src[i] : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const unsigned i = i0 + u * kBlock;
+            const unsigned i = i0 + u * kEmitBlock;
             if (i < n) {
                 if (i < ng)
                     out[da + i] = v[u];
@@ -1110,7 +1113,7 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     else
         hipLaunchKernelGGL(k_gle_tgr, dim3(F), dim3(kBlock), 0, stream, B);
     if (ev) (void)hipEventRecord(ev[10], stream);
-    hipLaunchKernelGGL(k_emit, dim3(NB, F), dim3(kBlock), 0, stream, B);
+    hipLaunchKernelGGL(k_emit, dim3(NB, F), dim3(kEmitBlock), 0, stream, B);
     if (ev) (void)hipEventRecord(ev[11], stream);
     return (int)hipGetLastError();
 }
