@@ -110,7 +110,7 @@ __device__ __forceinline__ unsigned bin_code_exact(const PwppDevParams &P, float
 // and further than f_margin_t (>= 8x the angle error) from every sector boundary lands in the same
 // bin in double.  Everything else -- and the exact directions of czm_atan2 -- returns false and
 // takes bin_code_exact.
-__device__ __forceinline__ bool bin_code_fast(const PwppDevParams &P, float x, float y, unsigned &code) {
+__device__ __forceinline__ bool bin_code_fast(const PwppDevParams &P, const float4 *zt, float x, float y, unsigned &code) {
     const float ax = fabsf(x), ay = fabsf(y);
     if (!(ax > 0.0f) || !(ay > 0.0f) || ax == ay) return false;  // axes, diagonals, NaN
     const float rf = __builtin_amdgcn_sqrtf(__builtin_fmaf(x, x, y * y));
@@ -120,12 +120,11 @@ __device__ __forceinline__ bool bin_code_fast(const PwppDevParams &P, float x, f
         return (rf <= lo - mr) || (rf >= hi + mr);  // NaN: not sure
     }
     const int k = (rf >= P.f_zone[1] ? 1 : 0) + (rf >= P.f_zone[2] ? 1 : 0) + (rf >= P.f_zone[3] ? 1 : 0);
-    const float zmin = k == 0 ? P.f_zone[0] : (k == 1 ? P.f_zone[1] : (k == 2 ? P.f_zone[2] : P.f_zone[3]));
-    const float inv_ring = k == 0 ? P.f_inv_ring[0] : (k == 1 ? P.f_inv_ring[1] : (k == 2 ? P.f_inv_ring[2] : P.f_inv_ring[3]));
-    const float inv_sec = k == 0 ? P.f_inv_sector[0] : (k == 1 ? P.f_inv_sector[1] : (k == 2 ? P.f_inv_sector[2] : P.f_inv_sector[3]));
-    const int nring = k == 0 ? P.rings[0] : (k == 1 ? P.rings[1] : (k == 2 ? P.rings[2] : P.rings[3]));
-    const int nsec = k == 0 ? P.sectors[0] : (k == 1 ? P.sectors[1] : (k == 2 ? P.sectors[2] : P.sectors[3]));
-    const int base = k == 0 ? P.bin_base[0] : (k == 1 ? P.bin_base[1] : (k == 2 ? P.bin_base[2] : P.bin_base[3]));
+    // the zone's constants come from a 128-byte LDS table (two ds_read_b128): as selects on the kernel
+    // arguments they cost ~45 VALU instructions and five per-lane global loads per point
+    const float4 za = zt[2 * k], zb = zt[2 * k + 1];
+    const float zmin = za.x, inv_ring = za.y, inv_sec = za.z;
+    const int nring = __float_as_int(za.w), nsec = __float_as_int(zb.x), base = __float_as_int(zb.y);
     // ring (zone and range boundaries are ring boundaries too)
     const float rq = (rf - zmin) * inv_ring;
     const float rfl = floorf(rq);
@@ -158,7 +157,16 @@ __device__ __forceinline__ bool bin_code_fast(const PwppDevParams &P, float x, f
     return !unsure;
 }
 
-__device__ __forceinline__ unsigned czm_code(const PwppDevParams &P, float x, float y, float z, float inten,
+// zone table of bin_code_fast: {zmin, 1/ring size, 1/sector size, rings}, {sectors, first bin, -, -} per zone
+__device__ __forceinline__ void fill_zone_table(const PwppDevParams &P, float4 *zt) {
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        zt[2 * k] = make_float4(P.f_zone[k], P.f_inv_ring[k], P.f_inv_sector[k], __int_as_float(P.rings[k]));
+        zt[2 * k + 1] = make_float4(__int_as_float(P.sectors[k]), __int_as_float(P.bin_base[k]), 0.0f, 0.0f);
+    }
+}
+
+__device__ __forceinline__ unsigned czm_code(const PwppDevParams &P, const float4 *zt, float x, float y, float z, float inten,
                                              bool has_intensity, double sensor_height, float rnr_z_guard, bool exact_only,
                                              bool never_exact = false) {
     const unsigned B = (unsigned)P.num_bins;
@@ -176,13 +184,14 @@ __device__ __forceinline__ unsigned czm_code(const PwppDevParams &P, float x, fl
     }
     if (z == FLT_MIN) return PWPP_CODE_DROP;  // ref :591 (tombstone value in the input itself)
     unsigned code = 0;
-    if (!exact_only && bin_code_fast(P, x, y, code)) return code;
+    if (!exact_only && bin_code_fast(P, zt, x, y, code)) return code;
     if (never_exact) return code;  // timing ablation only (PWPP_DEBUG_FLAGS & 128)
     return bin_code_exact(P, x, y);
 }
 
 __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
     __shared__ unsigned s_hist[PWPP_MAX_BINS + 2];
+    __shared__ float4 s_zt[8];
     const int f = blockIdx.y;
     const PwppFrameDesc fd = Bt.frames[f];
     const int first = blockIdx.x * kPtsPerBlock;
@@ -190,6 +199,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
     const PwppDevParams &P = Bt.P;
     const int NB = P.num_bins + 2;
     for (int b = threadIdx.x; b < NB; b += kBlock) s_hist[b] = 0;
+    fill_zone_table(P, s_zt);
     __syncthreads();
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const float rnr_z_guard = (float)(-sensor_height - 0.8) + 1e-3f;
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
         if (i < fd.n) {
             float x, y, z, w;
             load_point(fd, i, x, y, z, w);
-            const unsigned code = czm_code(P, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0, (Bt.debug & 128) != 0);
+            const unsigned code = czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0, (Bt.debug & 128) != 0);
             codes[i] = (uint16_t)code;
             if (code == PWPP_CODE_DROP) ++dropped;
             pcode[j] = code;
