@@ -75,6 +75,21 @@ __device__ __forceinline__ unsigned wave_run_add(unsigned *counters, unsigned co
     return old;
 }
 
+// Histogram flavour of wave_run_add (K1): only the first lane of a run needs anything -- the run
+// length, i.e. the distance to the next run head.
+__device__ __forceinline__ void wave_run_count(unsigned *counters, unsigned code, bool active) {
+    const int ln = lane_id();
+    const unsigned key = active ? code : (0x80000000u | (unsigned)ln);
+    const unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
+    const bool head = ln == 0 || key != prev;
+    const unsigned long long heads = __ballot(head);
+    if (head && active) {
+        const unsigned long long above = (heads >> ln) >> 1;  // run heads after this lane
+        const int len = above ? __ffsll((long long)above) : 64 - ln;
+        atomicAdd(&counters[code], (unsigned)len);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K1  RNR + CZM code + histogram
 // ------------------------------------------------------------------------------------------
@@ -221,8 +236,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
     }
 #pragma unroll
     for (int j = 0; j < kPtsPerBlock / kBlock; ++j) {
-        unsigned pos;
-        (void)wave_run_add(s_hist, pcode[j], pcode[j] != PWPP_CODE_DROP, pos);
+        wave_run_count(s_hist, pcode[j], pcode[j] != PWPP_CODE_DROP);
     }
     __syncthreads();
     unsigned *gcount = Bt.bin_count + (size_t)f * NB;
