@@ -132,6 +132,10 @@ PARAM_VARIANTS = [
     dict(sensor_height=2.0), dict(num_rings_of_interest=2), dict(adaptive_seed_selection_margin=-0.9),
     dict(sectors=(36, 36, 36, 36)), dict(sectors=(8, 8, 8, 8), rings=(1, 1, 1, 1)), dict(rings=(3, 5, 2, 6)),
     dict(elev=(-1.5, -1.4, -1.3, -1.2), flat=(1e-4, 2e-4, 3e-4, 4e-4)),
+    # the dual seed pass of the big-bin kernel: R-VPF threshold below / equal to / above the R-GPF one,
+    # and planes that come out vertical almost always (strip -> the stashed seed totals are dropped)
+    dict(th_seeds_v=0.05), dict(th_seeds=0.25, th_seeds_v=0.25), dict(th_seeds_v=0.6, th_seeds=0.05),
+    dict(uprightness_thr=0.9999, th_dist_v=0.3), dict(uprightness_thr=0.9999, th_dist_v=0.02, num_iter=2),
 ]
 
 
@@ -159,6 +163,14 @@ def test_parameter_variants(kitti, oracle, variant):
     for pts in (kitti[0], syn, kitti[4]):
         h.estimate_ground(pts)
         assert_frame_equal(h, 0, est.run(pts), pts.shape[0], state_index=0)
+    # the same frames as one batch: more than four frames take the throughput plan (k_fit_w64 kernels),
+    # a single frame the latency plan (k_fit_srows + k_fit_stream)
+    frames = [kitti[1], syn, kitti[3], kitti[0], kitti[5], syn]
+    hb = pwpp_hip.Handle(p)
+    hb.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+    for i, pts in enumerate(frames):
+        ref = ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(pts)
+        assert_frame_equal(hb, i, ref, pts.shape[0])
 
 
 def test_layouts_and_three_columns(kitti, oracle):
