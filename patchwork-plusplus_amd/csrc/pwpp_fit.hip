@@ -1641,7 +1641,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
 
 // launches of K4; ev (optional) = 7 events recorded around up to six launches
 #define PWPP_DEFAULT_FIT_PLAN "W16:1023,W64.2:65535"
-#define PWPP_LATENCY_FIT_PLAN "S64:511"
+#define PWPP_LATENCY_FIT_PLAN "S64:65535"
 #define PWPP_LATENCY_PLAN_MAX_FRAMES 4
 // `aux` (optional): a second stream + two events.  For a handful of frames the fit kernels are
 // latency-bound chains; the workgroup kernel for the big bins then runs CONCURRENTLY with the
@@ -1663,8 +1663,9 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     // whatever is larger than the last entry goes to the workgroup-per-patch kernel.
     // PWPP_FIT_PLAN overrides the default for tuning experiments.
     const char *plan = getenv("PWPP_FIT_PLAN");
-    // throughput plan for batches; for a handful of frames the chain latency of a patch is what
-    // counts, so big patches get a whole workgroup (k_fit_stream) and the rest one wave each
+    // throughput plan for batches (64 / 2 patches per wave, lane-parallel solves); for a handful of
+    // frames the chain latency of a patch is what counts: one prefetching wave per patch, every patch
+    // at once (198 us per KITTI frame; with the > 511-point bins on k_fit_stream instead: 225 us)
     if (!plan) plan = F <= PWPP_LATENCY_PLAN_MAX_FRAMES ? PWPP_LATENCY_FIT_PLAN : PWPP_DEFAULT_FIT_PLAN;
     int k_lo = 0, slot = 0;
     unsigned n_lo = 1;
