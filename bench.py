@@ -116,7 +116,11 @@ def main():
     torch.cuda.synchronize()
     ptrs = [big.data_ptr() + int(offs[i]) * 16 for i in range(F)]
 
-    h = pwpp_hip.Handle(device=local_rank)
+    params = pwpp_hip.default_params()
+    if args.workload == "dense":  # BASELINE.json configs[4]: 36-sector CZM
+        for k in range(4):
+            params.num_sectors_each_zone[k] = 36
+    h = pwpp_hip.Handle(params, device=local_rank)
     batch = h.make_device_batch(ptrs, ns)
 
     def step():
@@ -175,7 +179,7 @@ def main():
             "config": {"workload": "configs[2]: batch of %d replayed 64-beam frames per GPU, device-resident in %d distinct "
                                    "buffers (%.2f GB), fresh state per frame, default 4-zone CZM"
                                    % (F, F, offs[-1] * 16 / 1e9) if args.workload == "kitti" else
-                                   "configs[4]-style: %d dense 128-beam ~500k-pt frames per GPU, default CZM" % F,
+                                   "configs[4]: %d dense synthetic 128-beam ~500k-pt frames per GPU, 36-sector CZM" % F,
                        "frames_per_gpu": F, "points_per_frame": int(np.mean(ns)), "parallelism": "frames sharded, dp%d" % world},
             "latency": {"workload": "configs[1]: single frame, device-resident, fresh state", "ms_per_frame_wall": 1000.0 * lat,
                         "gpu_us": lat_gpu_us},

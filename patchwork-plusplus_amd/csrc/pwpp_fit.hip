@@ -1669,7 +1669,10 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     if (!plan) plan = F <= PWPP_LATENCY_PLAN_MAX_FRAMES ? PWPP_LATENCY_FIT_PLAN : PWPP_DEFAULT_FIT_PLAN;
     int k_lo = 0, slot = 0;
     unsigned n_lo = 1;
-    const bool fork = aux != nullptr && !ev && F <= PWPP_LATENCY_PLAN_MAX_FRAMES && !getenv("PWPP_FIT_PLAN");
+    // PWPP_FIT_CONCURRENT=1: the second size class runs on the aux stream beside the first (+3.5 % on
+    // the 1024-frame batch; off by default: the per-kernel times bench.py reports lose their meaning)
+    const bool concurrent = aux != nullptr && !ev && F > PWPP_LATENCY_PLAN_MAX_FRAMES && getenv("PWPP_FIT_CONCURRENT") != nullptr;
+    const bool fork = concurrent || (aux != nullptr && !ev && F <= PWPP_LATENCY_PLAN_MAX_FRAMES && !getenv("PWPP_FIT_PLAN"));
     if (fork) {  // the big-bin kernel only depends on K3; its bucket range starts where the latency plan ends
         (void)hipEventRecord(aux_fork, stream);
         (void)hipStreamWaitEvent(aux, aux_fork, 0);
@@ -1688,34 +1691,35 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
         const int k_hi = pwpp_size_bucket(upper + 1u);
         if (k_hi > k_lo) {
             if (ev) (void)hipEventRecord(ev[slot], stream);
+            const hipStream_t ls = (concurrent && slot >= 1) ? aux : stream;  // later classes beside the first one
             const unsigned patches = cap(n_lo);
             const dim3 grid(F, (patches * (unsigned)g + kBlock - 1) / kBlock);
-            if (mode == 'L' && g == 16) hipLaunchKernelGGL(k_fit_rows<16>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-            else if (mode == 'L' && g == 32) hipLaunchKernelGGL(k_fit_rows<32>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-            else if (mode == 'L' && g == 64) hipLaunchKernelGGL(k_fit_rows<64>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-            else if (mode == 'S' && g == 8) hipLaunchKernelGGL(k_fit_srows<8>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-            else if (mode == 'S' && g == 16) hipLaunchKernelGGL(k_fit_srows<16>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-            else if (mode == 'S' && g == 32) hipLaunchKernelGGL(k_fit_srows<32>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-            else if (mode == 'S' && g == 64) hipLaunchKernelGGL(k_fit_srows<64>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+            if (mode == 'L' && g == 16) hipLaunchKernelGGL(k_fit_rows<16>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            else if (mode == 'L' && g == 32) hipLaunchKernelGGL(k_fit_rows<32>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            else if (mode == 'L' && g == 64) hipLaunchKernelGGL(k_fit_rows<64>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            else if (mode == 'S' && g == 8) hipLaunchKernelGGL(k_fit_srows<8>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            else if (mode == 'S' && g == 16) hipLaunchKernelGGL(k_fit_srows<16>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            else if (mode == 'S' && g == 32) hipLaunchKernelGGL(k_fit_srows<32>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            else if (mode == 'S' && g == 64) hipLaunchKernelGGL(k_fit_srows<64>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'W') {  // "W<lanes per patch>.<patches per wave>"
                 if (pw == 0) pw = 64;
                 const dim3 wgrid(F, (patches + (unsigned)pw * kWaves - 1) / ((unsigned)pw * kWaves));
-                if (g == 16 && pw == 64) hipLaunchKernelGGL((k_fit_w64<16, 64>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-                else if (g == 16 && pw == 32) hipLaunchKernelGGL((k_fit_w64<16, 32>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-                else if (g == 16 && pw == 16) hipLaunchKernelGGL((k_fit_w64<16, 16>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-                else if (g == 64 && pw == 32) hipLaunchKernelGGL((k_fit_w64<64, 32>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-                else if (g == 64 && pw == 16) hipLaunchKernelGGL((k_fit_w64<64, 16>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-                else if (g == 64 && pw == 8) hipLaunchKernelGGL((k_fit_w64<64, 8>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-                else if (g == 64 && pw == 4) hipLaunchKernelGGL((k_fit_w64<64, 4>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-                else if (g == 64 && pw == 2) hipLaunchKernelGGL((k_fit_w64<64, 2>), wgrid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
+                if (g == 16 && pw == 64) hipLaunchKernelGGL((k_fit_w64<16, 64>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+                else if (g == 16 && pw == 32) hipLaunchKernelGGL((k_fit_w64<16, 32>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+                else if (g == 16 && pw == 16) hipLaunchKernelGGL((k_fit_w64<16, 16>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+                else if (g == 64 && pw == 32) hipLaunchKernelGGL((k_fit_w64<64, 32>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+                else if (g == 64 && pw == 16) hipLaunchKernelGGL((k_fit_w64<64, 16>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+                else if (g == 64 && pw == 8) hipLaunchKernelGGL((k_fit_w64<64, 8>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+                else if (g == 64 && pw == 4) hipLaunchKernelGGL((k_fit_w64<64, 4>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+                else if (g == 64 && pw == 2) hipLaunchKernelGGL((k_fit_w64<64, 2>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
                 else return (int)hipErrorInvalidValue;
             }
             else if (mode == 'P') {
                 const int rounds = 2 * B.P.num_iter + 2;
                 for (int r = 0; r < rounds; ++r) {
-                    if (g == 64) hipLaunchKernelGGL(k_ph_rows<64>, grid, dim3(kBlock), 0, stream, B, k_lo, k_hi);
-                    else hipLaunchKernelGGL(k_ph_rows<16>, dim3(F, (patches * 16u + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, B, k_lo, k_hi);
-                    hipLaunchKernelGGL(k_ph_solve, dim3(F, (patches + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, B, k_lo, k_hi);
+                    if (g == 64) hipLaunchKernelGGL(k_ph_rows<64>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+                    else hipLaunchKernelGGL(k_ph_rows<16>, dim3(F, (patches * 16u + kBlock - 1) / kBlock), dim3(kBlock), 0, ls, B, k_lo, k_hi);
+                    hipLaunchKernelGGL(k_ph_solve, dim3(F, (patches + kBlock - 1) / kBlock), dim3(kBlock), 0, ls, B, k_lo, k_hi);
                 }
             }
             else return (int)hipErrorInvalidValue;
