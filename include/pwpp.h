@@ -200,6 +200,10 @@ int pwpp_reset_kernel_profile(pwpp_handle *h);
 const char *pwpp_kernel_name(int k);
 /* fixed-point shift s of the plane-fit arithmetic contract for this handle */
 int pwpp_get_fxp_shift(pwpp_handle *h);
+/* one-pass binning (fixed bin segments; DESIGN.md 3, K1'): batches launched that way and how many of
+ * them had to be redone on the exact two-pass path because a bin outgrew its segment.  Finishes the
+ * batch in flight first.  No reference counterpart. */
+int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,8 @@ struct PinnedBuf {
 const char *kKernelNames[PWPP_NUM_KERNELS] = {"k_czm_bin", "k_czm_scan", "k_czm_scatter", "k_fit_w64<16,64>", "k_fit_w64<64,2>",
                                               "k_fit[2]", "k_fit[3]", "k_fit[4]", "k_fit_stream", "k_gle_tgr", "k_emit"};  // fit slots: default PWPP_FIT_PLAN
 
+bool g_slot0_one_pass = false;
+
 }  // namespace
 
 struct pwpp_handle {
@@ -114,6 +116,15 @@ struct pwpp_handle {
     bool pending = false;  // launches in flight, results not yet fetched
     double time_us = 0.0;
     std::vector<PwppFrameDesc> descs;  // host copy of the last batch (device pointers inside)
+    // one-pass binning (fixed bin segments, DESIGN.md section 3 K1'): state of the batch in flight
+    bool one_pass = false;           // the batch in flight uses fixed segments; overflow flags are checked when it lands
+    int one_pass_holdoff = 0;        // batches to run on the two-pass path after an overflow
+    int64_t slots_per_frame = 0;     // of the current capacity table
+    int cap_max_n = -1;              // largest frame the capacity table on the device was built for
+    int max_n = 0;
+    int64_t total_points = 0;
+    int cols = 4, layout = 0;
+    long long one_pass_batches = 0, one_pass_redone = 0;
 
     // workspace
     DevBuf<PwppFrameDesc> d_frames;
@@ -127,6 +138,7 @@ struct pwpp_handle {
     DevBuf<int32_t> d_out;
     DevBuf<uint32_t> d_bins;  // 5 slabs of frames*(B+2): count, off, cursor, dst_a, dst_b
     DevBuf<uint32_t> d_cls_start;  // frames * 8
+    DevBuf<uint32_t> d_cap_off;    // B + 3 segment starts of the one-pass path
     DevBuf<uint16_t> d_cls_list;   // frames * B
     DevBuf<PwppPatchRec> d_recs;
     DevBuf<PwppFitState> d_fit;
@@ -246,6 +258,116 @@ void fill_default_state(const pwpp_handle *h, PwppStateScalar &s) {
     }
 }
 
+int finish_pending(pwpp_handle *h);
+
+// Segment sizes of the one-pass path for batches whose largest frame has max_n points: a bin of zone
+// k gets `scale` times its even share of such a frame (KITTI: the fullest bin holds 2.0x the even
+// share of its zone; default scale 4), the two pseudo-bins (RNR hits, out-of-range points) an eighth
+// of the frame each.  PWPP_ONE_PASS_SCALE overrides the scale (tests use a tiny one to force the
+// overflow path).
+int build_capacity_table(pwpp_handle *h, int max_n) {
+    const PwppDevParams &P = h->dp;
+    const int B = P.num_bins, NB = B + 2;
+    double scale = 4.0;
+    if (const char *e = std::getenv("PWPP_ONE_PASS_SCALE")) scale = std::atof(e);
+    if (!(scale > 0.0)) scale = 4.0;
+    std::vector<uint32_t> off((size_t)NB + 1);
+    uint64_t run = 0;
+    for (int b = 0; b < NB; ++b) {
+        off[(size_t)b] = (uint32_t)run;
+        double cap;
+        if (b < B) {
+            int k = 0;
+            while (k < 3 && b >= P.bin_base[k + 1]) ++k;
+            const int bins_k = P.bin_base[k + 1] - P.bin_base[k];
+            cap = scale * (double)max_n / (double)(bins_k > 0 ? bins_k : 1) + 64.0;
+        } else {
+            cap = (double)max_n / 8.0 + 64.0;
+        }
+        if (cap > (double)max_n) cap = (double)max_n;
+        run += ((uint64_t)cap + 15u) & ~(uint64_t)15u;
+        if (run >= ((uint64_t)1 << 32)) return fail(PWPP_E_NOMEM, "one-pass capacity table overflows 32-bit offsets");
+    }
+    off[(size_t)NB] = (uint32_t)run;
+    int rc = h->d_cap_off.ensure((size_t)NB + 1);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(h->d_cap_off.p, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    h->slots_per_frame = (int64_t)run;
+    h->cap_max_n = max_n;
+    return PWPP_OK;
+}
+
+// Launches the pipeline over the batch described by h->descs (buffers sized, inputs on the device).
+// one_pass: fixed bin segments (k_czm_bin_scatter); otherwise the exact two-pass binning.
+int launch_prepared(pwpp_handle *h, bool one_pass) {
+    const int B = h->dp.num_bins, NB = B + 2;
+    const int frames = h->frames;
+    // where a frame's bins live in the bin-ordered buffers
+    int64_t base = 0;
+    for (int f = 0; f < frames; ++f) {
+        PwppFrameDesc &d = h->descs[(size_t)f];
+        d.sbase = one_pass ? (int64_t)f * h->slots_per_frame : base;
+        base += d.n;
+    }
+    std::memcpy(h->h_frames.p, h->descs.data(), (size_t)frames * sizeof(PwppFrameDesc));
+    HIPCHK(hipMemcpyAsync(h->d_frames.p, h->h_frames.p, (size_t)frames * sizeof(PwppFrameDesc), hipMemcpyHostToDevice, h->stream));
+
+    PwppBatch bt;
+    std::memset(&bt, 0, sizeof(bt));
+    bt.P = h->dp;
+    bt.frames = h->d_frames.p;
+    bt.num_frames = h->frames;
+    bt.max_n = h->max_n;
+    {
+        const char *dbg = std::getenv("PWPP_DEBUG_FLAGS");  // timing ablations only; results are wrong when set
+        bt.debug = dbg ? std::atoi(dbg) : 0;
+    }
+    if (h->mode == PWPP_MODE_FRESH) {
+        bt.P.hist_cap = h->fresh_hist_cap;
+        bt.st_scalar = h->d_st_fresh.p;
+        bt.st_hist = h->d_hist_fresh.p;
+    } else {
+        bt.P.hist_cap = h->stream_hist_cap;
+        bt.st_scalar = h->d_st_stream.p;
+        bt.st_hist = h->d_hist_stream.p;
+    }
+    bt.codes = h->d_codes.p;
+    const size_t slab = (size_t)h->frames * NB;
+    bt.bin_count = h->d_bins.p;
+    bt.bin_off = h->d_bins.p + slab;
+    bt.bin_cursor = h->d_bins.p + 2 * slab;
+    bt.dst_a = h->d_bins.p + 3 * slab;
+    bt.dst_b = h->d_bins.p + 4 * slab;
+    bt.cls_start = h->d_cls_start.p;
+    bt.cls_list = h->d_cls_list.p;
+    bt.sorted_xyz = h->d_sorted_xyz.p;
+    bt.sorted_idx = h->d_sorted_idx.p;
+    bt.plist = h->d_plist.p;
+    bt.recs = h->d_recs.p;
+    bt.fit = h->d_fit.p;
+    bt.out_idx = h->d_out.p;
+    bt.centers = h->d_centers.p;
+    bt.normals = h->d_normals.p;
+    bt.results = h->d_results.p;
+    bt.dbg = h->d_dbg.p;
+
+    bt.cap_off = one_pass ? h->d_cap_off.p : nullptr;
+    HIPCHK(hipEventRecord(h->ev_begin, h->stream));
+    // zero the histogram, the scatter cursors and the per-frame result counters
+    HIPCHK(hipMemsetAsync(bt.bin_count, 0, slab * sizeof(uint32_t), h->stream));
+    if (!one_pass) HIPCHK(hipMemsetAsync(bt.bin_cursor, 0, slab * sizeof(uint32_t), h->stream));
+    HIPCHK(hipMemsetAsync(bt.results, 0, (size_t)frames * sizeof(PwppFrameResult), h->stream));
+    if (bt.debug & 4) HIPCHK(hipMemsetAsync(bt.dbg, 0, 64 * sizeof(unsigned long long), h->stream));
+    const int lrc = pwpp_launch_pipeline(&bt, h->stream, h->profiling ? h->ev_k : nullptr, h->aux_stream, h->aux_fork, h->aux_join);
+    if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    HIPCHK(hipEventRecord(h->ev_end, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_results.p, h->d_results.p, (size_t)frames * sizeof(PwppFrameResult), hipMemcpyDeviceToHost, h->stream));
+    h->profile_pending = h->profiling;
+    h->one_pass = one_pass;
+    g_slot0_one_pass = one_pass;
+    return PWPP_OK;
+}
+
 int finish_pending(pwpp_handle *h) {
     if (!h->pending) return PWPP_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -261,6 +383,19 @@ int finish_pending(pwpp_handle *h) {
             h->prof_launches[k] += 1;
         }
         h->profile_pending = false;
+    }
+    if (h->one_pass) {  // did every bin fit its segment?  if not, redo the batch on the exact two-pass path
+        bool over = false;
+        for (int f = 0; f < h->frames; ++f) over = over || h->h_results.p[f].overflow != 0;
+        h->one_pass = false;
+        if (over) {
+            ++h->one_pass_redone;
+            h->one_pass_holdoff = 8;
+            const int rc = launch_prepared(h, false);
+            if (rc) return rc;
+            h->pending = true;
+            return finish_pending(h);
+        }
     }
     h->have_results = true;
     return PWPP_OK;
@@ -289,7 +424,10 @@ int pwpp_device_count(void) {
     return n;
 }
 
-const char *pwpp_kernel_name(int k) { return (k >= 0 && k < PWPP_NUM_KERNELS) ? kKernelNames[k] : ""; }
+const char *pwpp_kernel_name(int k) {
+    if (k == 0 && g_slot0_one_pass) return "k_czm_bin_scatter";  // what the last launch ran in the first slot
+    return (k >= 0 && k < PWPP_NUM_KERNELS) ? kKernelNames[k] : "";
+}
 
 int pwpp_params_default(pwpp_params *p) {  // reference patchworkpp.h:79-111
     if (!p) return fail(PWPP_E_ARG, "null params");
@@ -399,6 +537,7 @@ int pwpp_destroy(pwpp_handle *h) {
     h->d_recs.release();
     h->d_fit.release();
     h->d_cls_start.release();
+    h->d_cap_off.release();
     h->d_cls_list.release();
     h->d_centers.release();
     h->d_normals.release();
@@ -451,13 +590,39 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     if (total >= ((int64_t)1 << 31)) return fail(PWPP_E_ARG, "batch of %lld points exceeds 2^31", (long long)total);
     const size_t tp = (size_t)(total > 0 ? total : 1);
 
+    // One-pass binning (fixed bin segments, k_czm_bin_scatter) for batches of independent frames: the
+    // bin-ordered buffers hold frames x slots_per_frame records instead of one per point.  Used when
+    // the memory is there; any overflow is caught when the batch lands and the batch is redone exactly.
+    bool one_pass = false;
+    size_t bin_slots = tp;
+    {
+        static const bool env_off = std::getenv("PWPP_NO_ONE_PASS") != nullptr;
+        if (h->one_pass_holdoff > 0) {
+            --h->one_pass_holdoff;
+        } else if (!env_off && mode == PWPP_MODE_FRESH && frames > 4 && max_n > 0) {
+            if (max_n > h->cap_max_n || 2 * (int64_t)max_n < h->cap_max_n) {
+                if ((rc = finish_pending(h))) return rc;
+                if ((rc = build_capacity_table(h, max_n))) return rc;
+            }
+            const size_t want = (size_t)frames * (size_t)h->slots_per_frame;
+            size_t free_b = 0, total_b = 0;
+            const size_t per_slot = sizeof(PwppXyz) + 2 * sizeof(int32_t);
+            const size_t held = (h->d_sorted_xyz.cap + h->d_sorted_idx.cap + h->d_plist.cap) * sizeof(int32_t) + h->d_sorted_xyz.cap * 2 * sizeof(int32_t);
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (want + want / 8 + 64) * per_slot * 21 / 20 <= free_b + held &&
+                want < ((size_t)1 << 40)) {
+                one_pass = true;
+                bin_slots = want;
+            }
+        }
+    }
+
     if ((rc = h->d_frames.ensure((size_t)frames))) return rc;
     if ((rc = h->h_frames.ensure((size_t)frames))) return rc;
     if ((rc = h->h_base.ensure((size_t)frames + 1))) return rc;
     if ((rc = h->d_codes.ensure(tp))) return rc;
-    if ((rc = h->d_sorted_xyz.ensure(tp + 16))) return rc;  // slack: load_chunk reads record 0 of a patch beyond its end
-    if ((rc = h->d_sorted_idx.ensure(tp))) return rc;
-    if ((rc = h->d_plist.ensure(tp))) return rc;
+    if ((rc = h->d_sorted_xyz.ensure(bin_slots + 16))) return rc;  // slack: load_chunk reads record 0 of a patch beyond its end
+    if ((rc = h->d_sorted_idx.ensure(bin_slots))) return rc;
+    if ((rc = h->d_plist.ensure(bin_slots))) return rc;
     if ((rc = h->d_out.ensure(tp))) return rc;
     if ((rc = h->d_bins.ensure((size_t)frames * NB * 5))) return rc;
     if ((rc = h->d_recs.ensure((size_t)frames * B))) return rc;
@@ -504,61 +669,15 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
         base += n[f];
     }
     h->h_base.p[frames] = base;
-    std::memcpy(h->h_frames.p, h->descs.data(), (size_t)frames * sizeof(PwppFrameDesc));
-    HIPCHK(hipMemcpyAsync(h->d_frames.p, h->h_frames.p, (size_t)frames * sizeof(PwppFrameDesc), hipMemcpyHostToDevice, h->stream));
 
-    PwppBatch bt;
-    std::memset(&bt, 0, sizeof(bt));
-    bt.P = h->dp;
-    bt.frames = h->d_frames.p;
-    bt.num_frames = frames;
-    bt.max_n = max_n;
-    {
-        const char *dbg = std::getenv("PWPP_DEBUG_FLAGS");  // timing ablations only; results are wrong when set
-        bt.debug = dbg ? std::atoi(dbg) : 0;
-    }
-    if (mode == PWPP_MODE_FRESH) {
-        bt.P.hist_cap = h->fresh_hist_cap;
-        bt.st_scalar = h->d_st_fresh.p;
-        bt.st_hist = h->d_hist_fresh.p;
-    } else {
-        bt.P.hist_cap = h->stream_hist_cap;
-        bt.st_scalar = h->d_st_stream.p;
-        bt.st_hist = h->d_hist_stream.p;
-    }
-    bt.codes = h->d_codes.p;
-    const size_t slab = (size_t)frames * NB;
-    bt.bin_count = h->d_bins.p;
-    bt.bin_off = h->d_bins.p + slab;
-    bt.bin_cursor = h->d_bins.p + 2 * slab;
-    bt.dst_a = h->d_bins.p + 3 * slab;
-    bt.dst_b = h->d_bins.p + 4 * slab;
-    bt.cls_start = h->d_cls_start.p;
-    bt.cls_list = h->d_cls_list.p;
-    bt.sorted_xyz = h->d_sorted_xyz.p;
-    bt.sorted_idx = h->d_sorted_idx.p;
-    bt.plist = h->d_plist.p;
-    bt.recs = h->d_recs.p;
-    bt.fit = h->d_fit.p;
-    bt.out_idx = h->d_out.p;
-    bt.centers = h->d_centers.p;
-    bt.normals = h->d_normals.p;
-    bt.results = h->d_results.p;
-    bt.dbg = h->d_dbg.p;
-
-    HIPCHK(hipEventRecord(h->ev_begin, h->stream));
-    // zero the histogram, the scatter cursors and the per-frame result counters
-    HIPCHK(hipMemsetAsync(bt.bin_count, 0, slab * sizeof(uint32_t), h->stream));
-    HIPCHK(hipMemsetAsync(bt.bin_cursor, 0, slab * sizeof(uint32_t), h->stream));
-    HIPCHK(hipMemsetAsync(bt.results, 0, (size_t)frames * sizeof(PwppFrameResult), h->stream));
-    if (bt.debug & 4) HIPCHK(hipMemsetAsync(bt.dbg, 0, 64 * sizeof(unsigned long long), h->stream));
-    const int lrc = pwpp_launch_pipeline(&bt, h->stream, h->profiling ? h->ev_k : nullptr, h->aux_stream, h->aux_fork, h->aux_join);
-    if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
-    HIPCHK(hipEventRecord(h->ev_end, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_results.p, h->d_results.p, (size_t)frames * sizeof(PwppFrameResult), hipMemcpyDeviceToHost, h->stream));
-    h->profile_pending = h->profiling;
     h->frames = frames;
     h->mode = mode;
+    h->max_n = max_n;
+    h->total_points = total;
+    h->cols = cols;
+    h->layout = layout;
+    if (one_pass) ++h->one_pass_batches;
+    if ((rc = launch_prepared(h, one_pass))) return rc;
     h->pending = true;
     h->have_results = false;
     if (mem == PWPP_MEM_HOST) return finish_pending(h);  // the caller's buffers may go away
@@ -794,6 +913,16 @@ int pwpp_reset_kernel_profile(pwpp_handle *h) {
     return PWPP_OK;
 }
 int pwpp_get_fxp_shift(pwpp_handle *h) { return h ? h->dp.fxp_shift : PWPP_E_ARG; }
+
+int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone) {
+    if (!h) return fail(PWPP_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    if (batches) *batches = h->one_pass_batches;
+    if (redone) *redone = h->one_pass_redone;
+    return PWPP_OK;
+}
 
 /* not part of the public header: timing probes of the last call (PWPP_DEBUG_FLAGS & 4) */
 int pwpp_debug_read(pwpp_handle *h, unsigned long long *out64) {

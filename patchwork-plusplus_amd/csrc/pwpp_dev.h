@@ -46,9 +46,11 @@ struct PwppFrameDesc {
     int32_t cols;      // 3 or 4
     int32_t layout;    // PWPP_LAYOUT_*
     int32_t state_in;  // index into the state arrays, -1 = fresh (defaults from params)
-    int64_t base;      // first slot of this frame in the per-point workspaces
+    int64_t base;      // first slot of this frame in the compact per-point workspaces (codes, out_idx)
     int32_t state_out; // index the updated state is written to
     int32_t pad_;
+    int64_t sbase;     // first slot of this frame in the bin-ordered workspaces (sorted_*, plist); == base
+                       // on the two-pass path, frame * slots_per_frame on the one-pass path (see cap_off)
 };
 
 struct PwppStateScalar {  // = pwpp_state
@@ -83,7 +85,9 @@ struct PwppFitState {  // per (frame, bin): the fit chain of a patch between the
 };
 
 struct PwppFrameResult {
-    int32_t n_ground, n_nonground, n_patches, n_rnr, n_oor, n_dropped, pad0, pad1;
+    int32_t n_ground, n_nonground, n_patches, n_rnr, n_oor, n_dropped;
+    int32_t pad0;      // history slab full (flag)
+    int32_t overflow;  // one-pass binning: some bin of this frame outgrew its segment (the batch is redone on the two-pass path)
 };
 
 // everything a launch needs, by value in the kernarg segment
@@ -100,6 +104,8 @@ struct PwppBatch {
     int32_t max_n;               // largest frame of the batch
     int32_t debug;               // ablation switches for timing experiments only (PWPP_DEBUG_FLAGS); 0 in production
     int32_t pad_;
+    const uint32_t *cap_off;     // one-pass binning: [B+3] first slot of every bin's fixed segment inside a frame
+                                 // (cap_off[B+2] = slots per frame); null on the two-pass path
     PwppStateScalar *st_scalar;  // [num_states]
     double *st_hist;             // [num_states][2][4][hist_cap]
     uint16_t *codes;             // [total points]
@@ -108,7 +114,7 @@ struct PwppBatch {
     uint32_t *bin_cursor;        // [frames][B+2]
     uint32_t *cls_start;         // [frames][PWPP_CLS_STRIDE] first entry of each size bucket in cls_list
     uint16_t *cls_list;          // [frames][B] patch bins sorted by size bucket
-    PwppXyz *sorted_xyz;         // [total points] 12-byte {x,y,z} records grouped by bin; x = NaN: stripped by R-VPF
+    PwppXyz *sorted_xyz;         // [total points | frames x slots per frame] 12-byte {x,y,z} records grouped by bin; x = NaN: stripped by R-VPF
     int *sorted_idx;             // [total points] cloud index of the record (read by the last fit pass and K6 only)
     int32_t *plist;              // [total points] per patch: ground candidates from the front, non-ground from the back
     PwppPatchRec *recs;          // [frames][B]

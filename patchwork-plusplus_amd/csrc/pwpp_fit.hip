@@ -303,9 +303,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_rows(PwppBatch Bt, int b_lo, 
     const unsigned n = alive ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
     const PwppFrameDesc fd = Bt.frames[f];
     const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    const PwppXyz *pts = Bt.sorted_xyz + fd.base + off;
-    const int *pidx = Bt.sorted_idx + fd.base + off;
-    int *plist = Bt.plist + fd.base + off;
+    const PwppXyz *pts = Bt.sorted_xyz + fd.sbase + off;
+    const int *pidx = Bt.sorted_idx + fd.sbase + off;
+    int *plist = Bt.plist + fd.sbase + off;
     const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;  // ref :90
@@ -660,8 +660,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo,
     const unsigned n = alive ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
     const PwppFrameDesc fd = Bt.frames[f];
     const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    const PatchRef pts = patch_ref(Bt, (size_t)fd.base + off);
-    int *plist = Bt.plist + fd.base + off;
+    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + off);
+    int *plist = Bt.plist + fd.sbase + off;
     const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
     const int ln = lane_id();
     const int j = ln & (G - 1), row = ln / G;
     const PwppFrameDesc fd = Bt.frames[f];
-    int *frame_plist = Bt.plist + fd.base;
+    int *frame_plist = Bt.plist + fd.sbase;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;  // ref :90
     const float qscale = (float)(1 << P.fxp_shift);
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
                 const unsigned qn = sh.p[q].n, qoff = sh.p[q].off;
                 const bool use_cutoff = (sh.p[q].flags & 2) != 0;
                 const unsigned nchunk_max = wave_max_u32(need_row ? (qn + 8u * G - 1u) / (8u * G) : 0u);
-                const double l = srow_lpr<G>(patch_ref(Bt, (size_t)fd.base + qoff), qn, nchunk_max, need_row, use_cutoff, cutoff, P.num_lpr);
+                const double l = srow_lpr<G>(patch_ref(Bt, (size_t)fd.sbase + qoff), qn, nchunk_max, need_row, use_cutoff, cutoff, P.num_lpr);
                 if (need_row && j == 0) sh.lpr[q] = l;
             }
             wave_lds_sync();
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
             qpl.ny = pp.ny;
             qpl.nz = pp.nz;
             qpl.d = pp.d;
-            const PatchRef pts = patch_ref(Bt, (size_t)fd.base + pp.off);
+            const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + pp.off);
             int *plist = frame_plist + pp.off;
             const unsigned qn = on ? pp.n : 0u;
             const unsigned nchunk_max = wave_max_u32((qn + 8u * G - 1u) / (8u * G));
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
                 qpl.ny = pp.ny;
                 qpl.nz = pp.nz;
                 qpl.d = pp.d;
-                const PatchRef pts = patch_ref(Bt, (size_t)fd.base + pp.off);
+                const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + pp.off);
                 const unsigned qn = vrow ? pp.n : 0u;
                 const unsigned nchunk_max = wave_max_u32((qn + 8u * G - 1u) / (8u * G));
                 bool any = false;
@@ -1130,8 +1130,8 @@ __global__ __launch_bounds__(kBlock, 5) void k_ph_rows(PwppBatch Bt, int b_lo, i
     const unsigned n = kind != ST_DONE ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
     const PwppFrameDesc fd = Bt.frames[f];
     const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    const PatchRef pts = patch_ref(Bt, (size_t)fd.base + off);
-    int *plist = Bt.plist + fd.base + off;
+    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + off);
+    int *plist = Bt.plist + fd.sbase + off;
     const bool use_cutoff = bin < P.bin_base[1];  // zone 0
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;  // ref :90
@@ -1508,8 +1508,8 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
     PwppPatchRec *rec = Bt.recs + (size_t)f * P.num_bins + bin;
     const PwppFrameDesc fd = Bt.frames[f];
     const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    const PatchRef pts = patch_ref(Bt, (size_t)fd.base + off);
-    int *plist = Bt.plist + fd.base + off;
+    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + off);
+    int *plist = Bt.plist + fd.sbase + off;
     const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;  // ref :90

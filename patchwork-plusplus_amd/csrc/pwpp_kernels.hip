@@ -249,39 +249,129 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K1'  one-pass binning (k_czm_bin_scatter): code AND scatter in the same kernel.
+// The two-pass path streams the cloud twice (K1: 18 B/pt, K3: 34 B/pt) only because a point's
+// slot needs the frame's complete histogram.  With 288 GB of HBM the bins can have FIXED segments
+// instead: bin b of every frame owns cap_off[b+1] - cap_off[b] slots (a multiple of its expected
+// share of the largest frame, sized on the host), so the slot is  segment start + the range this
+// workgroup reserves with one global atomic per bin + the rank inside the workgroup  -- no scan
+// in between, 16 bytes read and 16 written per point.  A bin that outgrows its segment raises the
+// frame's overflow flag (points beyond the segment are not written); the host then redoes the
+// batch on the exact two-pass path, so the result never depends on the capacities.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt) {
+    __shared__ unsigned s_cnt[PWPP_MAX_BINS + 2];     // points of this workgroup per bin, then its first slot in the bin
+    __shared__ unsigned s_seg[PWPP_MAX_BINS + 3];     // segment starts
+    __shared__ float4 s_zt[8];
+    const int f = blockIdx.y;
+    const PwppFrameDesc fd = Bt.frames[f];
+    const int first = blockIdx.x * kPtsPerBlock;
+    if (first >= fd.n) return;
+    const PwppDevParams &P = Bt.P;
+    const int NB = P.num_bins + 2;
+    for (int b = threadIdx.x; b < NB; b += kBlock) s_cnt[b] = 0;
+    for (int b = threadIdx.x; b <= NB; b += kBlock) s_seg[b] = Bt.cap_off[b];
+    fill_zone_table(P, s_zt);
+    __syncthreads();
+    const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
+    const float rnr_z_guard = (float)(-sensor_height - 0.8) + 1e-3f;
+    constexpr int kPer = kPtsPerBlock / kBlock;
+    unsigned pc[kPer];  // code | rank inside the workgroup << 16
+    PwppXyz pt[kPer];
+    unsigned dropped = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = first + j * kBlock + threadIdx.x;
+        unsigned code = PWPP_CODE_DROP;
+        pt[j].x = pt[j].y = pt[j].z = 0.0f;
+        if (i < fd.n) {
+            float x, y, z, w;
+            load_point(fd, i, x, y, z, w);
+            code = czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0, (Bt.debug & 128) != 0);
+            if (code == PWPP_CODE_DROP) ++dropped;
+            pt[j].x = x;
+            pt[j].y = y;
+            pt[j].z = z;
+        }
+        unsigned pos;
+        const unsigned old = wave_run_add(s_cnt, code, code != PWPP_CODE_DROP, pos);
+        pc[j] = code | ((old + pos) << 16);
+    }
+    __syncthreads();
+    unsigned *gcount = Bt.bin_count + (size_t)f * NB;
+    for (int b = threadIdx.x; b < NB; b += kBlock) {
+        const unsigned c = s_cnt[b];
+        s_cnt[b] = c ? atomicAdd(&gcount[b], c) : 0u;  // histogram and range reservation in one
+    }
+    dropped = wave_sum_u32(dropped);
+    if (lane_id() == 0 && dropped) atomicAdd((unsigned *)&Bt.results[f].n_dropped, dropped);
+    __syncthreads();
+    PwppXyz *sorted_xyz = Bt.sorted_xyz + fd.sbase;
+    int *sorted_idx = Bt.sorted_idx + fd.sbase;
+    bool over = false;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const unsigned code = pc[j] & 0xffffu;
+        if (code != PWPP_CODE_DROP) {
+            const unsigned seg = s_seg[code], cap = s_seg[code + 1] - seg;
+            const unsigned r = s_cnt[code] + (pc[j] >> 16);
+            if (r < cap) {
+                sorted_xyz[seg + r] = pt[j];
+                sorted_idx[seg + r] = first + j * kBlock + (int)threadIdx.x;
+            } else {
+                over = true;
+            }
+        }
+    }
+    if (__any(over) && lane_id() == 0) Bt.results[f].overflow = 1;
+}
+
+// ------------------------------------------------------------------------------------------
 // K2  exclusive scan of the per-frame histogram
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     __shared__ unsigned s_part[kBlock];
     const int f = blockIdx.x;
     const int NB = Bt.P.num_bins + 2;
-    const unsigned *cnt = Bt.bin_count + (size_t)f * NB;
+    unsigned *cnt = Bt.bin_count + (size_t)f * NB;
     unsigned *off = Bt.bin_off + (size_t)f * NB;
-    constexpr int kPer = (PWPP_MAX_BINS + 2 + kBlock - 1) / kBlock;
-    unsigned local[kPer];
-    unsigned sum = 0;
-    const int b0 = threadIdx.x * kPer;
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const int b = b0 + j;
-        local[j] = b < NB ? cnt[b] : 0u;
-        sum += local[j];
-    }
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    // Hillis-Steele over 256 partials
-    for (int o = 1; o < kBlock; o <<= 1) {
-        const unsigned v = threadIdx.x >= (unsigned)o ? s_part[threadIdx.x - o] : 0u;
+    if (Bt.cap_off) {  // one-pass binning: fixed segments; a bin never reports more points than its segment holds
+        for (int b = threadIdx.x; b < NB; b += kBlock) {
+            const unsigned seg = Bt.cap_off[b], cap = Bt.cap_off[b + 1] - seg;
+            off[b] = seg;
+            if (cnt[b] > cap) {
+                cnt[b] = cap;
+                Bt.results[f].overflow = 1;
+            }
+        }
         __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    unsigned run = s_part[threadIdx.x] - sum;  // exclusive
+    } else {
+        constexpr int kPer = (PWPP_MAX_BINS + 2 + kBlock - 1) / kBlock;
+        unsigned local[kPer];
+        unsigned sum = 0;
+        const int b0 = threadIdx.x * kPer;
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const int b = b0 + j;
-        if (b < NB) off[b] = run;
-        run += local[j];
+        for (int j = 0; j < kPer; ++j) {
+            const int b = b0 + j;
+            local[j] = b < NB ? cnt[b] : 0u;
+            sum += local[j];
+        }
+        s_part[threadIdx.x] = sum;
+        __syncthreads();
+        // Hillis-Steele over 256 partials
+        for (int o = 1; o < kBlock; o <<= 1) {
+            const unsigned v = threadIdx.x >= (unsigned)o ? s_part[threadIdx.x - o] : 0u;
+            __syncthreads();
+            s_part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        unsigned run = s_part[threadIdx.x] - sum;  // exclusive
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int b = b0 + j;
+            if (b < NB) off[b] = run;
+            run += local[j];
+        }
     }
     if (threadIdx.x == 0) {
         Bt.results[f].n_rnr = (int)cnt[Bt.P.num_bins];
@@ -378,8 +468,8 @@ __global__ __launch_bounds__(kBlock) void k_czm_scatter(PwppBatch Bt) {
     }
     __syncthreads();
     const unsigned *off = Bt.bin_off + (size_t)f * NB;
-    PwppXyz *sorted_xyz = Bt.sorted_xyz + fd.base;
-    int *sorted_idx = Bt.sorted_idx + fd.base;
+    PwppXyz *sorted_xyz = Bt.sorted_xyz + fd.sbase;
+    int *sorted_idx = Bt.sorted_idx + fd.sbase;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         if (code[j] != PWPP_CODE_DROP) {
@@ -1065,11 +1155,11 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt) {
     const unsigned da = Bt.dst_a[(size_t)f * NB + seg];
     const bool whole = seg >= B || (uint64_t)n < P.min_pts;
     if (whole) {
-        const int *src = Bt.sorted_idx + fd.base + off;
+        const int *src = Bt.sorted_idx + fd.sbase + off;
         for (unsigned i = threadIdx.x; i < n; i += kEmitBlock) out[da + i] = src[i];
         return;
     }
-    const int *src = Bt.plist + fd.base + off;
+    const int *src = Bt.plist + fd.sbase + off;
     const unsigned ng = (unsigned)Bt.recs[(size_t)f * B + seg].n_ground;
     const unsigned db = Bt.dst_b[(size_t)f * NB + seg];
     for (unsigned i0 = threadIdx.x; i0 < n; i0 += 4 * kEmitBlock) {  // four loads in flight per thread
@@ -1125,11 +1215,18 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     const int NB = B.P.num_bins + 2;
     const unsigned gx = (unsigned)((B.max_n + kPtsPerBlock - 1) / kPtsPerBlock);
     if (ev) (void)hipEventRecord(ev[0], stream);
-    if (gx > 0) hipLaunchKernelGGL(k_czm_bin, dim3(gx, F), dim3(kBlock), 0, stream, B);
-    if (ev) (void)hipEventRecord(ev[1], stream);
-    hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
-    if (ev) (void)hipEventRecord(ev[2], stream);
-    if (gx > 0) hipLaunchKernelGGL(k_czm_scatter, dim3(gx, F), dim3(kBlock), 0, stream, B);
+    if (B.cap_off) {  // one-pass binning (fixed bin segments)
+        if (gx > 0) hipLaunchKernelGGL(k_czm_bin_scatter, dim3(gx, F), dim3(kBlock), 0, stream, B);
+        if (ev) (void)hipEventRecord(ev[1], stream);
+        hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
+        if (ev) (void)hipEventRecord(ev[2], stream);
+    } else {
+        if (gx > 0) hipLaunchKernelGGL(k_czm_bin, dim3(gx, F), dim3(kBlock), 0, stream, B);
+        if (ev) (void)hipEventRecord(ev[1], stream);
+        hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
+        if (ev) (void)hipEventRecord(ev[2], stream);
+        if (gx > 0) hipLaunchKernelGGL(k_czm_scatter, dim3(gx, F), dim3(kBlock), 0, stream, B);
+    }
     const int frc = pwpp_launch_fit(batch, stream, ev ? ev + 3 : nullptr, aux, aux_fork, aux_join);  // records ev[3..9]
     if (frc) return frc;
     if (B.P.min_pts == 0)

@@ -96,6 +96,7 @@ def load():
         L.pwpp_get_kernel_profile.argtypes = [vp, vp, vp]
         L.pwpp_reset_kernel_profile.argtypes = [vp]
         L.pwpp_get_fxp_shift.argtypes = [vp]
+        L.pwpp_get_one_pass_stats.argtypes = [vp, vp, vp]
         L.pwpp_kernel_name.argtypes = [ci]
         _lib = L
     return _lib
@@ -308,3 +309,9 @@ class Handle:
 
     def fxp_shift(self):
         return self._L.pwpp_get_fxp_shift(self._h)
+
+    def one_pass_stats(self):
+        """(batches launched with one-pass binning, batches redone on the two-pass path after an overflow)"""
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._L.pwpp_get_one_pass_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)

@@ -373,3 +373,43 @@ def test_cpp_class_demo_program(kitti, golden, tmp_path):
         height = float(re.search(r"height: ([-0-9.]+)", line).group(1))
         assert [ng, nn, npat] == list(golden["f32/seq/%d/counts" % k])
         assert abs(height - golden["f32/seq/%d/state" % k][0]) < 1e-4
+
+
+def test_one_pass_binning_and_its_overflow_fallback(kitti, oracle, monkeypatch):
+    """Batches of independent frames bin in one pass into fixed bin segments (k_czm_bin_scatter).
+    (1) the default capacities hold KITTI frames: the one-pass path is taken and nothing is redone;
+    (2) with absurdly small segments every frame overflows: the batch is redone on the exact
+        two-pass path, later batches skip the one-pass attempt for a while; results are the oracle's
+        either way;
+    (3) a cloud with most points in one sector overflows the default capacities, same fallback."""
+    frames = [kitti[i % 6] for i in range(7)]
+    refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(p) for p in frames[:6]]
+    h = pwpp_hip.Handle()
+    h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+    for i, pts in enumerate(frames):
+        assert_frame_equal(h, i, refs[i % 6], pts.shape[0])
+    assert h.one_pass_stats() == (1, 0)
+    # (3) 70 % of a frame's points squeezed into a 10-degree wedge (still a valid cloud)
+    rng = np.random.default_rng(5)
+    wedge = kitti[0].copy()
+    sel = rng.random(wedge.shape[0]) < 0.7
+    r = np.hypot(wedge[sel, 0], wedge[sel, 1])
+    a = rng.uniform(0.1, 0.27, sel.sum())
+    wedge[sel, 0] = (r * np.cos(a)).astype(np.float32)
+    wedge[sel, 1] = (r * np.sin(a)).astype(np.float32)
+    odd = [wedge, kitti[1], kitti[2], wedge, kitti[3]]
+    h.estimate_ground_batch(odd, mode=pwpp_hip.MODE_FRESH)
+    for i, pts in enumerate(odd):
+        assert_frame_equal(h, i, ol.Estimator(oracle, arith=ol.ARITH_FXP).run(pts), pts.shape[0])
+    assert h.one_pass_stats() == (2, 1)
+    h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)  # hold-off: straight to the two-pass path
+    for i, pts in enumerate(frames):
+        assert_frame_equal(h, i, refs[i % 6], pts.shape[0])
+    assert h.one_pass_stats() == (2, 1)
+    # (2)
+    monkeypatch.setenv("PWPP_ONE_PASS_SCALE", "0.05")
+    h2 = pwpp_hip.Handle()
+    h2.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+    for i, pts in enumerate(frames):
+        assert_frame_equal(h2, i, refs[i % 6], pts.shape[0])
+    assert h2.one_pass_stats() == (1, 1)
