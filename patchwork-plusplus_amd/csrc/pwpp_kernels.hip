@@ -259,13 +259,14 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
 // frame's overflow flag (points beyond the segment are not written); the host then redoes the
 // batch on the exact two-pass path, so the result never depends on the capacities.
 // ------------------------------------------------------------------------------------------
+constexpr int kOnePassPts = 1024;  // points per workgroup of K1'
 __global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt) {
     __shared__ unsigned s_cnt[PWPP_MAX_BINS + 2];     // points of this workgroup per bin, then its first slot in the bin
     __shared__ unsigned s_seg[PWPP_MAX_BINS + 3];     // segment starts
     __shared__ float4 s_zt[8];
     const int f = blockIdx.y;
     const PwppFrameDesc fd = Bt.frames[f];
-    const int first = blockIdx.x * kPtsPerBlock;
+    const int first = blockIdx.x * kOnePassPts;
     if (first >= fd.n) return;
     const PwppDevParams &P = Bt.P;
     const int NB = P.num_bins + 2;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt) {
     __syncthreads();
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const float rnr_z_guard = (float)(-sensor_height - 0.8) + 1e-3f;
-    constexpr int kPer = kPtsPerBlock / kBlock;
+    constexpr int kPer = kOnePassPts / kBlock;
     unsigned pc[kPer];  // code | rank inside the workgroup << 16
     PwppXyz pt[kPer];
     unsigned dropped = 0;
@@ -1216,7 +1217,8 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     const unsigned gx = (unsigned)((B.max_n + kPtsPerBlock - 1) / kPtsPerBlock);
     if (ev) (void)hipEventRecord(ev[0], stream);
     if (B.cap_off) {  // one-pass binning (fixed bin segments)
-        if (gx > 0) hipLaunchKernelGGL(k_czm_bin_scatter, dim3(gx, F), dim3(kBlock), 0, stream, B);
+        const unsigned gx1 = (unsigned)((B.max_n + kOnePassPts - 1) / kOnePassPts);
+        if (gx1 > 0) hipLaunchKernelGGL(k_czm_bin_scatter, dim3(gx1, F), dim3(kBlock), 0, stream, B);
         if (ev) (void)hipEventRecord(ev[1], stream);
         hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
         if (ev) (void)hipEventRecord(ev[2], stream);
