@@ -88,7 +88,11 @@ struct Row {
             case 3: tl = PWPP_DPP(lo, PWPP_DPP_MIR); th = PWPP_DPP(hi, PWPP_DPP_MIR); break;
             default: tl = __builtin_amdgcn_ds_swizzle(lo, PWPP_SWZ16); th = __builtin_amdgcn_ds_swizzle(hi, PWPP_SWZ16); break;
         }
-        return v + (long long)(((unsigned long long)(unsigned)th << 32) | (unsigned long long)(unsigned)tl);
+        // the two moved halves form the register pair of ONE 64-bit add (v_lshl_add_u64); written with
+        // shifts and ORs the compiler splits it into two 64-bit adds plus a move
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const v2i pair = {tl, th};
+        return v + __builtin_bit_cast(long long, pair);
     }
     __device__ static __forceinline__ long long sum_i64(long long v) {
         v = step64(v, 0);

@@ -64,9 +64,10 @@ def load():
     """Load libpwpp_hip.so (raises if it has not been built -- there is no fallback)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise PwppError("%s not built; run __graft_entry__.build() or make -C patchwork-plusplus_amd" % LIB_PATH)
-        L = ctypes.CDLL(LIB_PATH)
+        path = os.environ.get("PWPP_LIB_PATH", LIB_PATH)  # A/B runs of two builds (tools/ab_bench.sh)
+        if not os.path.exists(path):
+            raise PwppError("%s not built; run __graft_entry__.build() or make -C patchwork-plusplus_amd" % path)
+        L = ctypes.CDLL(path)
         L.pwpp_last_error.restype = ctypes.c_char_p
         L.pwpp_kernel_name.restype = ctypes.c_char_p
         L.pwpp_get_height.restype = ctypes.c_double
