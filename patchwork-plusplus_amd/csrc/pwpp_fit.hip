@@ -1667,10 +1667,22 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     // whatever is larger than the last entry goes to the workgroup-per-patch kernel.
     // PWPP_FIT_PLAN overrides the default for tuning experiments.
     const char *plan = getenv("PWPP_FIT_PLAN");
-    // throughput plan for batches (64 / 2 patches per wave, lane-parallel solves); for a handful of
-    // frames the chain latency of a patch is what counts: one prefetching wave per patch, every patch
-    // at once (198 us per KITTI frame; with the > 511-point bins on k_fit_stream instead: 225 us)
-    if (!plan) plan = F <= PWPP_LATENCY_PLAN_MAX_FRAMES ? PWPP_LATENCY_FIT_PLAN : PWPP_DEFAULT_FIT_PLAN;
+    // The right granularity depends on how much work there is to spread over 1024 SIMDs (measured with
+    // tools/plan_by_frames.sh on KITTI frames; "frames" below = points of the batch / 125 000):
+    //   <= 48   one prefetching wave per patch, every patch at once      (chain latency is what counts)
+    //   <= 320  16 small patches per wave; big bins one wave each         (8 -> 32 waves per frame)
+    //   <= 448  16 small patches per wave; big bins two per wave
+    //   <= 640  32 small patches per wave; big bins two per wave
+    //   more    64 small patches per wave; big bins two per wave          (fewest solve instances)
+    // e.g. 32 frames: 93 k frames/s instead of 44 k with the last plan; 256 frames: 237 k instead of 208 k.
+    if (!plan) {
+        const double eff = (double)F * (double)B.max_n / 125000.0;
+        plan = eff <= 48.0 ? PWPP_LATENCY_FIT_PLAN
+             : eff <= 320.0 ? "W16.16:1023,S64:65535"
+             : eff <= 448.0 ? "W16.16:1023,W64.2:65535"
+             : eff <= 640.0 ? "W16.32:1023,W64.2:65535"
+                            : PWPP_DEFAULT_FIT_PLAN;
+    }
     int k_lo = 0, slot = 0;
     unsigned n_lo = 1;
     // PWPP_FIT_CONCURRENT=1: the second size class runs on the aux stream beside the first (+3.5 % on

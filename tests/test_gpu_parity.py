@@ -140,7 +140,7 @@ PARAM_VARIANTS = [
 
 
 @pytest.mark.parametrize("variant", PARAM_VARIANTS, ids=lambda v: ",".join("%s=%s" % kv for kv in v.items()))
-def test_parameter_variants(kitti, oracle, variant):
+def test_parameter_variants(kitti, oracle, variant, monkeypatch):
     p = pwpp_hip.default_params()
     for k, v in variant.items():
         if k == "sectors":
@@ -163,14 +163,19 @@ def test_parameter_variants(kitti, oracle, variant):
     for pts in (kitti[0], syn, kitti[4]):
         h.estimate_ground(pts)
         assert_frame_equal(h, 0, est.run(pts), pts.shape[0], state_index=0)
-    # the same frames as one batch: more than four frames take the throughput plan (k_fit_w64 kernels),
-    # a single frame the latency plan (k_fit_srows + k_fit_stream)
+    # the same frames as one batch (one-pass binning), under the plan the launcher picks for this
+    # little work (one wave per patch) and under the plans of bigger batches (k_fit_w64 kernels)
     frames = [kitti[1], syn, kitti[3], kitti[0], kitti[5], syn]
+    refs = [ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(pts) for pts in frames]
     hb = pwpp_hip.Handle(p)
-    hb.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
-    for i, pts in enumerate(frames):
-        ref = ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(pts)
-        assert_frame_equal(hb, i, ref, pts.shape[0])
+    for plan in (None, "W16:1023,W64.2:65535", "W16.16:1023,S64:65535"):
+        if plan is None:
+            monkeypatch.delenv("PWPP_FIT_PLAN", raising=False)
+        else:
+            monkeypatch.setenv("PWPP_FIT_PLAN", plan)
+        hb.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+        for i, pts in enumerate(frames):
+            assert_frame_equal(hb, i, refs[i], pts.shape[0])
 
 
 def test_layouts_and_three_columns(kitti, oracle):
