@@ -107,7 +107,12 @@ typedef enum pwpp_decision {
 
 enum { PWPP_LAYOUT_ROW_MAJOR = 0, /* (n, cols) C-order: np.fromfile(..).reshape(-1,4), python/examples/demo_visualize.py:10-14 */
        PWPP_LAYOUT_COL_MAJOR = 1  /* Eigen::MatrixXf default storage: cols planes of n floats (patchworkpp.h:152) */ };
-enum { PWPP_MEM_HOST = 0, PWPP_MEM_DEVICE = 1 };
+enum { PWPP_MEM_HOST = 0,         /* pageable or pinned host memory; the call returns when the results are ready */
+       PWPP_MEM_DEVICE = 1,       /* device memory; asynchronous */
+       PWPP_MEM_HOST_PINNED = 2   /* page-locked host memory (pwpp_host_alloc / hipHostMalloc) that stays valid and
+                                     unchanged until pwpp_synchronize(): the copies and the launches are only
+                                     enqueued, so a second handle can overlap its own transfers and kernels
+                                     (double-buffered ingest) */ };
 enum { PWPP_MODE_FRESH = 0,   /* every frame starts from the handle's Params (= a fresh PatchWorkpp object per frame) */
        PWPP_MODE_STREAMS = 1  /* frame i belongs to stream i and reads+updates that stream's adaptive state
                                  (= one long-lived PatchWorkpp object per stream, demo_sequential.cpp:54-67) */ };
@@ -135,7 +140,7 @@ int pwpp_estimate_ground(pwpp_handle *h, const float *points, int n, int cols, i
  * memory according to `mem`), n[i] its point count.  PWPP_MODE_FRESH: each frame is
  * processed with fresh state.  PWPP_MODE_STREAMS: frames <= streams configured with
  * pwpp_set_num_streams(); frame i continues stream i.  Asynchronous when mem is
- * PWPP_MEM_DEVICE: call pwpp_synchronize() before reading results. */
+ * PWPP_MEM_DEVICE or PWPP_MEM_HOST_PINNED: call pwpp_synchronize() before reading results. */
 int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const int32_t *n, int frames,
                                int cols, int layout, int mem, int mode);
 int pwpp_synchronize(pwpp_handle *h);

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libpwpp_hip.so")
 LAYOUT_ROW_MAJOR, LAYOUT_COL_MAJOR = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 MODE_FRESH, MODE_STREAMS = 0, 1
+MEM_HOST_PINNED = 2
 NUM_KERNELS = 11
 
 DEC_NAMES = {1: "not_upright", 2: "far_ground", 3: "heading", 4: "ground", 5: "tgr_reject", 6: "tgr_revert"}
@@ -186,6 +187,16 @@ class Handle:
         ns = (ctypes.c_int32 * len(frames))(*[f.shape[0] for f in frames])
         self._check(self._L.pwpp_estimate_ground_batch(self._h, ptrs, ns, len(frames), cols, LAYOUT_ROW_MAJOR,
                                                        MEM_HOST, mode))
+
+    def submit_pinned_batch(self, frames, mode=MODE_FRESH):
+        """Frames in page-locked host memory (pinned_empty): copies and launches are only enqueued;
+        the arrays must stay untouched until synchronize() / a getter."""
+        cols = frames[0].shape[1]
+        ptrs = (ctypes.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+        ns = (ctypes.c_int32 * len(frames))(*[f.shape[0] for f in frames])
+        self._keep = (ptrs, ns, frames)
+        self._check(self._L.pwpp_estimate_ground_batch(self._h, ptrs, ns, len(frames), cols, LAYOUT_ROW_MAJOR,
+                                                       MEM_HOST_PINNED, mode))
 
     def estimate_ground_batch_device(self, ptrs, ns, cols=4, layout=LAYOUT_ROW_MAJOR, mode=MODE_FRESH):
         """Device-resident frames: ptrs = device addresses (ints), asynchronous until synchronize()."""

@@ -352,6 +352,35 @@ def test_ingest_pinned_buffers_and_bulk_index_copy(kitti):
     pwpp_hip.pinned_free(out)
 
 
+def test_ingest_async_pinned_slab_two_handles(kitti, oracle):
+    """PWPP_MEM_HOST_PINNED is asynchronous; frames that lie back to back in one
+    page-locked slab go over in merged copies; two handles (= two streams) work on two chunks at once.
+    Results are the oracle's."""
+    chunks = [[0, 1, 2, 3, 4, 5, 0], [5, 4, 3, 2, 1]]   # 7 frames: one-pass binning; 5 frames too
+    slabs, views = [], []
+    for ids in chunks:
+        rows = sum(kitti[k].shape[0] for k in ids)
+        slab = pwpp_hip.pinned_empty((rows, 4))
+        at, fr = 0, []
+        for k in ids:
+            n = kitti[k].shape[0]
+            slab[at:at + n] = kitti[k]
+            fr.append(slab[at:at + n])
+            at += n
+        slabs.append(slab)
+        views.append(fr)
+    ha, hb = pwpp_hip.Handle(), pwpp_hip.Handle()
+    ha.submit_pinned_batch(views[0])   # returns at once
+    hb.submit_pinned_batch(views[1])
+    refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(kitti[k]) for k in range(6)]
+    for h, ids in ((ha, chunks[0]), (hb, chunks[1])):
+        h.synchronize()
+        for i, k in enumerate(ids):
+            assert_frame_equal(h, i, refs[k], kitti[k].shape[0])
+    for s_ in slabs:
+        pwpp_hip.pinned_free(s_)
+
+
 def test_cpp_class_demo_program(kitti, golden, tmp_path):
     """The C++ mirror of patchwork::PatchWorkpp through a compiled program that follows the
     reference's demo_sequential.cpp: one object over frames 0..2, counts and sensor height as the
