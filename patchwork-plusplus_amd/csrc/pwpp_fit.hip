@@ -1499,6 +1499,250 @@ __device__ __forceinline__ double point_to_plane(float nx, float ny, float nz, d
     return nx * p.x + ny * p.y + nz * p.z + d;
 }
 
+// ------------------------------------------------------------------------------------------
+// k_fit_brows: FOUR waves per patch -- the latency flavour of k_fit_srows<64>.  With a handful of
+// frames in flight the run time of the fit stage is the chain of its largest patch (~5000 points:
+// 10 chunks per pass, 6 passes, 5 solves on one wave = 118 us per KITTI frame).  Here the four
+// waves of a workgroup stream every fourth chunk of the same patch (next chunk prefetched), add
+// their integer moments through LDS (exact, so the split over waves changes nothing) and all
+// solve the same 3x3 problem; the lowest points are selected per wave and merged.
+// ------------------------------------------------------------------------------------------
+struct BRowShared {
+    long long mom[kWaves][10];
+    unsigned keys[kWaves][PWPP_MAX_LPR];  // every wave's smallest keys, ascending
+    unsigned dropped[kWaves];
+    int elig[kWaves];
+    unsigned cnt_g, cnt_ng;
+    FitShared fs;  // for block_lpr, the exact fall-back of the lowest-point selection
+};
+
+// LPR (ref :84-103) with the points of the patch dealt out to the four waves chunk by chunk
+__device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsigned nchunk, bool use_cutoff, double cutoff, int num_lpr) {
+    const unsigned INF = 0xFFFFFFFFu;
+    const int wv = wave_id(), ln = lane_id();
+    unsigned k0 = INF, k1 = INF, k2 = INF, k3 = INF, dropped = INF;
+    int elig = 0;
+    for (unsigned c = (unsigned)wv; c < nchunk; c += kWaves) {
+        ChunkPts cp;
+        load_chunk<64>(cp, pts, n, c);
+        const unsigned act = chunk_act(cp);
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
+            unsigned x = e ? z_key(cp.lp.z[k]) : INF;
+            ce(k0, x);
+            ce(k1, x);
+            ce(k2, x);
+            ce(k3, x);
+            dropped = x < dropped ? x : dropped;
+            elig += e ? 1 : 0;
+        }
+    }
+    const int total_w = Row<64>::sum_i32(elig);
+    const int keff_w = total_w < num_lpr ? total_w : num_lpr;
+    for (int r = 0; r < keff_w; ++r) {  // this wave's keff_w smallest kept keys, ascending (wave-uniform trip count)
+        const unsigned m = Row<64>::min_u32(k0);
+        if (ln == 0) sh.keys[wv][r] = m;
+        const int lowest = __ffsll((long long)__ballot(k0 == m)) - 1;
+        if (ln == lowest) {
+            k0 = k1;
+            k1 = k2;
+            k2 = k3;
+            k3 = INF;
+        }
+    }
+    const unsigned dmin = Row<64>::min_u32(dropped);
+    if (ln == 0) {
+        sh.dropped[wv] = dmin;
+        sh.elig[wv] = total_w;
+    }
+    __syncthreads();
+    // merge the four ascending lists (every thread the same way)
+    int total = 0;
+    unsigned dall = INF;
+    int listed[kWaves], pos[kWaves];
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        total += sh.elig[w];
+        dall = sh.dropped[w] < dall ? sh.dropped[w] : dall;
+        listed[w] = sh.elig[w] < num_lpr ? sh.elig[w] : num_lpr;
+        pos[w] = 0;
+    }
+    const int keff = total < num_lpr ? total : num_lpr;
+    double sum = 0.0;
+    unsigned T = 0;
+    for (int r = 0; r < keff; ++r) {
+        unsigned best = INF;
+        int bw = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const unsigned head = pos[w] < listed[w] ? sh.keys[w][pos[w]] : INF;
+            if (head < best) {
+                best = head;
+                bw = w;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) pos[w] += (w == bw) ? 1 : 0;
+        sum += (double)key_z(best);
+        T = best;
+    }
+    __syncthreads();  // the lists are free again
+    if (keff > 0 && dall < T) return block_lpr(sh.fs, pts, n, use_cutoff, cutoff, num_lpr);  // a lane held > 4 of the lowest: exact path
+    return keff ? sum / (double)keff : 0.0;  // ref :103
+}
+
+__global__ __launch_bounds__(kBlock, 3) void k_fit_brows(PwppBatch Bt, int b_lo, int b_hi) {
+    __shared__ BRowShared sh;
+    const int f = blockIdx.x;
+    const PwppDevParams &P = Bt.P;
+    const int NB = P.num_bins + 2;
+    const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
+    const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
+    if (cbeg + blockIdx.y >= cend) return;            // workgroup-uniform
+    const unsigned slot = cend - 1u - blockIdx.y;     // largest patches first
+    const int wv = wave_id(), ln = lane_id();
+    const int bin = (int)Bt.cls_list[(size_t)f * P.num_bins + slot];
+    const unsigned n = Bt.bin_count[(size_t)f * NB + bin];
+    const PwppFrameDesc fd = Bt.frames[f];
+    const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
+    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + off);
+    int *plist = Bt.plist + fd.sbase + off;
+    const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
+    const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
+    const double cutoff = P.margin * sensor_height;
+    const bool use_cutoff = zone == 0;
+    const float qscale = (float)(1 << P.fxp_shift);
+    const unsigned nchunk = (n + 511u) / 512u;
+
+    PlaneFit pl;
+    pl.nx = pl.ny = pl.nz = 0.0f;
+    pl.mean[0] = pl.mean[1] = pl.mean[2] = 0.0f;
+    pl.sv[0] = pl.sv[1] = pl.sv[2] = 0.0f;
+    pl.d = 0.0;
+    double lpr = 0.0;
+    bool lpr_valid = false;
+    int kind = (P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED;  // everything below is workgroup-uniform
+    int it = 0;
+    if (threadIdx.x == 0) {
+        sh.cnt_g = 0;
+        sh.cnt_ng = 0;
+    }
+    __syncthreads();
+
+    for (int guard = 0; guard < 4 * P.num_iter + 8 && kind != ST_DONE; ++guard) {
+        if ((kind == ST_VPF || kind == ST_SEED) && !lpr_valid) {
+            lpr = brow_lpr(sh, pts, n, nchunk, use_cutoff, cutoff, P.num_lpr);
+            lpr_valid = true;
+        }
+        const double thr_seed = lpr + ((kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds);
+        const bool last = kind == ST_ITER && it == P.num_iter - 1;
+        Moments m;
+        m.clear();
+        ChunkMoments cm;
+        cm.clear();
+        unsigned done = 0;
+        ChunkPts cp;
+        load_chunk<64>(cp, pts, n, (unsigned)wv);
+        for (unsigned c = (unsigned)wv; c < nchunk; c += kWaves) {
+            ChunkPts nx;  // this wave's next chunk is in flight while this one is accumulated
+            load_chunk<64>(nx, pts, n, c + kWaves);
+            int w[kPPT];
+            if (last) load_chunk_idx<64>(w, pts, n, c);
+            const unsigned gmask = lane_stage_accum(cp.lp, chunk_act(cp), kind, thr_seed, P.th_dist, pl, qscale, cm);
+            if (++done % kFlushChunks == 0u) {
+                cm.flush_into(m);
+                cm.clear();
+            }
+            if (last) {  // the split is written BEFORE the plane is replaced (ref :529-541)
+                const unsigned ngm = cp.valid & ~gmask;
+                unsigned tg, tn;
+                unsigned bg = Row<64>::excl_scan((unsigned)__popc(gmask), tg);
+                unsigned bn = Row<64>::excl_scan((unsigned)__popc(ngm), tn);
+                unsigned base_g = 0, base_n = 0;
+                if (ln == 0) {
+                    base_g = atomicAdd(&sh.cnt_g, tg);
+                    base_n = atomicAdd(&sh.cnt_ng, tn);
+                }
+                bg += (unsigned)__builtin_amdgcn_readfirstlane((int)base_g);
+                bn += (unsigned)__builtin_amdgcn_readfirstlane((int)base_n);
+#pragma unroll
+                for (int k = 0; k < kPPT; ++k) {
+                    if (gmask >> k & 1u)
+                        plist[bg++] = w[k];
+                    else if (ngm >> k & 1u)
+                        plist[n - 1u - (bn++)] = w[k];
+                }
+            }
+            cp = nx;
+        }
+        cm.flush_into(m);
+        {   // the wave's sums -> LDS -> totals of the patch (every thread)
+            long long v[10];
+            v[0] = Row<64>::sum_i64(m.n);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[1 + k] = Row<64>::sum_i64(m.s1[k]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v[4 + k] = Row<64>::sum_i64(m.s2[k]);
+            if (ln < 10) {
+                long long mine = v[0];
+#pragma unroll
+                for (int k = 1; k < 10; ++k) mine = ln == k ? v[k] : mine;
+                sh.mom[wv][ln] = mine;
+            }
+        }
+        __syncthreads();
+        long long tot[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            long long t = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < kWaves; ++w2) t += sh.mom[w2][k];
+            tot[k] = t;
+        }
+        __syncthreads();
+        const long long cnt = tot[0];
+        if (cnt > 0) {  // empty: ref :49
+            const long long s1[3] = {tot[1], tot[2], tot[3]};
+            __int128 s2[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s2[k] = (__int128)tot[4 + k];  // <= 65535 points: fits int64
+            plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);
+        }
+        if (kind == ST_VPF) {
+            const bool vertical = (double)pl.nz < P.uprightness_thr;  // ref :489
+            if (vertical) {
+                int any = 0;
+                for (unsigned c = (unsigned)wv; c < nchunk; c += kWaves) {
+                    ChunkPts cs2;
+                    load_chunk<64>(cs2, pts, n, c);
+                    const unsigned hit = lane_strip(cs2.lp, chunk_act(cs2), true, pl, P.th_dist_v);
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k)
+                        if (hit >> k & 1u) strip_point(pts, c * 512u + (unsigned)k * 64u + (unsigned)ln);
+                    any |= hit != 0u;
+                }
+                if (__syncthreads_or(any)) lpr_valid = false;  // the working set changed (and the marks are visible)
+            }
+            ++it;
+            if (!vertical || it >= P.num_iter) {
+                kind = ST_SEED;
+                it = 0;
+            }
+        } else if (kind == ST_SEED) {
+            kind = (cnt == 0 && P.enable_RVPF != 0 && zone != 0) ? ST_LAZY : ST_ITER;
+        } else if (kind == ST_LAZY) {
+            kind = ST_ITER;
+        } else if (kind == ST_ITER) {
+            if (last) {
+                if (threadIdx.x == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt);
+                kind = ST_DONE;
+            }
+            ++it;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
     __shared__ FitShared sh;
     const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
@@ -1645,11 +1889,8 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
 
 // launches of K4; ev (optional) = 7 events recorded around up to six launches
 #define PWPP_DEFAULT_FIT_PLAN "W16:1023,W64.2:65535"
-#define PWPP_LATENCY_FIT_PLAN "S64:65535"
-#define PWPP_LATENCY_PLAN_MAX_FRAMES 4
-// `aux` (optional): a second stream + two events.  For a handful of frames the fit kernels are
-// latency-bound chains; the workgroup kernel for the big bins then runs CONCURRENTLY with the
-// row kernels (fork after K3, join before K5) instead of after them.
+#define PWPP_LATENCY_FIT_PLAN "B64:65535"
+// `aux` (optional): a second stream + two events, for PWPP_FIT_CONCURRENT (classes of a plan side by side).
 extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
                                hipEvent_t aux_fork, hipEvent_t aux_join) {
     const PwppBatch &B = *batch;
@@ -1669,15 +1910,18 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     const char *plan = getenv("PWPP_FIT_PLAN");
     // The right granularity depends on how much work there is to spread over 1024 SIMDs (measured with
     // tools/plan_by_frames.sh on KITTI frames; "frames" below = points of the batch / 125 000):
-    //   <= 48   one prefetching wave per patch, every patch at once      (chain latency is what counts)
+    //   <= 6    FOUR waves per patch, every patch at once (k_fit_brows)    (chain latency is what counts)
+    //   <= 48   one prefetching wave per patch, every patch at once
     //   <= 320  16 small patches per wave; big bins one wave each         (8 -> 32 waves per frame)
     //   <= 448  16 small patches per wave; big bins two per wave
     //   <= 640  32 small patches per wave; big bins two per wave
     //   more    64 small patches per wave; big bins two per wave          (fewest solve instances)
-    // e.g. 32 frames: 93 k frames/s instead of 44 k with the last plan; 256 frames: 237 k instead of 208 k.
+    // e.g. 1 frame: 0.153 ms instead of 0.196 with the second plan; 32 frames: 93 k frames/s instead of
+    // 44 k with the last plan; 256 frames: 237 k instead of 208 k.
     if (!plan) {
         const double eff = (double)F * (double)B.max_n / 125000.0;
-        plan = eff <= 48.0 ? PWPP_LATENCY_FIT_PLAN
+        plan = eff <= 6.0 ? PWPP_LATENCY_FIT_PLAN
+             : eff <= 48.0 ? "S64:65535"
              : eff <= 320.0 ? "W16.16:1023,S64:65535"
              : eff <= 448.0 ? "W16.16:1023,W64.2:65535"
              : eff <= 640.0 ? "W16.32:1023,W64.2:65535"
@@ -1685,11 +1929,12 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     }
     int k_lo = 0, slot = 0;
     unsigned n_lo = 1;
-    // PWPP_FIT_CONCURRENT=1: the second size class runs on the aux stream beside the first (+3.5 % on
-    // the 1024-frame batch; off by default: the per-kernel times bench.py reports lose their meaning)
-    const bool concurrent = aux != nullptr && !ev && F > PWPP_LATENCY_PLAN_MAX_FRAMES && getenv("PWPP_FIT_CONCURRENT") != nullptr;
-    const bool fork = concurrent || (aux != nullptr && !ev && F <= PWPP_LATENCY_PLAN_MAX_FRAMES && !getenv("PWPP_FIT_PLAN"));
-    if (fork) {  // the big-bin kernel only depends on K3; its bucket range starts where the latency plan ends
+    // The classes of a plan are independent of each other: PWPP_FIT_CONCURRENT=1 runs the later ones on
+    // the aux stream beside the first (fork after K3, join before K5; +3.5 % on the 1024-frame batch;
+    // off by default: the per-kernel times bench.py reports would lose their meaning).
+    const bool concurrent = aux != nullptr && !ev && getenv("PWPP_FIT_CONCURRENT") != nullptr;
+    const bool fork = concurrent;
+    if (fork) {  // every class only depends on K3
         (void)hipEventRecord(aux_fork, stream);
         (void)hipStreamWaitEvent(aux, aux_fork, 0);
     }
@@ -1717,6 +1962,7 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
             else if (mode == 'S' && g == 16) hipLaunchKernelGGL(k_fit_srows<16>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'S' && g == 32) hipLaunchKernelGGL(k_fit_srows<32>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'S' && g == 64) hipLaunchKernelGGL(k_fit_srows<64>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            else if (mode == 'B') hipLaunchKernelGGL(k_fit_brows, dim3(F, patches), dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'W') {  // "W<lanes per patch>.<patches per wave>"
                 if (pw == 0) pw = 64;
                 const dim3 wgrid(F, (patches + (unsigned)pw * kWaves - 1) / ((unsigned)pw * kWaves));

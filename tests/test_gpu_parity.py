@@ -316,7 +316,8 @@ def test_points_on_bin_boundaries(oracle):
 
 
 @pytest.mark.parametrize("plan", ["L16:127,L32:255,L64:511,S64:65535", "S8:63,S16:255,S32:1023,S64:4095", "S8:65535", "S64:65535",
-                                  "W16:65535", "W16:255,P16:2047,P64:65535", "P16:65535", "S16:100"])
+                                  "W16:65535", "W16:255,P16:2047,P64:65535", "P16:65535", "S16:100",
+                                  "W16.16:1023,W64.2:65535", "W16.32:511,W64.4:65535", "S64:255,B64:65535", "B64:65535"])
 def test_every_fit_kernel_variant(kitti, oracle, plan, monkeypatch):
     """All fit kernels (LDS-parked rows, streaming rows of every width, 64-patch waves, the phase
     kernels with one-lane-per-patch solves, the workgroup kernel for whatever exceeds the plan) produce the same bit-exact result: the integer plane-fit sums do
