@@ -621,7 +621,13 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     if ((rc = h->h_frames.ensure((size_t)frames))) return rc;
     if ((rc = h->h_base.ensure((size_t)frames + 1))) return rc;
     if ((rc = h->d_codes.ensure(tp))) return rc;
-    if ((rc = h->d_sorted_xyz.ensure(bin_slots + 16))) return rc;  // slack: load_chunk reads record 0 of a patch beyond its end
+    // (slack: load_chunk reads record 0 of a patch beyond its end)
+    if (one_pass && (h->d_sorted_xyz.ensure(bin_slots + 16) || h->d_sorted_idx.ensure(bin_slots) || h->d_plist.ensure(bin_slots))) {
+        one_pass = false;  // the big allocation failed after all (fragmentation): compact layout, two-pass binning
+        bin_slots = tp;
+        (void)hipGetLastError();
+    }
+    if ((rc = h->d_sorted_xyz.ensure(bin_slots + 16))) return rc;
     if ((rc = h->d_sorted_idx.ensure(bin_slots))) return rc;
     if ((rc = h->d_plist.ensure(bin_slots))) return rc;
     if ((rc = h->d_out.ensure(tp))) return rc;

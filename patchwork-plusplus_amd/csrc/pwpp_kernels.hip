@@ -357,16 +357,22 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
             local[j] = b < NB ? cnt[b] : 0u;
             sum += local[j];
         }
-        s_part[threadIdx.x] = sum;
-        __syncthreads();
-        // Hillis-Steele over 256 partials
-        for (int o = 1; o < kBlock; o <<= 1) {
-            const unsigned v = threadIdx.x >= (unsigned)o ? s_part[threadIdx.x - o] : 0u;
-            __syncthreads();
-            s_part[threadIdx.x] += v;
-            __syncthreads();
+        // inclusive scan inside the wave (shuffles), then the four wave totals through LDS: one barrier
+        // instead of the sixteen of a Hillis-Steele scan over 256 partials (a single frame waits for this)
+        unsigned incl = sum;
+        {
+            const int ln = lane_id();
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = (unsigned)__shfl_up((int)incl, o, 64);
+                if (ln >= o) incl += t;
+            }
+            if (ln == 63) s_part[wave_id()] = incl;
         }
-        unsigned run = s_part[threadIdx.x] - sum;  // exclusive
+        __syncthreads();
+        unsigned before = 0;
+        for (int w = 0; w < wave_id(); ++w) before += s_part[w];
+        unsigned run = before + incl - sum;  // exclusive
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
             const int b = b0 + j;
