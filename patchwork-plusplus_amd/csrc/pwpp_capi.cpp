@@ -153,6 +153,10 @@ struct pwpp_handle {
     int stream_hist_cap = 0, fresh_hist_cap = 0;
     DevBuf<PwppStateScalar> d_st_stream, d_st_fresh;
     DevBuf<double> d_hist_stream, d_hist_fresh;
+    // one-pass batches of stateful streams: the state of the streams before the batch, so that a redo after an
+    // overflow starts from it (the first attempt has already advanced sensor height, thresholds, histories)
+    DevBuf<PwppStateScalar> d_st_snap;
+    DevBuf<double> d_hist_snap;
 };
 
 namespace {
@@ -391,6 +395,11 @@ int finish_pending(pwpp_handle *h) {
         if (over) {
             ++h->one_pass_redone;
             h->one_pass_holdoff = 8;
+            if (h->mode == PWPP_MODE_STREAMS) {  // back to the streams' state before the first attempt
+                const size_t slab = (size_t)8 * (size_t)h->stream_hist_cap;
+                HIPCHK(hipMemcpyAsync(h->d_st_stream.p, h->d_st_snap.p, (size_t)h->frames * sizeof(PwppStateScalar), hipMemcpyDeviceToDevice, h->stream));
+                HIPCHK(hipMemcpyAsync(h->d_hist_stream.p, h->d_hist_snap.p, (size_t)h->frames * slab * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            }
             const int rc = launch_prepared(h, false);
             if (rc) return rc;
             h->pending = true;
@@ -549,6 +558,8 @@ int pwpp_destroy(pwpp_handle *h) {
     h->d_st_fresh.release();
     h->d_hist_stream.release();
     h->d_hist_fresh.release();
+    h->d_st_snap.release();
+    h->d_hist_snap.release();
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     for (int k = 0; k <= PWPP_NUM_KERNELS; ++k)
@@ -600,7 +611,7 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
         static const bool env_off = std::getenv("PWPP_NO_ONE_PASS") != nullptr;
         if (h->one_pass_holdoff > 0) {
             --h->one_pass_holdoff;
-        } else if (!env_off && mode == PWPP_MODE_FRESH && frames > 4 && max_n > 0) {
+        } else if (!env_off && frames > 4 && max_n > 0) {
             if (max_n > h->cap_max_n || 2 * (int64_t)max_n < h->cap_max_n) {
                 if ((rc = finish_pending(h))) return rc;
                 if ((rc = build_capacity_table(h, max_n))) return rc;
@@ -700,6 +711,13 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     h->cols = cols;
     h->layout = layout;
     if (one_pass) ++h->one_pass_batches;
+    if (one_pass && mode == PWPP_MODE_STREAMS) {  // stream i = frame i: keep what a redo must start from
+        const size_t slab = (size_t)8 * (size_t)h->stream_hist_cap;
+        if ((rc = h->d_st_snap.ensure((size_t)frames))) return rc;
+        if ((rc = h->d_hist_snap.ensure((size_t)frames * slab))) return rc;
+        HIPCHK(hipMemcpyAsync(h->d_st_snap.p, h->d_st_stream.p, (size_t)frames * sizeof(PwppStateScalar), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_hist_snap.p, h->d_hist_stream.p, (size_t)frames * slab * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
     if ((rc = launch_prepared(h, one_pass))) return rc;
     h->pending = true;
     h->have_results = false;

@@ -114,6 +114,34 @@ def test_multi_stream_lockstep(kitti, oracle):
             assert_frame_equal(h, s, ests[s].run(frames[s]), frames[s].shape[0], state_index=s)
 
 
+def test_multi_stream_one_pass_with_state_restore(kitti, oracle):
+    """Six stateful streams in lock-step take the one-pass binning.  In step 1 one stream gets a cloud
+    that overflows its bin segments: the batch is redone on the two-pass path FROM THE STATE BEFORE
+    THE STEP (the first attempt had already advanced sensor height, thresholds and histories of every
+    stream).  Every stream must keep following its own sequential oracle."""
+    S = 6
+    rng = np.random.default_rng(9)
+    wedge = kitti[2].copy()
+    sel = rng.random(wedge.shape[0]) < 0.7
+    r = np.hypot(wedge[sel, 0], wedge[sel, 1])
+    a = rng.uniform(0.1, 0.27, sel.sum())
+    wedge[sel, 0] = (r * np.cos(a)).astype(np.float32)
+    wedge[sel, 1] = (r * np.sin(a)).astype(np.float32)
+    h = pwpp_hip.Handle()
+    h.set_num_streams(S)
+    ests = [ol.Estimator(oracle, arith=ol.ARITH_FXP) for _ in range(S)]
+    redone = []
+    for t in range(12):   # (the hold-off after the overflow lasts 8 batches)
+        frames = [kitti[(s + t) % 6] for s in range(S)]
+        if t == 1:
+            frames[3] = wedge
+        h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_STREAMS)
+        for s in range(S):
+            assert_frame_equal(h, s, ests[s].run(frames[s]), frames[s].shape[0], state_index=s)
+        redone.append(h.one_pass_stats())
+    assert redone[0] == (1, 0) and redone[1] == (2, 1) and redone[9] == (2, 1) and redone[11][0] >= 3
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_synthetic_with_edge_cases(oracle, seed):
     pts = pwpp_synth.add_edge_cases(pwpp_synth.make_cloud(seed), seed)
