@@ -205,6 +205,16 @@ int pwpp_reset_kernel_profile(pwpp_handle *h);
 const char *pwpp_kernel_name(int k);
 /* fixed-point shift s of the plane-fit arithmetic contract for this handle */
 int pwpp_get_fxp_shift(pwpp_handle *h);
+/* Order of the points INSIDE a patch's part of the index lists (the parts themselves always follow the
+ * reference: bin traversal order, TGR candidates at the end of their ring).
+ *   PWPP_ORDER_SCATTER   (default) whatever the binning atomics produced -- same sets, fastest;
+ *   PWPP_ORDER_REFERENCE the reference's order (patchworkpp.cpp:199 sorts a bin by z; :500,:532): ground
+ *                        candidates ascending in z; non-ground: the points each R-VPF round removed, then
+ *                        the rest, each ascending in z; small bins / RNR / out-of-range in cloud order.
+ *                        Equal z: cloud order (the reference's std::sort leaves ties unspecified).
+ * Applies to the batches launched after the call. */
+enum { PWPP_ORDER_SCATTER = 0, PWPP_ORDER_REFERENCE = 1 };
+int pwpp_set_output_order(pwpp_handle *h, int order);
 /* one-pass binning (fixed bin segments; DESIGN.md 3, K1'): batches launched that way and how many of
  * them had to be redone on the exact two-pass path because a bin outgrew its segment.  Finishes the
  * batch in flight first.  No reference counterpart. */

@@ -19,7 +19,7 @@
 #include "pwpp_dev.h"
 
 extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
-                                    hipEvent_t aux_fork, hipEvent_t aux_join);
+                                    hipEvent_t aux_fork, hipEvent_t aux_join, unsigned long long *order_a, unsigned long long *order_b);
 extern "C" int pwpp_launch_gather_xyz(const PwppFrameDesc *fd, const int *idx, int count, float *out, hipStream_t stream);
 
 static_assert(sizeof(pwpp_state) == sizeof(PwppStateScalar), "pwpp_state must mirror PwppStateScalar");
@@ -136,6 +136,8 @@ struct pwpp_handle {
     DevBuf<int> d_sorted_idx;
     DevBuf<int32_t> d_plist;
     DevBuf<int32_t> d_out;
+    DevBuf<unsigned long long> d_ord_a, d_ord_b;  // scratch of the reference-order mode (long sub-lists)
+    int output_order = PWPP_ORDER_SCATTER;
     DevBuf<uint32_t> d_bins;  // 5 slabs of frames*(B+2): count, off, cursor, dst_a, dst_b
     DevBuf<uint32_t> d_cls_start;  // frames * 8
     DevBuf<uint32_t> d_cap_off;    // B + 3 segment starts of the one-pass path
@@ -362,7 +364,9 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     if (!one_pass) HIPCHK(hipMemsetAsync(bt.bin_cursor, 0, slab * sizeof(uint32_t), h->stream));
     HIPCHK(hipMemsetAsync(bt.results, 0, (size_t)frames * sizeof(PwppFrameResult), h->stream));
     if (bt.debug & 4) HIPCHK(hipMemsetAsync(bt.dbg, 0, 64 * sizeof(unsigned long long), h->stream));
-    const int lrc = pwpp_launch_pipeline(&bt, h->stream, h->profiling ? h->ev_k : nullptr, h->aux_stream, h->aux_fork, h->aux_join);
+    const bool ordered = h->output_order == PWPP_ORDER_REFERENCE;
+    const int lrc = pwpp_launch_pipeline(&bt, h->stream, h->profiling ? h->ev_k : nullptr, h->aux_stream, h->aux_fork, h->aux_join,
+                                         ordered ? h->d_ord_a.p : nullptr, ordered ? h->d_ord_b.p : nullptr);
     if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
     HIPCHK(hipMemcpyAsync(h->h_results.p, h->d_results.p, (size_t)frames * sizeof(PwppFrameResult), hipMemcpyDeviceToHost, h->stream));
@@ -542,6 +546,8 @@ int pwpp_destroy(pwpp_handle *h) {
     h->d_sorted_idx.release();
     h->d_plist.release();
     h->d_out.release();
+    h->d_ord_a.release();
+    h->d_ord_b.release();
     h->d_bins.release();
     h->d_recs.release();
     h->d_fit.release();
@@ -642,6 +648,10 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     if ((rc = h->d_sorted_idx.ensure(bin_slots))) return rc;
     if ((rc = h->d_plist.ensure(bin_slots))) return rc;
     if ((rc = h->d_out.ensure(tp))) return rc;
+    if (h->output_order == PWPP_ORDER_REFERENCE) {
+        if ((rc = h->d_ord_a.ensure(tp))) return rc;
+        if ((rc = h->d_ord_b.ensure(tp))) return rc;
+    }
     if ((rc = h->d_bins.ensure((size_t)frames * NB * 5))) return rc;
     if ((rc = h->d_recs.ensure((size_t)frames * B))) return rc;
     if ((rc = h->d_fit.ensure((size_t)frames * B))) return rc;
@@ -954,6 +964,16 @@ int pwpp_reset_kernel_profile(pwpp_handle *h) {
     return PWPP_OK;
 }
 int pwpp_get_fxp_shift(pwpp_handle *h) { return h ? h->dp.fxp_shift : PWPP_E_ARG; }
+
+int pwpp_set_output_order(pwpp_handle *h, int order) {
+    if (!h) return fail(PWPP_E_ARG, "null handle");
+    if (order != PWPP_ORDER_SCATTER && order != PWPP_ORDER_REFERENCE) return fail(PWPP_E_ARG, "bad order %d", order);
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    h->output_order = order;
+    return PWPP_OK;
+}
 
 int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone) {
     if (!h) return fail(PWPP_E_ARG, "null handle");

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_fit_rows(PwppBatch Bt, int b_lo, 
                     if (gmask >> k & 1u)
                         plist[bg++] = idx;  // regionwise_ground_ from the front
                     else
-                        plist[n - 1u - (bn++)] = idx;  // regionwise_nonground_ (R-VPF strips included) from the back
+                        plist[n - 1u - (bn++)] = idx | ((strip >> k & 1u) ? (1 << 24) : 0);  // regionwise_nonground_ from the back (R-VPF strips marked; this kernel does not keep their round)
                 }
             }
             if (kind != ST_DONE && cnt > 0) plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);  // empty: ref :49
@@ -462,7 +462,16 @@ __device__ __forceinline__ PatchRef patch_ref(const PwppBatch &Bt, size_t first)
 }
 // R-VPF removes a point from the patch's working set (ref :495-503) by overwriting its x with NaN:
 // a binned point never has a NaN x, and the coordinates of a removed point are not needed again.
-__device__ __forceinline__ void strip_point(const PatchRef &pr, unsigned i) { pr.xyz[i].x = __uint_as_float(0x7fc00000u); }
+// The NaN's payload is the R-VPF round (1-based): the reference appends the points a round removes to
+// regionwise_nonground_ round by round (ref :500), which the reference-order output mode reproduces.
+__device__ __forceinline__ void strip_point(const PatchRef &pr, unsigned i, int round) {
+    pr.xyz[i].x = __uint_as_float(0x7fc00000u | (unsigned)((round + 1) & 0xff));
+}
+// what the last R-GPF round writes for a non-ground point: its cloud index, plus in bits 24-31 the
+// R-VPF round that removed it (0: none) -- k_emit masks it off, k_order_sublists sorts by it
+__device__ __forceinline__ int nonground_entry(int idx, float x) {
+    return (x != x) ? (idx | (int)((__float_as_uint(x) & 0xffu) << 24)) : idx;
+}
 
 template <int G>
 __device__ __forceinline__ void load_chunk(ChunkPts &cp, const PatchRef &pr, unsigned n, unsigned c) {
@@ -725,7 +734,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo,
                     if (gm >> k & 1u)
                         plist[bg++] = w[k];
                     else if (ngm >> k & 1u)
-                        plist[n - 1u - (bn++)] = w[k];
+                        plist[n - 1u - (bn++)] = nonground_entry(w[k], cp.lp.x[k]);
                 }
             }
             cp = nx;
@@ -755,7 +764,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo,
                     for (int k = 0; k < kPPT; ++k) {
                         if (hit >> k & 1u) {
                             const unsigned i = c * (8u * G) + (unsigned)k * G + (unsigned)j;
-                            strip_point(pts, i);
+                            strip_point(pts, i, it);
                         }
                     }
                     any = any || hit != 0;
@@ -802,7 +811,8 @@ struct W64Patch {
     unsigned off, n;
     int kind;        // stage of the coming points phase; ST_DONE = nothing to do
     int flags;       // bit0: last R-GPF round (write the split), bit1: zone-0 cut-off applies, bit2: dual seed pass
-    float nx, ny, nz, pad_;
+    float nx, ny, nz;
+    int vpf_round;   // the R-VPF round of the strip in progress (reference-order output)
     double d;
     double thr_seed;
     double thr_band;  // dual seed pass: upper end of the band [thr_seed, thr_band)
@@ -978,7 +988,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
                         if (gm >> k & 1u)
                             plist[bg++] = w[k];
                         else if (ngm >> k & 1u)
-                            plist[qn - 1u - (bn++)] = w[k];
+                            plist[qn - 1u - (bn++)] = nonground_entry(w[k], cp.lp.x[k]);
                     }
                 }
             }
@@ -1045,6 +1055,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
                 sh.p[ln].ny = pl.ny;
                 sh.p[ln].nz = pl.nz;
                 sh.p[ln].d = pl.d;
+                sh.p[ln].vpf_round = it;
                 sh.stripped[ln] = 0;
             }
             wave_lds_sync();
@@ -1070,7 +1081,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
                     for (int k = 0; k < kPPT; ++k) {
                         if (hit >> k & 1u) {
                             const unsigned i = c * (8u * G) + (unsigned)k * G + (unsigned)j;
-                            strip_point(pts, i);
+                            strip_point(pts, i, pp.vpf_round);
                         }
                     }
                     any = any || hit != 0;
@@ -1161,7 +1172,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_ph_rows(PwppBatch Bt, int b_lo, i
             for (int k = 0; k < kPPT; ++k) {
                 if (hit >> k & 1u) {
                     const unsigned i = c * (8u * G) + (unsigned)k * G + (unsigned)j;
-                    strip_point(pts, i);
+                    strip_point(pts, i, st->it);
                 }
             }
             any = any || hit != 0;
@@ -1212,7 +1223,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_ph_rows(PwppBatch Bt, int b_lo, i
                 if (gm >> k & 1u)
                     plist[bg++] = w[k];
                 else if (ngm >> k & 1u)
-                    plist[n - 1u - (bn++)] = w[k];
+                    plist[n - 1u - (bn++)] = nonground_entry(w[k], cp.lp.x[k]);
             }
         }
     }
@@ -1671,7 +1682,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_brows(PwppBatch Bt, int b_lo,
                     if (gmask >> k & 1u)
                         plist[bg++] = w[k];
                     else if (ngm >> k & 1u)
-                        plist[n - 1u - (bn++)] = w[k];
+                        plist[n - 1u - (bn++)] = nonground_entry(w[k], cp.lp.x[k]);
                 }
             }
             cp = nx;
@@ -1719,7 +1730,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_brows(PwppBatch Bt, int b_lo,
                     const unsigned hit = lane_strip(cs2.lp, chunk_act(cs2), true, pl, P.th_dist_v);
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k)
-                        if (hit >> k & 1u) strip_point(pts, c * 512u + (unsigned)k * 64u + (unsigned)ln);
+                        if (hit >> k & 1u) strip_point(pts, c * 512u + (unsigned)k * 64u + (unsigned)ln, it);
                     any |= hit != 0u;
                 }
                 if (__syncthreads_or(any)) lpr_valid = false;  // the working set changed (and the marks are visible)
@@ -1802,7 +1813,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
                     if (pt_stripped(p)) continue;
                     const double dist = point_to_plane(nx, ny, nz, d, p);
                     if (fabs(dist) < P.th_dist_v) {  // ref :499 -> non_ground_dst
-                        strip_point(pts, i);
+                        strip_point(pts, i, it);
                         any = 1;
                     }
                 }
@@ -1860,7 +1871,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
                 if (g)
                     plist[bg + (unsigned)__popcll(mg & lt)] = idx;
                 else if (in)
-                    plist[n - 1u - (bn + (unsigned)__popcll(mn & lt))] = idx;
+                    plist[n - 1u - (bn + (unsigned)__popcll(mn & lt))] = nonground_entry(idx, p.x);
             }
         }
         reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);  // ref :537-542

@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
 // One WAVE per bin: a frame has ~500 bins of ~250 points, and with four-wave blocks three of four
 // waves were launched only to find nothing to do (2 M waves per batch; the kernel was bound by wave launches).
 constexpr int kEmitBlock = 64;
-__global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt) {
+__global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt, bool keep_cat) {
     const int f = blockIdx.y, seg = blockIdx.x;
     const PwppDevParams &P = Bt.P;
     const int B = P.num_bins, NB = B + 2;
@@ -1183,9 +1183,117 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt) {
                 if (i < ng)
                     out[da + i] = v[u];
                 else
-                    out[db + (i - ng)] = v[u];
+                    out[db + (i - ng)] = keep_cat ? v[u] : (v[u] & 0x00ffffff);  // bits 24-31: R-VPF round (k_order_sublists)
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K7 (optional)  reference order inside the sub-lists
+// k_gle_tgr / k_emit already put the SUB-LISTS where the reference appends them (bin traversal order,
+// TGR candidates at the end of their ring).  Inside a sub-list the reference's order is that of the
+// z-sorted bin (ref :199): ground candidates ascending in z; regionwise_nonground_ = the points R-VPF
+// removed, round by round, each round ascending in z, then the rest ascending in z (ref :500,:532);
+// small bins, RNR hits and out-of-range points in cloud order.  This kernel sorts every sub-list of
+// out_idx by (R-VPF round, z, cloud index).  Equal z: the reference's std::sort is unstable, so its
+// order among ties is an artefact of libstdc++; ties come out in cloud order here.
+// One workgroup per (frame, bin); sub-lists up to 4096 entries are sorted in LDS (bitonic), longer
+// ones tile by tile and then merged through two scratch arrays indexed like out_idx.
+// ------------------------------------------------------------------------------------------
+constexpr int kOrdTile = 4096;
+__device__ __forceinline__ void ord_tile_sort(unsigned long long *s_key, int len) {  // len <= kOrdTile, padded with ~0
+    int np = 1;
+    while (np < len) np <<= 1;
+    for (int i = len + (int)threadIdx.x; i < np; i += kBlock) s_key[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < np / 2; t += kBlock) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const unsigned long long a = s_key[lo], b = s_key[hi];
+                if ((a > b) == up) {
+                    s_key[lo] = b;
+                    s_key[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_order_sublists(PwppBatch Bt, unsigned long long *scr_a, unsigned long long *scr_b) {
+    __shared__ unsigned long long s_key[kOrdTile];
+    const int f = blockIdx.y, seg = blockIdx.x;
+    const PwppDevParams &P = Bt.P;
+    const int B = P.num_bins, NB = B + 2;
+    const unsigned n = Bt.bin_count[(size_t)f * NB + seg];
+    if (n < 2) return;
+    const PwppFrameDesc fd = Bt.frames[f];
+    int *out = Bt.out_idx + fd.base;
+    const bool whole = seg >= B || (uint64_t)n < P.min_pts;
+    const unsigned ng = whole ? n : (unsigned)Bt.recs[(size_t)f * B + seg].n_ground;
+    for (int which = 0; which < 2; ++which) {
+        const unsigned start = which == 0 ? Bt.dst_a[(size_t)f * NB + seg] : Bt.dst_b[(size_t)f * NB + seg];
+        const int len = (int)(which == 0 ? ng : n - ng);
+        if (len < 1) continue;
+        auto make_key = [&](int entry) -> unsigned long long {
+            const int idx = entry & 0x00ffffff;
+            if (whole) return (unsigned long long)(unsigned)idx;  // cloud order
+            float x, y, z, w;
+            load_point(fd, idx, x, y, z, w);
+            unsigned cat = 0;
+            if (which == 1) {
+                cat = (unsigned)entry >> 24;      // R-VPF round (1-based) or 0
+                cat = cat ? cat : 255u;           // the points of the final split come last
+            }
+            return ((unsigned long long)cat << 56) | ((unsigned long long)z_key(z) << 24) | (unsigned long long)(unsigned)idx;
+        };
+        if (len <= kOrdTile) {
+            for (int i = threadIdx.x; i < len; i += kBlock) s_key[i] = make_key(out[start + i]);
+            __syncthreads();
+            ord_tile_sort(s_key, len);
+            for (int i = threadIdx.x; i < len; i += kBlock) out[start + i] = (int)(s_key[i] & 0x00ffffffull);
+            __syncthreads();
+            continue;
+        }
+        // long sub-list: sorted tiles, then merge passes a -> b -> a ...
+        unsigned long long *a = scr_a + fd.base + start, *b = scr_b + fd.base + start;
+        for (int t0 = 0; t0 < len; t0 += kOrdTile) {
+            const int tl = len - t0 < kOrdTile ? len - t0 : kOrdTile;
+            for (int i = threadIdx.x; i < tl; i += kBlock) s_key[i] = make_key(out[start + t0 + i]);
+            __syncthreads();
+            ord_tile_sort(s_key, tl);
+            for (int i = threadIdx.x; i < tl; i += kBlock) a[t0 + i] = s_key[i];
+            __syncthreads();
+        }
+        for (int width = kOrdTile; width < len; width <<= 1) {
+            __threadfence_block();
+            __syncthreads();
+            for (int i = threadIdx.x; i < len; i += kBlock) {
+                const int pair0 = (i / (2 * width)) * (2 * width);           // first element of the pair of runs
+                const int mid = pair0 + width < len ? pair0 + width : len;  // [pair0, mid) and [mid, end)
+                const int end = pair0 + 2 * width < len ? pair0 + 2 * width : len;
+                const unsigned long long key = a[i];
+                int lo, hi;
+                const bool left = i < mid;
+                if (left) { lo = mid; hi = end; } else { lo = pair0; hi = mid; }
+                while (lo < hi) {  // keys are distinct (they end in the cloud index): plain lower bound
+                    const int m = (lo + hi) >> 1;
+                    if (a[m] < key) lo = m + 1; else hi = m;
+                }
+                const int rank_other = left ? lo - mid : lo - pair0;
+                const int own = left ? i - pair0 : i - mid;
+                b[pair0 + own + rank_other] = key;
+            }
+            unsigned long long *t = a;
+            a = b;
+            b = t;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int i = threadIdx.x; i < len; i += kBlock) out[start + i] = (int)(a[i] & 0x00ffffffull);
+        __syncthreads();
     }
 }
 
@@ -1215,7 +1323,9 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
                                hipEvent_t aux_fork, hipEvent_t aux_join);
 
 extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev /* PWPP_NUM_KERNELS + 1 events or null */,
-                                    hipStream_t aux, hipEvent_t aux_fork, hipEvent_t aux_join) {
+                                    hipStream_t aux, hipEvent_t aux_fork, hipEvent_t aux_join,
+                                    unsigned long long *order_a /* reference-order mode: two scratch arrays, else null */,
+                                    unsigned long long *order_b) {
     const PwppBatch &B = *batch;
     const int F = B.num_frames;
     if (F <= 0) return 0;
@@ -1242,7 +1352,8 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     else
         hipLaunchKernelGGL(k_gle_tgr, dim3(F), dim3(kBlock), 0, stream, B);
     if (ev) (void)hipEventRecord(ev[10], stream);
-    hipLaunchKernelGGL(k_emit, dim3(NB, F), dim3(kEmitBlock), 0, stream, B);
+    hipLaunchKernelGGL(k_emit, dim3(NB, F), dim3(kEmitBlock), 0, stream, B, order_a != nullptr);
     if (ev) (void)hipEventRecord(ev[11], stream);
+    if (order_a) hipLaunchKernelGGL(k_order_sublists, dim3(NB, F), dim3(kBlock), 0, stream, B, order_a, order_b);
     return (int)hipGetLastError();
 }

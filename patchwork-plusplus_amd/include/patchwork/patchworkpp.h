@@ -207,6 +207,9 @@ public:
 
     double getHeight() { return pwpp_get_height(h_); }      // reference :154
     double getTimeTaken() { return pwpp_get_time_us(h_); }  // reference :155 (microseconds)
+    // extension: true = the points of a patch come out in the reference's own order (bins sorted by z,
+    // patchworkpp.cpp:199) instead of the scatter order; same sets either way (pwpp.h, pwpp_set_output_order)
+    void setReferenceOrder(bool on) { check(pwpp_set_output_order(h_, on ? PWPP_ORDER_REFERENCE : PWPP_ORDER_SCATTER)); }
 
     Cloud getGround() { return xyz(true); }          // reference :157
     Cloud getNonground() { return xyz(false); }      // reference :158

@@ -99,6 +99,7 @@ def load():
         L.pwpp_reset_kernel_profile.argtypes = [vp]
         L.pwpp_get_fxp_shift.argtypes = [vp]
         L.pwpp_get_one_pass_stats.argtypes = [vp, vp, vp]
+        L.pwpp_set_output_order.argtypes = [vp, ci]
         L.pwpp_kernel_name.argtypes = [ci]
         _lib = L
     return _lib
@@ -321,6 +322,10 @@ class Handle:
 
     def fxp_shift(self):
         return self._L.pwpp_get_fxp_shift(self._h)
+
+    def set_output_order(self, reference):
+        """True: the points of a patch come out in the reference's order (z-sorted bins); False: scatter order."""
+        self._check(self._L.pwpp_set_output_order(self._h, 1 if reference else 0))
 
     def one_pass_stats(self):
         """(batches launched with one-pass binning, batches redone on the two-pass path after an overflow)"""

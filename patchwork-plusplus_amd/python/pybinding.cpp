@@ -95,6 +95,7 @@ PYBIND11_MODULE(pypatchworkpp, m) {
         .def("estimateGround", &estimate_ground)
         .def("getHeight", &PatchWorkpp::getHeight)
         .def("getTimeTaken", &PatchWorkpp::getTimeTaken)
+        .def("setReferenceOrder", &PatchWorkpp::setReferenceOrder, py::arg("on"))
         .def("getGround", [](PatchWorkpp &s) { return to_numpy(s.getGround()); })
         .def("getNonground", [](PatchWorkpp &s) { return to_numpy(s.getNonground()); })
         .def("getCenters", [](PatchWorkpp &s) { return to_numpy(s.getCenters()); })

@@ -532,3 +532,40 @@ def test_full_size_batch_properties(kitti):
     single = pwpp_hip.Handle()
     single.estimate_ground_batch([kitti[3]], mode=pwpp_hip.MODE_FRESH)
     assert np.array_equal(np.sort(single.ground_indices(0)), np.sort(h.ground_indices(3)))  # latency plan, two-pass binning
+
+
+def test_reference_output_order(kitti, oracle):
+    """with PWPP_ORDER_REFERENCE the index lists come out in the reference's order --
+    parts in bin traversal order (always), and inside a patch's part the order of the z-sorted bin:
+    ascending z, the points removed by R-VPF first in the non-ground part.  The oracle emits the
+    reference's own order; the only freedom is among points of equal z, where the reference's
+    unstable std::sort leaves the order to libstdc++ (here: cloud order)."""
+    syn = pwpp_synth.add_edge_cases(pwpp_synth.make_cloud(7, beams=48, azimuth_steps=1500), 7)
+    frames = [kitti[0], kitti[3], syn, kitti[5], kitti[1], kitti[2]]
+    refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(p) for p in frames]
+    h = pwpp_hip.Handle()
+    h.set_output_order(True)
+    total, moved = 0, 0
+    for batch in ([frames[0]], frames):   # latency plan + two-pass binning, then a batch (one-pass binning)
+        h.estimate_ground_batch(batch, mode=pwpp_hip.MODE_FRESH)
+        for i, pts in enumerate(batch):
+            ref = refs[i]
+            z = pts[:, 2]
+            for mine, theirs in ((h.ground_indices(i), ref.ground_idx), (h.nonground_indices(i), ref.nonground_idx)):
+                theirs = np.asarray(theirs)
+                assert len(mine) == len(theirs)
+                assert np.array_equal(np.sort(mine), np.sort(theirs))
+                zm, zt = z[mine], z[theirs]
+                assert np.array_equal(zm, zt, equal_nan=True), "the z sequence differs from the reference's"
+                diff = np.nonzero(mine != theirs)[0]
+                # every position that differs sits in a run of equal z
+                for d in diff[:2000]:
+                    assert (d > 0 and zm[d - 1] == zm[d]) or (d + 1 < len(zm) and zm[d + 1] == zm[d])
+                total += len(mine)
+                moved += len(diff)
+            # getGround()/getNonground() rows stay aligned with the index lists
+            assert np.array_equal(h.ground(i), pts[h.ground_indices(i), :3])
+    assert moved < 0.02 * total, "only ties may move: %d of %d" % (moved, total)
+    h.set_output_order(False)
+    h.estimate_ground_batch([frames[0]], mode=pwpp_hip.MODE_FRESH)
+    assert np.array_equal(np.sort(h.ground_indices(0)), np.sort(refs[0].ground_idx))
