@@ -1201,15 +1201,15 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt, bool keep_cat
 // One workgroup per (frame, bin); sub-lists up to 4096 entries are sorted in LDS (bitonic), longer
 // ones tile by tile and then merged through two scratch arrays indexed like out_idx.
 // ------------------------------------------------------------------------------------------
-constexpr int kOrdTile = 4096;
-__device__ __forceinline__ void ord_tile_sort(unsigned long long *s_key, int len) {  // len <= kOrdTile, padded with ~0
+template <int BLOCK>
+__device__ __forceinline__ void ord_tile_sort(unsigned long long *s_key, int len) {  // len <= tile size, padded with ~0
     int np = 1;
     while (np < len) np <<= 1;
-    for (int i = len + (int)threadIdx.x; i < np; i += kBlock) s_key[i] = ~0ull;
+    for (int i = len + (int)threadIdx.x; i < np; i += BLOCK) s_key[i] = ~0ull;
     __syncthreads();
     for (int k = 2; k <= np; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < np / 2; t += kBlock) {
+            for (int t = threadIdx.x; t < np / 2; t += BLOCK) {
                 const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
                 const bool up = (lo & k) == 0;
                 const unsigned long long a = s_key[lo], b = s_key[hi];
@@ -1222,13 +1222,16 @@ __device__ __forceinline__ void ord_tile_sort(unsigned long long *s_key, int len
         }
     }
 }
-__global__ __launch_bounds__(kBlock) void k_order_sublists(PwppBatch Bt, unsigned long long *scr_a, unsigned long long *scr_b) {
+// Two instantiations: <64, 256, 0> one wave per bin for the short lists (most of them: ~250 points),
+// <256, 4096, 256> a workgroup for the lists above 256 entries.  Each handles the lists in ITS range.
+template <int BLOCK, int kOrdTile, int kMinLen>
+__global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned long long *scr_a, unsigned long long *scr_b) {
     __shared__ unsigned long long s_key[kOrdTile];
     const int f = blockIdx.y, seg = blockIdx.x;
     const PwppDevParams &P = Bt.P;
     const int B = P.num_bins, NB = B + 2;
     const unsigned n = Bt.bin_count[(size_t)f * NB + seg];
-    if (n < 2) return;
+    if (n < 1) return;
     const PwppFrameDesc fd = Bt.frames[f];
     int *out = Bt.out_idx + fd.base;
     const bool whole = seg >= B || (uint64_t)n < P.min_pts;
@@ -1236,7 +1239,7 @@ __global__ __launch_bounds__(kBlock) void k_order_sublists(PwppBatch Bt, unsigne
     for (int which = 0; which < 2; ++which) {
         const unsigned start = which == 0 ? Bt.dst_a[(size_t)f * NB + seg] : Bt.dst_b[(size_t)f * NB + seg];
         const int len = (int)(which == 0 ? ng : n - ng);
-        if (len < 1) continue;
+        if (len < 1 || len <= kMinLen || (kMinLen == 0 && len > kOrdTile)) continue;  // not this instantiation's range
         auto make_key = [&](int entry) -> unsigned long long {
             const int idx = entry & 0x00ffffff;
             if (whole) return (unsigned long long)(unsigned)idx;  // cloud order
@@ -1250,10 +1253,10 @@ __global__ __launch_bounds__(kBlock) void k_order_sublists(PwppBatch Bt, unsigne
             return ((unsigned long long)cat << 56) | ((unsigned long long)z_key(z) << 24) | (unsigned long long)(unsigned)idx;
         };
         if (len <= kOrdTile) {
-            for (int i = threadIdx.x; i < len; i += kBlock) s_key[i] = make_key(out[start + i]);
+            for (int i = threadIdx.x; i < len; i += BLOCK) s_key[i] = make_key(out[start + i]);
             __syncthreads();
-            ord_tile_sort(s_key, len);
-            for (int i = threadIdx.x; i < len; i += kBlock) out[start + i] = (int)(s_key[i] & 0x00ffffffull);
+            ord_tile_sort<BLOCK>(s_key, len);
+            for (int i = threadIdx.x; i < len; i += BLOCK) out[start + i] = (int)(s_key[i] & 0x00ffffffull);
             __syncthreads();
             continue;
         }
@@ -1261,16 +1264,16 @@ __global__ __launch_bounds__(kBlock) void k_order_sublists(PwppBatch Bt, unsigne
         unsigned long long *a = scr_a + fd.base + start, *b = scr_b + fd.base + start;
         for (int t0 = 0; t0 < len; t0 += kOrdTile) {
             const int tl = len - t0 < kOrdTile ? len - t0 : kOrdTile;
-            for (int i = threadIdx.x; i < tl; i += kBlock) s_key[i] = make_key(out[start + t0 + i]);
+            for (int i = threadIdx.x; i < tl; i += BLOCK) s_key[i] = make_key(out[start + t0 + i]);
             __syncthreads();
-            ord_tile_sort(s_key, tl);
-            for (int i = threadIdx.x; i < tl; i += kBlock) a[t0 + i] = s_key[i];
+            ord_tile_sort<BLOCK>(s_key, tl);
+            for (int i = threadIdx.x; i < tl; i += BLOCK) a[t0 + i] = s_key[i];
             __syncthreads();
         }
         for (int width = kOrdTile; width < len; width <<= 1) {
             __threadfence_block();
             __syncthreads();
-            for (int i = threadIdx.x; i < len; i += kBlock) {
+            for (int i = threadIdx.x; i < len; i += BLOCK) {
                 const int pair0 = (i / (2 * width)) * (2 * width);           // first element of the pair of runs
                 const int mid = pair0 + width < len ? pair0 + width : len;  // [pair0, mid) and [mid, end)
                 const int end = pair0 + 2 * width < len ? pair0 + 2 * width : len;
@@ -1292,7 +1295,7 @@ __global__ __launch_bounds__(kBlock) void k_order_sublists(PwppBatch Bt, unsigne
         }
         __threadfence_block();
         __syncthreads();
-        for (int i = threadIdx.x; i < len; i += kBlock) out[start + i] = (int)(a[i] & 0x00ffffffull);
+        for (int i = threadIdx.x; i < len; i += BLOCK) out[start + i] = (int)(a[i] & 0x00ffffffull);
         __syncthreads();
     }
 }
@@ -1354,6 +1357,9 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     if (ev) (void)hipEventRecord(ev[10], stream);
     hipLaunchKernelGGL(k_emit, dim3(NB, F), dim3(kEmitBlock), 0, stream, B, order_a != nullptr);
     if (ev) (void)hipEventRecord(ev[11], stream);
-    if (order_a) hipLaunchKernelGGL(k_order_sublists, dim3(NB, F), dim3(kBlock), 0, stream, B, order_a, order_b);
+    if (order_a) {
+        hipLaunchKernelGGL((k_order_sublists<64, 256, 0>), dim3(NB, F), dim3(64), 0, stream, B, order_a, order_b);
+        hipLaunchKernelGGL((k_order_sublists<256, 4096, 256>), dim3(NB, F), dim3(256), 0, stream, B, order_a, order_b);
+    }
     return (int)hipGetLastError();
 }
