@@ -254,7 +254,10 @@ __device__ __forceinline__ unsigned lane_stage_accum(const LanePts &lp, unsigned
     unsigned gmask = 0;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
-        const bool inc = (act >> k & 1u) && plane_dist(tx, ty, tz, td, lp.x[k], lp.y[k], lp.z[k]) < thr;  // one-sided
+        // (no short circuit: the distance of a slot beyond the patch's end is computed on a stand-in record and
+        // discarded -- one masked compare instead of a branch around the test)
+        const bool below = plane_dist(tx, ty, tz, td, lp.x[k], lp.y[k], lp.z[k]) < thr;  // one-sided
+        const bool inc = below & ((act >> k & 1u) != 0u);
         if (inc) {  // (a branch on purpose: seed passes include only ~10 % of the points)
             gmask |= 1u << k;
             cm.add(lp.x[k], lp.y[k], lp.z[k], qscale);
