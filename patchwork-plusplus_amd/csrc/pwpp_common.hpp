@@ -273,10 +273,14 @@ struct ChunkMoments {
     // create time), so their clamp can never act and the rounded product is converted float ->
     // double directly (v_rndne_f32, v_cvt_f64_f32); z is unbounded and may be NaN: integer path.
     __device__ __forceinline__ void add(float x, float y, float z, float scale) {
+        n += 1;
+        add_uncounted(x, y, z, scale);
+    }
+    // (the caller adds the number of points itself, e.g. the population count of a chunk's mask)
+    __device__ __forceinline__ void add_uncounted(float x, float y, float z, float scale) {
         const double dx = (double)__builtin_rintf(x * scale), dy = (double)__builtin_rintf(y * scale);
         const int qz = fxp_quantise(z, scale);
         const double dz = (double)qz;
-        n += 1;
         s1x += dx;
         s1y += dy;
         s1z += qz;

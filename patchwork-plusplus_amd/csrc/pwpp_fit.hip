@@ -260,9 +260,10 @@ __device__ __forceinline__ unsigned lane_stage_accum(const LanePts &lp, unsigned
         const bool inc = below & ((act >> k & 1u) != 0u);
         if (inc) {  // (a branch on purpose: seed passes include only ~10 % of the points)
             gmask |= 1u << k;
-            cm.add(lp.x[k], lp.y[k], lp.z[k], qscale);
+            cm.add_uncounted(lp.x[k], lp.y[k], lp.z[k], qscale);
         }
     }
+    cm.n += __popc(gmask);
     return gmask;
 }
 __device__ __forceinline__ unsigned lane_stage_moments(const LanePts &lp, unsigned act, int kind, double thr_seed,
