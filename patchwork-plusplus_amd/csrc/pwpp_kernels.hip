@@ -260,13 +260,18 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
 // batch on the exact two-pass path, so the result never depends on the capacities.
 // ------------------------------------------------------------------------------------------
 constexpr int kOnePassPts = 1024;  // points per workgroup of K1'
-__global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt) {
+__global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt, int tiles_per_frame) {
     __shared__ unsigned s_cnt[PWPP_MAX_BINS + 2];     // points of this workgroup per bin, then its first slot in the bin
     __shared__ unsigned s_seg[PWPP_MAX_BINS + 3];     // segment starts
     __shared__ float4 s_zt[8];
-    const int f = blockIdx.y;
+    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and the
+    // scattered 12-byte / 4-byte records of a bin merge into full lines only if the workgroups that write
+    // that bin share an L2.  So XCD k takes the frames k, k + 8, ..., all tiles of a frame in a row.
+    const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+    const int f = xcd + 8 * (slot / tiles_per_frame);
+    if (f >= Bt.num_frames) return;
     const PwppFrameDesc fd = Bt.frames[f];
-    const int first = blockIdx.x * kOnePassPts;
+    const int first = (slot % tiles_per_frame) * kOnePassPts;
     if (first >= fd.n) return;
     const PwppDevParams &P = Bt.P;
     const int NB = P.num_bins + 2;
@@ -288,7 +293,8 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt) {
         if (i < fd.n) {
             float x, y, z, w;
             load_point(fd, i, x, y, z, w);
-            code = czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0, (Bt.debug & 128) != 0);
+            code = (Bt.debug & 8192) ? (unsigned)((i >> 5) % 500)  // timing ablation only: no code computation
+                                     : czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0, (Bt.debug & 128) != 0);
             if (code == PWPP_CODE_DROP) ++dropped;
             pt[j].x = x;
             pt[j].y = y;
@@ -317,8 +323,10 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt) {
             const unsigned seg = s_seg[code], cap = s_seg[code + 1] - seg;
             const unsigned r = s_cnt[code] + (pc[j] >> 16);
             if (r < cap) {
-                sorted_xyz[seg + r] = pt[j];
-                sorted_idx[seg + r] = first + j * kBlock + (int)threadIdx.x;
+                if (!(Bt.debug & 4096)) {  // (timing ablation only: no stores)
+                    sorted_xyz[seg + r] = pt[j];
+                    sorted_idx[seg + r] = first + j * kBlock + (int)threadIdx.x;
+                }
             } else {
                 over = true;
             }
@@ -1337,7 +1345,7 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     if (ev) (void)hipEventRecord(ev[0], stream);
     if (B.cap_off) {  // one-pass binning (fixed bin segments)
         const unsigned gx1 = (unsigned)((B.max_n + kOnePassPts - 1) / kOnePassPts);
-        if (gx1 > 0) hipLaunchKernelGGL(k_czm_bin_scatter, dim3(gx1, F), dim3(kBlock), 0, stream, B);
+        if (gx1 > 0) hipLaunchKernelGGL(k_czm_bin_scatter, dim3(gx1 * (unsigned)((F + 7) / 8 * 8)), dim3(kBlock), 0, stream, B, (int)gx1);
         if (ev) (void)hipEventRecord(ev[1], stream);
         hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
         if (ev) (void)hipEventRecord(ev[2], stream);
