@@ -5,16 +5,22 @@
 //
 // A patch is a CZM bin with >= num_min_pts points: 10 ... ~30 000 points, median ~170.  Its
 // work is a chain of 4-7 dependent plane fits, each = one pass over the points + a serial
-// 3x3 eigen-solve.  The points of a patch are read from HBM/L2 ONCE into registers (8 per
-// lane) and stay there for the whole chain; how many lanes a patch gets depends on its size
-// (k_czm_scan sorts the patches of a frame into size classes):
+// 3x3 eigen-solve (Eigen's Jacobi, ~1500 instructions).  k_czm_scan sorts the patches of a
+// frame into quarter-octave size buckets; a PLAN (pwpp_launch_fit, bottom of this file) maps
+// bucket ranges to kernels, chosen by the amount of work in the batch:
 //
-//   class 0..2  n <= 128 / 256 / 512   k_fit_rows<16|32|64>: 16/32/64 lanes per patch, so one
-//                                      wave carries 4/2/1 patches; everything is wave-local
-//                                      (shuffles, ballots), no LDS, no barriers
-//   class 3..4  n <= 2048 / 8192       k_fit_block<256|1024>: one workgroup per patch, cross-wave
-//                                      sums through LDS, 2 barriers per fit
-//   class 5     larger                 k_fit_stream: points streamed from L2/HBM on every pass
+//   k_fit_w64<16,64|32|16>  64/32/16 small patches per wave: points phases in rows of 16 lanes
+//                           (4 patches at a time), then ONE solve phase with a patch per lane
+//   k_fit_w64<64,2>         big bins, two per wave: 64 lanes stream one patch at a time, the
+//                           two solves share an instruction stream; dual seed pass
+//   k_fit_srows<G>          one row of G lanes per patch, next chunk prefetched (mid-size batches)
+//   k_fit_brows             four waves per patch (a handful of frames: chain latency)
+//   k_fit_rows<G>           points parked in lane-private LDS slots (patches up to 8 G points)
+//   k_ph_rows + k_ph_solve  the chain cut into phase kernels, state in HBM
+//   k_fit_stream            whatever exceeds the plan (> 65535 points): workgroup per patch
+//
+// The streamed kernels re-read a patch once per stage (12-byte records, 5 passes for a zone-0
+// patch); DESIGN.md section 3 has the measurements that led here.
 //
 // All reductions are integer, so every variant produces bit-identical
 // planes and the same index sets whatever the lane count.

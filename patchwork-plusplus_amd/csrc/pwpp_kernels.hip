@@ -1,21 +1,23 @@
 // pwpp_kernels.hip -- the Patchwork++ estimateGround() hot path as hand-written HIP for
 // gfx950 (MI355X, CDNA4: wave64, 256 CUs in 8 XCDs, 160 KiB LDS/CU, HBM3E).
 //
-// One batch of F independent frames goes through eleven launches; every launch covers all
-// frames (grid.y = frame), so a 1024-frame batch is 11 launches, not 11264:
+// One batch of F independent frames goes through six or seven launches; every launch covers
+// all frames, so a 1024-frame batch is 6 launches, not 6144:
 //
-//   K1 k_czm_bin      RNR + CZM code per point + per-frame bin histogram   (ref :377-400, :578-622)
-//   K2 k_czm_scan     exclusive scan of the histogram -> bin offsets
-//   K3 k_czm_scatter  points grouped by bin: {x,y,z,idx} 16 B records      (ref :602-614 emplace_back)
-//   K4 k_fit_*        per patch: LPR seeds, R-VPF, R-GPF, final plane       (ref :77-149, :47-75, :467-554)
-//                     six launches by patch size class, see pwpp_fit.hip
-//   K5 k_gle_tgr      per frame: GLE ladder, A-GLE history, TGR, thresholds (ref :211-309, :338-375, :402-464)
-//   K6 k_emit         ground / non-ground index lists                       (ref :28-31, :18-26)
+//   K1' k_czm_bin_scatter  RNR + CZM code per point, straight into the bin's FIXED segment   (ref :377-400, :578-622)
+//       (or K1 k_czm_bin + K3 k_czm_scatter: histogram, then scatter -- the exact two-pass path
+//        for <= 4 frames and for the redo after a segment overflow)
+//   K2  k_czm_scan         bin offsets, patches sorted into size buckets
+//   K4  k_fit_*            per patch: LPR seeds, R-VPF, R-GPF, final plane       (ref :77-149, :47-75, :467-554)
+//                          one or two launches by patch size, see pwpp_fit.hip
+//   K5  k_gle_tgr          per frame: GLE ladder, A-GLE history, TGR, thresholds (ref :211-309, :338-375, :402-464)
+//   K6  k_emit             ground / non-ground index lists                       (ref :28-31, :18-26)
+//   K7  k_order_sublists   optional: the reference's order inside every part of the lists
 //
 // All reference citations are /root/reference/cpp/patchworkpp/src/patchworkpp.cpp unless a
-// header is named.  This is memory/latency-bound integer + scalar-float work: no MFMA
-// anywhere (3x3 covariances), the levers are coalesced 16 B/lane traffic, LDS-staged
-// atomics and keeping the per-patch iteration inside one workgroup.
+// header is named.  This is integer + scalar-float work bound by HBM traffic (binning, emit) and by
+// VALU issue (plane fits): no MFMA anywhere (3x3 covariances); the levers are coalesced 16 B/lane
+// traffic, LDS-staged atomics, XCD-aware grids and as few passes over a patch as the chain allows.
 //
 // ARITHMETIC CONTRACT.  Everything the reference evaluates in its own
 // float/double expressions is evaluated here with the same operations in the same order
