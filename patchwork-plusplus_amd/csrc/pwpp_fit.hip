@@ -805,8 +805,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo,
 // ------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------
 // k_fit_w64: one wave = 64 patches.  The VALU profile of the row kernels showed the serial
-// eigen-solve (~3800 instructions, executed once per wave for only 1-4 patches) to be ~75 %
-// of all issue cycles of the fit stage.  Here a wave owns up to 64 patches of a frame:
+// eigen-solve (~1800 VALU instructions, executed by all 64 lanes of a wave for only 1-4 patches)
+// to be the largest single consumer of issue cycles of the fit stage.  Here a wave owns up to 64 patches of a frame:
 //   * points phases run 4 patches at a time in rows of 16 lanes (points streamed from L2) and
 //     leave the ten integer moments of every patch in LDS;
 //   * the solve phase runs ONCE per stage with lane p solving patch p -- 64 different 3x3
@@ -1132,8 +1132,8 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
 //               per patch to global memory.  No eigen-solve in this kernel: few registers,
 //               eight waves per SIMD to hide the L2 latency of the streamed points.
 //   k_ph_solve  ONE LANE PER PATCH: plane from the moments + the state transition.  64 different
-//               3x3 problems per wave instruction stream instead of 1-4: the solve, ~75 % of the
-//               issue cycles of the row kernels, shrinks to a few percent.
+//               3x3 problems per wave instruction stream instead of 1-4: the solve, a third of the
+//               instructions of the row kernels, shrinks to a few percent.
 // A batch runs 2*num_iter + 2 rounds of (rows, solve); patches that are finished exit at once.
 // ------------------------------------------------------------------------------------------
 template <int G>
