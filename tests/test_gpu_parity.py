@@ -546,10 +546,12 @@ def test_reference_output_order(kitti, oracle):
     h = pwpp_hip.Handle()
     h.set_output_order(True)
     total, moved = 0, 0
-    for batch in ([frames[0]], frames):   # latency plan + two-pass binning, then a batch (one-pass binning)
+    dense = pwpp_synth.make_dense_cloud(77)   # bins of 10-30 k points: parts far beyond one 4096-entry tile (merge passes)
+    refs.append(ol.Estimator(oracle, arith=ol.ARITH_FXP).run(dense))
+    for batch in ([frames[0]], frames, [dense]):   # latency plan + two-pass binning, a batch (one-pass binning), long lists
         h.estimate_ground_batch(batch, mode=pwpp_hip.MODE_FRESH)
         for i, pts in enumerate(batch):
-            ref = refs[i]
+            ref = refs[6] if batch[0] is dense else refs[i]
             z = pts[:, 2]
             for mine, theirs in ((h.ground_indices(i), ref.ground_idx), (h.nonground_indices(i), ref.nonground_idx)):
                 theirs = np.asarray(theirs)
