@@ -522,7 +522,7 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~Row<64>::
 // that overflows, an exact but slow extraction by distinct values runs.
 template <int G>
 __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max, bool need, bool use_cutoff, double cutoff,
-                           int num_lpr) {
+                           int num_lpr, int force = 0 /* tests: 1 = take the second pass, 2 = and the exact extraction (PWPP_DEBUG_FLAGS 16384 / 32768) */) {
     const int j = lane_id() & (G - 1);
     const unsigned INF = 0xFFFFFFFFu;
     unsigned k0 = INF, k1 = INF, k2 = INF, k3 = INF, dropped = INF;
@@ -563,7 +563,7 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
             k3 = INF;
         }
     }
-    const bool fast = need && keff > 0 && Row<G>::min_u32(dropped) < T;  // second pass needed (row-uniform)
+    const bool fast = need && keff > 0 && (Row<G>::min_u32(dropped) < T || force != 0);  // second pass needed (row-uniform)
     bool exact_path = false;
     if (__any(fast)) {
         const unsigned U = T;  // an upper bound of the keff-th smallest key of the row
@@ -589,8 +589,8 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
             }
         }
         const bool row_over = Row<G>::ballot(overflow) != 0ull;
-        exact_path = fast && row_over;
-        const bool ok = fast && !row_over;
+        exact_path = fast && (row_over || force == 2);
+        const bool ok = fast && !row_over && force != 2;
         int nless = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) nless += key[q] != INF ? 1 : 0;
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo,
         if (!__any(kind != ST_DONE)) break;
         const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
         if (__any(need_lpr)) {
-            const double l = (Bt.debug & 512) ? -1.7 : srow_lpr<G>(pts, n, nchunk_max, need_lpr, use_cutoff, cutoff, P.num_lpr);
+            const double l = (Bt.debug & 512) ? -1.7 : srow_lpr<G>(pts, n, nchunk_max, need_lpr, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
             if (need_lpr) {
                 lpr = l;
                 lpr_valid = true;
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
                 const unsigned qn = sh.p[q].n, qoff = sh.p[q].off;
                 const bool use_cutoff = (sh.p[q].flags & 2) != 0;
                 const unsigned nchunk_max = wave_max_u32(need_row ? (qn + 8u * G - 1u) / (8u * G) : 0u);
-                const double l = srow_lpr<G>(patch_ref(Bt, (size_t)fd.sbase + qoff), qn, nchunk_max, need_row, use_cutoff, cutoff, P.num_lpr);
+                const double l = srow_lpr<G>(patch_ref(Bt, (size_t)fd.sbase + qoff), qn, nchunk_max, need_row, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
                 if (need_row && j == 0) sh.lpr[q] = l;
             }
             wave_lds_sync();
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_ph_rows(PwppBatch Bt, int b_lo, i
     // ---- lowest-point representative (ref :84-103)
     const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
     if (__any(need_lpr)) {
-        const double l = srow_lpr<G>(pts, n, nchunk_max, need_lpr, use_cutoff, cutoff, P.num_lpr);
+        const double l = srow_lpr<G>(pts, n, nchunk_max, need_lpr, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
         if (need_lpr) {
             lpr = l;
             if (j == 0) {
@@ -1538,7 +1538,8 @@ struct BRowShared {
 };
 
 // LPR (ref :84-103) with the points of the patch dealt out to the four waves chunk by chunk
-__device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsigned nchunk, bool use_cutoff, double cutoff, int num_lpr) {
+__device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsigned nchunk, bool use_cutoff, double cutoff, int num_lpr,
+                           int force = 0) {
     const unsigned INF = 0xFFFFFFFFu;
     const int wv = wave_id(), ln = lane_id();
     unsigned k0 = INF, k1 = INF, k2 = INF, k3 = INF, dropped = INF;
@@ -1609,7 +1610,7 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsi
         T = best;
     }
     __syncthreads();  // the lists are free again
-    if (keff > 0 && dall < T) return block_lpr(sh.fs, pts, n, use_cutoff, cutoff, num_lpr);  // a lane held > 4 of the lowest: exact path
+    if (keff > 0 && (dall < T || force != 0)) return block_lpr(sh.fs, pts, n, use_cutoff, cutoff, num_lpr);  // a lane held > 4 of the lowest: exact path
     return keff ? sum / (double)keff : 0.0;  // ref :103
 }
 
@@ -1653,7 +1654,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_brows(PwppBatch Bt, int b_lo,
 
     for (int guard = 0; guard < 4 * P.num_iter + 8 && kind != ST_DONE; ++guard) {
         if ((kind == ST_VPF || kind == ST_SEED) && !lpr_valid) {
-            lpr = brow_lpr(sh, pts, n, nchunk, use_cutoff, cutoff, P.num_lpr);
+            lpr = brow_lpr(sh, pts, n, nchunk, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
             lpr_valid = true;
         }
         const double thr_seed = lpr + ((kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds);

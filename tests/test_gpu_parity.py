@@ -571,3 +571,20 @@ def test_reference_output_order(kitti, oracle):
     h.set_output_order(False)
     h.estimate_ground_batch([frames[0]], mode=pwpp_hip.MODE_FRESH)
     assert np.array_equal(np.sort(h.ground_indices(0)), np.sort(refs[0].ground_idx))
+
+
+@pytest.mark.parametrize("flags", ["16384", "32768"])
+def test_lowest_point_selection_fallbacks(kitti, oracle, flags, monkeypatch):
+    """The one-pass selection of the num_lpr lowest points falls back to a gather pass (a lane held
+    more than four of them) and, if that overflows, to an exact extraction by distinct values (streamed
+    rows) or a radix select (four-waves-per-patch kernel).  The fall-backs are rare on real clouds, so
+    PWPP_DEBUG_FLAGS 16384 / 32768 force them for every patch: the results must not change."""
+    monkeypatch.setenv("PWPP_DEBUG_FLAGS", flags)
+    frames = [kitti[0], kitti[4], kitti[2], kitti[1], kitti[5], kitti[3]]
+    refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(p) for p in frames]
+    h = pwpp_hip.Handle()
+    for plan in ("W16:1023,W64.2:65535", "S16:255,S64:65535", "B64:65535"):
+        monkeypatch.setenv("PWPP_FIT_PLAN", plan)
+        h.estimate_ground_batch(frames[:5] if plan.startswith("B") else frames, mode=pwpp_hip.MODE_FRESH)
+        for i in range(5):
+            assert_frame_equal(h, i, refs[i], frames[i].shape[0])
