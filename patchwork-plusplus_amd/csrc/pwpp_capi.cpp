@@ -615,9 +615,10 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     size_t bin_slots = tp;
     {
         static const bool env_off = std::getenv("PWPP_NO_ONE_PASS") != nullptr;
+        static const int min_frames = std::getenv("PWPP_ONE_PASS_MIN_FRAMES") ? std::atoi(std::getenv("PWPP_ONE_PASS_MIN_FRAMES")) : 5;
         if (h->one_pass_holdoff > 0) {
             --h->one_pass_holdoff;
-        } else if (!env_off && frames > 4 && max_n > 0) {
+        } else if (!env_off && frames >= min_frames && max_n > 0) {
             if (max_n > h->cap_max_n || 2 * (int64_t)max_n < h->cap_max_n) {
                 if ((rc = finish_pending(h))) return rc;
                 if ((rc = build_capacity_table(h, max_n))) return rc;
