@@ -360,8 +360,8 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     bt.cap_off = one_pass ? h->d_cap_off.p : nullptr;
     HIPCHK(hipEventRecord(h->ev_begin, h->stream));
     // zero the histogram, the scatter cursors and the per-frame result counters
-    HIPCHK(hipMemsetAsync(bt.bin_count, 0, slab * sizeof(uint32_t), h->stream));
-    if (!one_pass) HIPCHK(hipMemsetAsync(bt.bin_cursor, 0, slab * sizeof(uint32_t), h->stream));
+    // (count, off, cursor are adjacent slabs: the two-pass path zeroes all three with one call)
+    HIPCHK(hipMemsetAsync(bt.bin_count, 0, (one_pass ? 1 : 3) * slab * sizeof(uint32_t), h->stream));
     HIPCHK(hipMemsetAsync(bt.results, 0, (size_t)frames * sizeof(PwppFrameResult), h->stream));
     if (bt.debug & 4) HIPCHK(hipMemsetAsync(bt.dbg, 0, 64 * sizeof(unsigned long long), h->stream));
     const bool ordered = h->output_order == PWPP_ORDER_REFERENCE;
@@ -627,8 +627,9 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
             size_t free_b = 0, total_b = 0;
             const size_t per_slot = sizeof(PwppXyz) + 2 * sizeof(int32_t);
             const size_t held = (h->d_sorted_xyz.cap + h->d_sorted_idx.cap + h->d_plist.cap) * sizeof(int32_t) + h->d_sorted_xyz.cap * 2 * sizeof(int32_t);
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (want + want / 8 + 64) * per_slot * 21 / 20 <= free_b + held &&
-                want < ((size_t)1 << 40)) {
+            const bool have = h->d_sorted_xyz.cap >= want + 16 && h->d_sorted_idx.cap >= want && h->d_plist.cap >= want;  // already allocated
+            if (have || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (want + want / 8 + 64) * per_slot * 21 / 20 <= free_b + held &&
+                         want < ((size_t)1 << 40))) {
                 one_pass = true;
                 bin_slots = want;
             }
