@@ -631,7 +631,8 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
         } else if (!env_off && frames >= min_frames && max_n > 0) {
             if (max_n > h->cap_max_n || 2 * (int64_t)max_n < h->cap_max_n) {
                 if ((rc = finish_pending(h))) return rc;
-                if ((rc = build_capacity_table(h, max_n))) return rc;
+                // (an eighth of headroom: frames of a sensor differ by a few hundred points, the table should not follow them)
+                if ((rc = build_capacity_table(h, max_n + max_n / 8))) return rc;
             }
             const size_t want = (size_t)frames * (size_t)h->slots_per_frame;
             size_t free_b = 0, total_b = 0;
