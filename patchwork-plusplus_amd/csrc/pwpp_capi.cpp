@@ -270,8 +270,8 @@ int finish_pending(pwpp_handle *h);
 
 // Segment sizes of the one-pass path for batches whose largest frame has max_n points: a bin of zone
 // k gets `scale` times its even share of such a frame (KITTI: the fullest bin holds 2.0x the even
-// share of its zone; default scale 4), the two pseudo-bins (RNR hits, out-of-range points) an eighth
-// of the frame each.  PWPP_ONE_PASS_SCALE overrides the scale (tests use a tiny one to force the
+// share of its zone; default scale 4), the two pseudo-bins (RNR hits, out-of-range points) a whole
+// frame each.  PWPP_ONE_PASS_SCALE overrides the scale (tests use a tiny one to force the
 // overflow path).
 int build_capacity_table(pwpp_handle *h, int max_n) {
     const PwppDevParams &P = h->dp;
@@ -290,7 +290,8 @@ int build_capacity_table(pwpp_handle *h, int max_n) {
             const int bins_k = P.bin_base[k + 1] - P.bin_base[k];
             cap = scale * (double)max_n / (double)(bins_k > 0 ? bins_k : 1) + 64.0;
         } else {
-            cap = (double)max_n / 8.0 + 64.0;
+            cap = (double)max_n;  // RNR hits / out-of-range points: a sensor that sees further than max_range leaves
+                                  // a third of its points here, so these two can hold a whole frame each
         }
         if (cap > (double)max_n) cap = (double)max_n;
         run += ((uint64_t)cap + 15u) & ~(uint64_t)15u;
