@@ -588,3 +588,25 @@ def test_lowest_point_selection_fallbacks(kitti, oracle, flags, monkeypatch):
         h.estimate_ground_batch(frames[:5] if plan.startswith("B") else frames, mode=pwpp_hip.MODE_FRESH)
         for i in range(5):
             assert_frame_equal(h, i, refs[i], frames[i].shape[0])
+
+
+def test_size_extremes(oracle):
+    """The largest frame the C-ABI accepts (4 194 304 points: bins far beyond 65 535 points go to the
+    workgroup kernel) and a batch of 60 tiny frames around one of 2 M points (the one-pass capacities
+    follow the largest frame); bit-exact against the oracle."""
+    rng = np.random.default_rng(3)
+    base = pwpp_synth.make_cloud(5, beams=64, azimuth_steps=2000)
+    reps = 4194304 // base.shape[0] + 1
+    big = np.concatenate([base + rng.normal(0, 0.01, base.shape).astype(np.float32) for _ in range(reps)])[:4194304]
+    h = pwpp_hip.Handle()
+    h.estimate_ground_batch([big], mode=pwpp_hip.MODE_FRESH)
+    assert_frame_equal(h, 0, ol.Estimator(oracle, arith=ol.ARITH_FXP).run(big), big.shape[0])
+    tiny = [base[rng.choice(base.shape[0], 800, replace=False)] for _ in range(60)]
+    mix = tiny[:30] + [big[:2000000]] + tiny[30:]
+    h2 = pwpp_hip.Handle()
+    h2.estimate_ground_batch(mix, mode=pwpp_hip.MODE_FRESH)
+    counts = h2.all_counts()
+    for i, pts in enumerate(mix):
+        assert counts[i, 0] + counts[i, 1] + counts[i, 5] == pts.shape[0]
+    for i in (5, 30, 60):
+        assert_frame_equal(h2, i, ol.Estimator(oracle, arith=ol.ARITH_FXP).run(mix[i]), mix[i].shape[0])
