@@ -610,3 +610,34 @@ def test_size_extremes(oracle):
         assert counts[i, 0] + counts[i, 1] + counts[i, 5] == pts.shape[0]
     for i in (5, 30, 60):
         assert_frame_equal(h2, i, ol.Estimator(oracle, arith=ol.ARITH_FXP).run(mix[i]), mix[i].shape[0])
+
+
+def test_long_sequence_history_trimming(kitti, oracle):
+    """60 consecutive frames on one stateful object and on six lock-step streams: the A-GLE histories
+    outgrow max_elevation_storage / max_flatness_storage (1000) after ~25 frames, so the front of the
+    history is erased every frame from then on (ref :354-355, :372-373); thresholds, sensor height and
+    the histories themselves must keep following the sequential oracle bit for bit."""
+    h = pwpp_hip.Handle()
+    est = ol.Estimator(oracle, arith=ol.ARITH_FXP)
+    for t in range(60):
+        pts = kitti[t % 6]
+        h.estimate_ground(pts)
+        ref = est.run(pts)
+        if t % 7 == 0 or t > 54:
+            assert_frame_equal(h, 0, ref, pts.shape[0], state_index=0)
+        else:
+            st = h.state(0)
+            assert st.sensor_height == ref.sensor_height and list(st.elevation_thr) == list(ref.elevation_thr)
+            assert list(st.flatness_thr) == list(ref.flatness_thr)
+    assert max(len(a) for a in ref.hist_elev) == 1000   # the trimming really happened
+    S = 6
+    hs = pwpp_hip.Handle()
+    hs.set_num_streams(S)
+    ests = [ol.Estimator(oracle, arith=ol.ARITH_FXP) for _ in range(S)]
+    for t in range(45):
+        frames = [kitti[(s + t) % 6] for s in range(S)]
+        hs.estimate_ground_batch(frames, mode=pwpp_hip.MODE_STREAMS)
+        refs = [ests[s].run(frames[s]) for s in range(S)]
+        if t % 11 == 0 or t > 41:
+            for s in range(S):
+                assert_frame_equal(hs, s, refs[s], frames[s].shape[0], state_index=s)
