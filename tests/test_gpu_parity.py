@@ -164,6 +164,13 @@ PARAM_VARIANTS = [
     # and planes that come out vertical almost always (strip -> the stashed seed totals are dropped)
     dict(th_seeds_v=0.05), dict(th_seeds=0.25, th_seeds_v=0.25), dict(th_seeds_v=0.6, th_seeds=0.05),
     dict(uprightness_thr=0.9999, th_dist_v=0.3), dict(uprightness_thr=0.9999, th_dist_v=0.02, num_iter=2),
+    # the edges of what pwpp_create accepts (tools/param_extremes.py has more)
+    dict(sectors=(128, 128, 128, 128), rings=(4, 4, 4, 4)),   # 2048 bins
+    dict(sectors=(1, 1, 1, 1), rings=(1, 1, 1, 1)),           # 4 bins of 10-80 k points: the workgroup kernel
+    dict(max_range=200.0, min_range=0.3),                     # fixed-point shift 15
+    dict(max_range=20.0, min_range=5.0),                      # most points out of range
+    dict(num_lpr=64, num_iter=7, th_seeds=0.02, th_dist=0.02), dict(num_min_pts=5000), dict(uprightness_thr=1.0),
+    dict(RNR_ver_angle_thr=10.0, RNR_intensity_thr=2.0),      # RNR takes almost everything below the sensor
 ]
 
 
