@@ -181,13 +181,16 @@ class Handle:
         self._check(self._L.pwpp_estimate_ground(self._h, _vp(pts), pts.shape[0], pts.shape[1], layout))
 
     def estimate_ground_batch(self, frames, mode=MODE_FRESH):
-        """Host frames (list of (n,cols) float32 C-contiguous arrays), synchronous."""
-        frames = [np.ascontiguousarray(f, dtype=np.float32) for f in frames]
+        """Host frames (list of (n,cols) float32 arrays, all C-contiguous or all Fortran-contiguous =
+        Eigen::MatrixXf storage), synchronous."""
+        col_major = all(f.dtype == np.float32 and f.flags["F_CONTIGUOUS"] and not f.flags["C_CONTIGUOUS"] for f in frames)
+        if not col_major:
+            frames = [np.ascontiguousarray(f, dtype=np.float32) for f in frames]
         cols = frames[0].shape[1]
         ptrs = (ctypes.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
         ns = (ctypes.c_int32 * len(frames))(*[f.shape[0] for f in frames])
-        self._check(self._L.pwpp_estimate_ground_batch(self._h, ptrs, ns, len(frames), cols, LAYOUT_ROW_MAJOR,
-                                                       MEM_HOST, mode))
+        self._check(self._L.pwpp_estimate_ground_batch(self._h, ptrs, ns, len(frames), cols,
+                                                       LAYOUT_COL_MAJOR if col_major else LAYOUT_ROW_MAJOR, MEM_HOST, mode))
 
     def submit_pinned_batch(self, frames, mode=MODE_FRESH):
         """Frames in page-locked host memory (pinned_empty): copies and launches are only enqueued;

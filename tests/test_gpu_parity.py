@@ -222,6 +222,13 @@ def test_layouts_and_three_columns(kitti, oracle):
         h = pwpp_hip.Handle(p)
         h.estimate_ground(arr)
         assert_frame_equal(h, 0, ref, pts.shape[0], state_index=0)
+    # the same layouts as batches (one-pass binning reads them through the same accessor)
+    refs = [ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(k) for k in kitti]
+    hb = pwpp_hip.Handle(p)
+    for conv in (lambda k: np.ascontiguousarray(k[:, :3]), np.asfortranarray, lambda k: np.asfortranarray(k[:, :3])):
+        hb.estimate_ground_batch([conv(k) for k in kitti], mode=pwpp_hip.MODE_FRESH)
+        for i in range(6):
+            assert_frame_equal(hb, i, refs[i], kitti[i].shape[0])
     # with RNR on, a 3-column cloud skips RNR (ref :379-382) but must still work
     h = pwpp_hip.Handle()
     h.estimate_ground(pts[:, :3].copy())
