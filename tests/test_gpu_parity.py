@@ -655,3 +655,35 @@ def test_long_sequence_history_trimming(kitti, oracle):
         if t % 11 == 0 or t > 41:
             for s in range(S):
                 assert_frame_equal(hs, s, refs[s], frames[s].shape[0], state_index=s)
+
+
+def test_handle_reuse_across_modes_and_sizes(kitti, oracle):
+    """One handle, interleaved: lock-step streams, a fresh batch (one-pass), a single fresh frame, a
+    bigger fresh batch, reference-order mode on and off.  The streams' adaptive state lives in its own
+    slabs and must not notice any of it; every result equals the oracle's."""
+    S = 3
+    h = pwpp_hip.Handle()
+    h.set_num_streams(S)
+    ests = [ol.Estimator(oracle, arith=ol.ARITH_FXP) for _ in range(S)]
+    fresh_refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(k) for k in kitti]
+
+    def step(t):
+        frames = [kitti[(s + t) % 6] for s in range(S)]
+        h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_STREAMS)
+        for s in range(S):
+            assert_frame_equal(h, s, ests[s].run(frames[s]), frames[s].shape[0], state_index=s)
+
+    step(0)
+    step(1)
+    h.estimate_ground_batch([kitti[i % 6] for i in range(7)], mode=pwpp_hip.MODE_FRESH)
+    for i in range(7):
+        assert_frame_equal(h, i, fresh_refs[i % 6], kitti[i % 6].shape[0], check_state=False)
+    step(2)
+    h.set_output_order(True)
+    h.estimate_ground_batch([kitti[4]], mode=pwpp_hip.MODE_FRESH)
+    assert np.array_equal(kitti[4][h.ground_indices(0), 2], kitti[4][np.asarray(fresh_refs[4].ground_idx), 2])
+    step(3)
+    h.set_output_order(False)
+    h.estimate_ground_batch([kitti[i % 6] for i in range(20)], mode=pwpp_hip.MODE_FRESH)
+    assert_frame_equal(h, 19, fresh_refs[1], kitti[1].shape[0], check_state=False)
+    step(4)
