@@ -316,6 +316,15 @@ def test_pybind_module_end_to_end(kitti, golden):
         assert abs(pw.getHeight() - golden["f32/seq/%d/state" % k][0]) < 1e-4
         assert pw.getTimeTaken() > 0
     pw.estimateGround(np.asfortranarray(kitti[0]).astype(np.float64))  # any array convertible to float32
+    # extension: the reference's own order inside a patch's part of the lists (z-sorted bins)
+    pw2 = pypatchworkpp.patchworkpp(params)
+    pw2.setReferenceOrder(True)
+    pw2.estimateGround(kitti[3])
+    h = pwpp_hip.Handle()
+    h.set_output_order(True)
+    h.estimate_ground_batch([kitti[3]], mode=pwpp_hip.MODE_STREAMS)
+    assert np.array_equal(pw2.getGroundIndices(), h.ground_indices(0))
+    assert np.array_equal(pw2.getNonground(), kitti[3][h.nonground_indices(0), :3])
 
 
 def test_points_on_bin_boundaries(oracle):
