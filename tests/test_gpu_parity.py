@@ -696,3 +696,31 @@ def test_handle_reuse_across_modes_and_sizes(kitti, oracle):
     h.estimate_ground_batch([kitti[i % 6] for i in range(20)], mode=pwpp_hip.MODE_FRESH)
     assert_frame_equal(h, 19, fresh_refs[1], kitti[1].shape[0], check_state=False)
     step(4)
+
+
+def test_error_reporting_on_the_device(kitti):
+    """Misuse comes back as an error code + message (RuntimeError in Python), never as a wrong result:
+    more frames than streams, a misaligned device buffer, unsupported parameters, reading results
+    before anything ran -- and the handle keeps working afterwards."""
+    import torch
+    h = pwpp_hip.Handle()
+    with pytest.raises(pwpp_hip.PwppError, match="no frame"):
+        h.ground_indices(0)
+    with pytest.raises(pwpp_hip.PwppError, match="streams"):
+        h.estimate_ground_batch([kitti[0], kitti[1]], mode=pwpp_hip.MODE_STREAMS)   # one stream by default
+    dev = torch.device("cuda", 0)
+    t = torch.from_numpy(kitti[0]).to(dev)
+    with pytest.raises(pwpp_hip.PwppError, match="aligned"):
+        h.estimate_ground_batch_device([t.data_ptr() + 4], [100])
+    with pytest.raises(pwpp_hip.PwppError, match="order"):
+        h._check(h._L.pwpp_set_output_order(h._h, 7))
+    for bad in (dict(num_zones=3), dict(num_iter=0), dict(num_lpr=65), dict(max_range=1.0, min_range=2.0), dict(max_range=1e7)):
+        p = pwpp_hip.default_params()
+        for k, v in bad.items():
+            setattr(p, k, v)
+        with pytest.raises(pwpp_hip.PwppError):
+            pwpp_hip.Handle(p)
+    h.estimate_ground(kitti[0])   # still usable
+    assert h.counts(0)[0] + h.counts(0)[1] == kitti[0].shape[0]
+    with pytest.raises(pwpp_hip.PwppError, match="out of range"):
+        h.ground_indices(3)
