@@ -724,3 +724,26 @@ def test_error_reporting_on_the_device(kitti):
     assert h.counts(0)[0] + h.counts(0)[1] == kitti[0].shape[0]
     with pytest.raises(pwpp_hip.PwppError, match="out of range"):
         h.ground_indices(3)
+
+
+def test_cpp_class_with_eigen_types(kitti, golden, tmp_path):
+    """The reference's exact C++ signatures (Eigen::MatrixXf in, Eigen::MatrixX3f / Eigen::VectorXi out)
+    of the class mirror.  Eigen is not in this image; the program is compiled against the test
+    infrastructure's stand-in for the Eigen API (oracle/eigen_shim, column-major like Eigen)."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "patchwork-plusplus_amd")
+    exe = str(tmp_path / "demo_eigen")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "oracle", "eigen_shim"), "-I", os.path.join(pkg, "include"),
+                    "-I", os.path.join(root, "include"), "-o", exe, os.path.join(pkg, "examples", "demo_eigen.cpp"),
+                    "-L", os.path.join(pkg, "lib"), "-lpwpp_hip", "-Wl,-rpath," + os.path.join(pkg, "lib")], check=True)
+    path = tmp_path / "000000.bin"
+    kitti[0].tofile(path)
+    out = subprocess.run([exe, str(path)], capture_output=True, text=True, check=True).stdout
+    ng = int(re.search(r"Ground Points\s+#: (\d+)", out).group(1))
+    nn = int(re.search(r"Nonground Points #: (\d+)", out).group(1))
+    npatch = int(re.search(r"patches: (\d+)", out).group(1))
+    assert [ng, nn, npatch] == list(golden["f32/fresh/0/counts"])
+    assert "aligned: 1" in out
