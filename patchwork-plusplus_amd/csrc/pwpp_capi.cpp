@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -91,7 +92,7 @@ struct PinnedBuf {
 const char *kKernelNames[PWPP_NUM_KERNELS] = {"k_czm_bin", "k_czm_scan", "k_czm_scatter", "k_fit_w64<16,64>", "k_fit_w64<64,2>",
                                               "k_fit[2]", "k_fit[3]", "k_fit[4]", "k_fit_stream", "k_gle_tgr", "k_emit"};  // fit slots: default PWPP_FIT_PLAN
 
-bool g_slot0_one_pass = false;
+std::atomic<bool> g_slot0_one_pass{false};  // diagnostic only (pwpp_kernel_name); handles on different threads may race to set it
 
 }  // namespace
 

@@ -533,6 +533,30 @@ __device__ void mean_stdev(const double *v, int n, double &mean, double &stdev) 
     stdev = sqrt(stdev);
 }
 
+// The same for values that already sit in LDS (stride in doubles): batches of sixteen reads, the
+// tail masked instead of walked one dependent read at a time.
+__device__ void mean_stdev_lds(const double *v, int stride, int n, double &mean, double &stdev) {  // ref :557-566
+    if (n <= 1) return;
+    double acc = 0.0;
+    for (int i = 0; i < n; i += 16) {
+        double t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = i + k < n ? v[(i + k) * stride] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = i + k < n ? acc + t[k] : acc;
+    }
+    mean = acc / n;
+    for (int i = 0; i < n; i += 16) {
+        double t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = i + k < n ? v[(i + k) * stride] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) stdev = i + k < n ? stdev + (t[k] - mean) * (t[k] - mean) : stdev;
+    }
+    stdev /= n - 1;
+    stdev = sqrt(stdev);
+}
+
 __global__ __launch_bounds__(64) void k_gle_tgr_seq(PwppBatch Bt) {
     __shared__ double s_ring_flat[PWPP_MAX_NEAR_BINS];
     __shared__ uint8_t s_dec[PWPP_MAX_BINS];
@@ -827,7 +851,8 @@ __device__ __forceinline__ void block_excl_scan(unsigned v[K], unsigned (*s_wave
 
 __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     __shared__ uint8_t s_dec[PWPP_MAX_BINS];
-    __shared__ unsigned s_e[4][PWPP_MAX_BINS + 1];   // exclusive prefixes: gmain, gtail, nmain, ntail
+    __shared__ __attribute__((aligned(16))) unsigned s_e[4][PWPP_MAX_BINS + 1];   // exclusive prefixes: gmain, gtail, nmain, ntail;
+                                                                                // later the staging tile of the histories
     __shared__ unsigned s_epush[PWPP_MAX_NEAR_BINS + 1];
     __shared__ double s_pseq[PWPP_MAX_NEAR_BINS];     // flatness of the pushed patches, in push order
     __shared__ unsigned s_wave[kBlock / 64][4];
@@ -835,6 +860,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     __shared__ int s_ring_first[PWPP_MAX_ROI + 1];    // first bin of near ring ci; [roi] = end
     __shared__ unsigned s_ring_cand[PWPP_MAX_ROI];
     __shared__ double s_ring_mean[PWPP_MAX_ROI], s_ring_std[PWPP_MAX_ROI];
+    __shared__ unsigned s_seg_begin[PWPP_MAX_ROI], s_seg_end[PWPP_MAX_ROI];  // slice of s_pseq behind the statistics of ring ci
     __shared__ int s_len0[2][PWPP_MAX_ROI];           // history lengths before this frame
     const int f = blockIdx.x;
     const PwppDevParams &P = Bt.P;
@@ -889,24 +915,38 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     const int near_end = s_ring_first[roi];  // bins [0, near_end) are "near" (concentric_idx < roi)
 
     // ---- pass 1: per-bin GLE (ref :217-282) ------------------------------------------------
-    const int b0 = threadIdx.x * kGlePer;
+    // Consecutive bins per thread: as few as cover the model (2 for the default 504 bins), so that a
+    // single frame keeps all four waves busy instead of one thread walking eight bins.  Everything a
+    // bin needs from global memory (its count, its patch record) is fetched once, up front and
+    // unconditionally: the kernel is a latency chain, every dependent round trip costs ~1 us.
+    const int per = (B + kBlock - 1) / kBlock;
+    const int b0 = threadIdx.x * per;
     unsigned a_patch = 0, a_push = 0;
     uint8_t dec[kGlePer];
     int ci_of[kGlePer];
+    unsigned nn[kGlePer];
+    PwppPatchRec rr[kGlePer];
+#pragma unroll
+    for (int j = 0; j < kGlePer; ++j) {
+        const int bin = b0 + j;
+        const bool have = j < per && bin < B;
+        nn[j] = have ? cnt[bin] : 0u;
+        rr[j] = recs[have ? bin : 0];
+    }
 #pragma unroll
     for (int j = 0; j < kGlePer; ++j) {
         const int bin = b0 + j;
         dec[j] = 0;
         ci_of[j] = 0;
-        if (bin >= B) continue;
-        const unsigned n = cnt[bin];
+        if (j >= per || bin >= B) continue;
+        const unsigned n = nn[j];
         if ((uint64_t)n < P.min_pts) continue;  // small bin
         // concentric index of the bin
         const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
         int ci = (bin - P.bin_base[zone]) / P.sectors[zone];
         for (int z = 0; z < zone; ++z) ci += P.rings[z];
         ci_of[j] = ci;
-        const PwppPatchRec r = recs[bin];
+        const PwppPatchRec &r = rr[j];
         const double uprightness = r.normal[2];
         const double elevation = r.mean[2];
         float fmin3 = r.sv[0];
@@ -947,10 +987,11 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
 #pragma unroll
         for (int j = 0; j < kGlePer; ++j) {
             const int bin = b0 + j;
+            if (j >= per) continue;
             if (bin < near_end) s_epush[bin] = p_push;
             if (bin < B) s_dec[bin] = dec[j];
             if (dec[j] == 0) continue;
-            const PwppPatchRec r = recs[bin];
+            const PwppPatchRec &r = rr[j];
             for (int i = 0; i < 3; ++i) {  // ref :211-212
                 centers[p_patch * 3 + i] = r.mean[i];
                 normals[p_patch * 3 + i] = r.normal[i];
@@ -978,7 +1019,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         const int ci = ci_of[j];
         const int pos = (int)(s_epush[bin] - s_epush[s_ring_first[ci]]);
         const int e = s_len0[0][ci] + pos, fl = s_len0[1][ci] + pos;
-        const PwppPatchRec r = recs[bin];
+        const PwppPatchRec &r = rr[j];
         if (e < P.hist_cap && fl < P.hist_cap) {
             hist_out[(0 * 4 + ci) * P.hist_cap + e] = (double)r.mean[2];
             hist_out[(1 * 4 + ci) * P.hist_cap + fl] = s_pseq[s_epush[bin]];
@@ -998,16 +1039,47 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
             if (nf > P.hist_cap) nf = P.hist_cap;
             s_st.elev_len[ci] = ne;
             s_st.flat_len[ci] = nf;
-            if (s_ring_cand[ci]) {
-                double m = 0.0, sd = 0.0;
-                mean_stdev(s_pseq + begin, (int)(end - begin), m, sd);  // ref :407-408
-                s_ring_mean[ci] = m;
-                s_ring_std[ci] = sd;
-                begin = end;
-            }
+            s_seg_begin[ci] = begin;
+            s_seg_end[ci] = end;
+            if (s_ring_cand[ci]) begin = end;
         }
     }
     __syncthreads();
+    if ((int)threadIdx.x < roi && s_ring_cand[threadIdx.x]) {  // one lane per ring with candidates
+        double m = 0.0, sd = 0.0;
+        const unsigned begin = s_seg_begin[threadIdx.x];
+        mean_stdev_lds(s_pseq + begin, 1, (int)(s_seg_end[threadIdx.x] - begin), m, sd);  // ref :407-408
+        s_ring_mean[threadIdx.x] = m;
+        s_ring_std[threadIdx.x] = sd;
+    }
+    __syncthreads();
+
+    // The histories are complete now (this frame's pushes included): start fetching their first tile
+    // for the threshold statistics at the end of the kernel, the loads fly while TGR and the list
+    // offsets are worked out.
+    constexpr int kHistTile = 496, kHistStride = 498;  // 8 rows, 16-byte aligned, on distinct LDS banks
+    constexpr int kHistPer = (kHistTile + kBlock - 1) / kBlock;
+    static_assert(sizeof(s_e) >= sizeof(double) * 8 * kHistStride, "history tile must fit into the retired s_e");
+    int len_w[8], maxlen = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        len_w[w] = (w & 3) < roi ? (w < 4 ? s_st.elev_len[w] : s_st.flat_len[w - 4]) : 0;
+        if (len_w[w] <= 1) len_w[w] = 0;  // mean_stdev leaves (0, 0) behind, ref :558
+        maxlen = len_w[w] > maxlen ? len_w[w] : maxlen;
+    }
+    const int my_len = threadIdx.x < 8 ? len_w[threadIdx.x & 7] : 0;
+    const int ntiles = (maxlen + kHistTile - 1) / kHistTile;
+    double v[8][kHistPer];
+    auto fetch = [&](int base) {  // unconditional loads (clamped), all in flight together
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+#pragma unroll
+            for (int q = 0; q < kHistPer; ++q) {
+                const int i = base + q * kBlock + (int)threadIdx.x;
+                v[w][q] = hist_out[(size_t)w * P.hist_cap + (i < len_w[w] ? i : 0)];
+            }
+    };
+    if (ntiles > 0) fetch(0);
 
     // ---- pass 2: TGR (ref :416-461) and what each bin appends to which list -----------------
     unsigned q4[4] = {0, 0, 0, 0};  // gmain, gtail, nmain, ntail of this thread's bins
@@ -1016,13 +1088,13 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     for (int j = 0; j < kGlePer; ++j) {
         const int bin = b0 + j;
         gm[j] = gt[j] = nm[j] = nt[j] = 0;
-        if (bin >= B) continue;
-        const unsigned n = cnt[bin];
+        if (j >= per || bin >= B) continue;
+        const unsigned n = nn[j];
         int d = dec[j] & 0x7f;
         if (d == 0) {
             nm[j] = n;  // small bin, whole (ref :193)
         } else {
-            const PwppPatchRec r = recs[bin];
+            const PwppPatchRec &r = rr[j];
             const unsigned ng = (unsigned)r.n_ground;
             if (d == 5 && P.enable_TGR) {
                 const int ci = ci_of[j];
@@ -1060,7 +1132,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
 #pragma unroll
         for (int j = 0; j < kGlePer; ++j) {
             const int bin = b0 + j;
-            if (bin >= B) continue;
+            if (j >= per || bin >= B) continue;
             for (int q = 0; q < 4; ++q) s_e[q][bin] = run[q];
             run[0] += gm[j];
             run[1] += gt[j];
@@ -1077,7 +1149,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
 #pragma unroll
     for (int j = 0; j < kGlePer; ++j) {
         const int bin = b0 + j;
-        if (bin >= B) continue;
+        if (j >= per || bin >= B) continue;
         const int d = dec[j];
         // ring of this bin: its first bin and the first bin of the next ring
         const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
@@ -1088,7 +1160,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
             dst_a[bin] = nmain_at;
             dst_b[bin] = 0;
         } else {
-            const unsigned ng = (unsigned)recs[bin].n_ground;
+            const unsigned ng = (unsigned)rr[j].n_ground;
             if (d == 1 || d == 3) {
                 dst_a[bin] = nmain_at;
                 dst_b[bin] = nmain_at + ng;
@@ -1117,13 +1189,67 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     // ---- adaptive thresholds for the next frame of this stream (ref :338-375) ---------------
     // lanes 0..3: elevation history of ring i, lanes 4..7: flatness history; sequential sums
     __shared__ double s_mean[8], s_std[8];
-    if (threadIdx.x < 8) {
-        const int which = threadIdx.x >> 2, i = threadIdx.x & 3;
-        double m = 0.0, sd = 0.0;
-        const int len = which == 0 ? s_st.elev_len[i] : s_st.flat_len[i];
-        if (i < roi) mean_stdev(hist_out + (which * 4 + i) * P.hist_cap, len, m, sd);
-        s_mean[threadIdx.x] = m;
-        s_std[threadIdx.x] = sd;
+    // The eight histories (up to max_*_storage + one frame's pushes each) live in global memory, and the
+    // reference's sums over them are sequential: one lane per history, ~2 x 1000 dependent f64 adds.
+    // Everything else is taken off that chain: all threads stage the histories through LDS in tiles
+    // (the next tile's loads are in flight while the current one is summed), and for the second pass
+    // they also square the deviations, so the summing lanes execute one add per value.
+    {
+        double *tile = reinterpret_cast<double *>(&s_e[0][0]);
+        double acc = 0.0, mean = 0.0;
+        for (int step = 0; step < 2 * ntiles; ++step) {
+            const int pass = step >= ntiles ? 1 : 0;
+            const int base = (step - pass * ntiles) * kHistTile;
+            __syncthreads();  // the previous tile has been summed; the means of pass 0 are in s_mean
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const double m = s_mean[w];
+#pragma unroll
+                for (int q = 0; q < kHistPer; ++q) {
+                    const int i = q * kBlock + (int)threadIdx.x;
+                    if (i < kHistTile) tile[w * kHistStride + i] = pass ? (v[w][q] - m) * (v[w][q] - m) : v[w][q];  // ref :564
+                }
+            }
+            __syncthreads();
+            if (step + 1 < 2 * ntiles) fetch(((step + 1) % ntiles) * kHistTile);
+            if (threadIdx.x < 8) {
+                const int left = my_len - base;
+                const int cnt_here = left < 0 ? 0 : (left < kHistTile ? left : kHistTile);
+                const double *row = tile + threadIdx.x * kHistStride;
+                int i = 0;
+                for (; i + 16 <= cnt_here; i += 16) {
+                    double2 t[8];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; ++k2) t[k2] = *reinterpret_cast<const double2 *>(row + i + 2 * k2);
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; ++k2) {
+                        acc += t[k2].x;
+                        acc += t[k2].y;
+                    }
+                }
+                if (i < cnt_here) {  // last, partial batch of the tile
+                    double t[16];
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) t[k2] = row[i + k2];
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) acc = i + k2 < cnt_here ? acc + t[k2] : acc;
+                }
+                if (step == ntiles - 1) {  // ref :561
+                    mean = my_len > 0 ? acc / my_len : 0.0;
+                    s_mean[threadIdx.x] = mean;
+                    acc = 0.0;
+                }
+            }
+        }
+        if (threadIdx.x < 8) {
+            double sd = 0.0;
+            if (my_len > 0) {
+                sd = acc / (my_len - 1);  // ref :565
+                sd = sqrt(sd);
+            }
+            s_mean[threadIdx.x] = mean;
+            s_std[threadIdx.x] = sd;
+        }
     }
     __syncthreads();
     __shared__ int s_shift[8];
@@ -1157,17 +1283,32 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         Bt.st_scalar[fd.state_out] = s_st;
     }
     __syncthreads();
-    for (int w = 0; w < 8; ++w) {  // erase(begin, begin + exceed), ref :354-355,372-373
-        const int sh = s_shift[w];
-        if (sh <= 0) continue;
-        double *h = hist_out + w * P.hist_cap;
-        const int newlen = w < 4 ? s_st.elev_len[w] : s_st.flat_len[w - 4];
-        for (int base = 0; base < newlen; base += kBlock) {
-            const int i = base + threadIdx.x;
-            double v = 0.0;
-            if (i < newlen) v = h[i + sh];
+    {  // erase(begin, begin + exceed), ref :354-355,372-373: every history at once, loads before stores
+        constexpr int kErasePer = 4;
+        int sh_w[8], new_w[8], maxnew = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            sh_w[w] = s_shift[w];
+            new_w[w] = sh_w[w] > 0 ? (w < 4 ? s_st.elev_len[w] : s_st.flat_len[w - 4]) : 0;
+            maxnew = new_w[w] > maxnew ? new_w[w] : maxnew;
+        }
+        for (int base = 0; base < maxnew; base += kErasePer * kBlock) {
+            double e[8][kErasePer];
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+#pragma unroll
+                for (int q = 0; q < kErasePer; ++q) {
+                    const int i = base + q * kBlock + (int)threadIdx.x;
+                    e[w][q] = hist_out[(size_t)w * P.hist_cap + (i < new_w[w] ? i + sh_w[w] : 0)];
+                }
             __syncthreads();
-            if (i < newlen) h[i] = v;
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+#pragma unroll
+                for (int q = 0; q < kErasePer; ++q) {
+                    const int i = base + q * kBlock + (int)threadIdx.x;
+                    if (i < new_w[w]) hist_out[(size_t)w * P.hist_cap + i] = e[w][q];
+                }
             __syncthreads();
         }
     }

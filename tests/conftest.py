@@ -5,6 +5,15 @@ import sys
 import numpy as np
 import pytest
 
+try:
+    # Load order matters when torch shares the process (two tests keep their input in torch tensors):
+    # the PyTorch wheel bundles its own ROCm runtime under the same SONAMEs as /opt/rocm's, and whichever
+    # libamdhip64 is mapped first serves both.  torch cannot start on /opt/rocm's copy, libpwpp_hip.so is
+    # happy with either, so torch goes first.
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)

@@ -698,6 +698,50 @@ def test_handle_reuse_across_modes_and_sizes(kitti, oracle):
     step(4)
 
 
+def test_handles_on_concurrent_host_threads(kitti, oracle):
+    """SURVEY section 8b, threading: distinct objects are independent (the reference has no globals), so
+    four host threads each drive their own handle -- a stateful sequence, then a fresh batch big enough
+    for the one-pass binning -- at the same time (ctypes drops the GIL around every call).  Results are
+    collected inside the threads and compared with the oracle afterwards."""
+    import threading
+    T = 4
+    seq_refs, fresh_refs = [], [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(k) for k in kitti]
+    for t in range(T):
+        est = ol.Estimator(oracle, arith=ol.ARITH_FXP)
+        seq_refs.append([est.run(kitti[(t + j) % 6]) for j in range(4)])
+    got, errors = [None] * T, []
+
+    def worker(t):
+        try:
+            h = pwpp_hip.Handle()
+            out = []
+            for j in range(4):
+                h.estimate_ground(kitti[(t + j) % 6])
+                out.append((np.sort(h.ground_indices(0)), h.normals(0).copy(), h.height()))
+            order = [(t + i) % 6 for i in range(6 + t)]
+            h.estimate_ground_batch([kitti[k] for k in order], mode=pwpp_hip.MODE_FRESH)
+            batch = [(np.sort(h.ground_indices(i)), h.normals(i).copy()) for i in range(len(order))]
+            got[t] = (out, order, batch)
+        except Exception as e:  # surfaced on the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(T):
+        out, order, batch = got[t]
+        for j, (gi, nrm, height) in enumerate(out):
+            ref = seq_refs[t][j]
+            assert np.array_equal(gi, np.sort(np.asarray(ref.ground_idx))) and height == ref.sensor_height
+            assert np.array_equal(nrm, ref.normals, equal_nan=True)
+        for (gi, nrm), k in zip(batch, order):
+            assert np.array_equal(gi, np.sort(np.asarray(fresh_refs[k].ground_idx)))
+            assert np.array_equal(nrm, fresh_refs[k].normals, equal_nan=True)
+
+
 def test_error_reporting_on_the_device(kitti):
     """Misuse comes back as an error code + message (RuntimeError in Python), never as a wrong result:
     more frames than streams, a misaligned device buffer, unsupported parameters, reading results
