@@ -375,7 +375,10 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     // (count, off, cursor are adjacent slabs: the two-pass path zeroes all three with one call)
     HIPCHK(hipMemsetAsync(bt.bin_count, 0, (one_pass ? 1 : 3) * slab * sizeof(uint32_t), h->stream));
     HIPCHK(hipMemsetAsync(bt.results, 0, (size_t)frames * sizeof(PwppFrameResult), h->stream));
-    if (bt.debug & 4) HIPCHK(hipMemsetAsync(bt.dbg, 0, 64 * sizeof(unsigned long long), h->stream));
+    if (bt.debug & 4) {
+        HIPCHK(hipMemsetAsync(bt.dbg, 0, 64 * sizeof(unsigned long long), h->stream));
+        HIPCHK(hipMemsetAsync(bt.dbg + 60, 0xFF, sizeof(unsigned long long), h->stream));  // slot 60 is a minimum
+    }
     const bool ordered = h->output_order == PWPP_ORDER_REFERENCE;
     const int lrc = pwpp_launch_pipeline(&bt, h->stream, h->profiling ? h->ev_k : nullptr, h->aux_stream, h->aux_fork, h->aux_join,
                                          ordered ? h->d_ord_a.p : nullptr, ordered ? h->d_ord_b.p : nullptr);

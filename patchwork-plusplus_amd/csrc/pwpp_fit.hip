@@ -666,13 +666,13 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
 }
 
 template <int G>
-__global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo, int b_hi) {
+__device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, int b_hi, unsigned by /* block index among the row blocks */) {
     const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
     const PwppDevParams &P = Bt.P;
     const int NB = P.num_bins + 2;
     const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
     const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
-    const unsigned tid = blockIdx.y * kBlock + threadIdx.x;
+    const unsigned tid = by * kBlock + threadIdx.x;
     if (cbeg + (tid & ~63u) / G >= cend) return;  // this wave has no patch
     const bool alive = cbeg + tid / G < cend;  // row-uniform
     // largest patches first: the list is sorted by size, a wave's run time grows with its patch,
@@ -798,6 +798,11 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo,
             ++it;
         }
     }
+}
+
+template <int G>
+__global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo, int b_hi) {
+    fit_srows_body<G>(Bt, b_lo, b_hi, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1533,7 +1538,12 @@ struct BRowShared {
     unsigned keys[kWaves][PWPP_MAX_LPR];  // every wave's smallest keys, ascending
     unsigned dropped[kWaves];
     int elig[kWaves];
+    double single_sum;   // a patch of one chunk: wave 0's result
+    unsigned single_T;
     unsigned cnt_g, cnt_ng;
+    long long mom2[kWaves][10];  // dual seed pass: the band between the two seed thresholds
+    long long mom_hi[kWaves][6], mom2_hi[kWaves][6];  // patches beyond 65535 points: upper halves of the second moments
+    PlaneFit plane[2];           // R-VPF fit | R-GPF seed fit, solved side by side by different waves
     FitShared fs;  // for block_lpr, the exact fall-back of the lowest-point selection
 };
 
@@ -1544,9 +1554,11 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsi
     const int wv = wave_id(), ln = lane_id();
     unsigned k0 = INF, k1 = INF, k2 = INF, k3 = INF, dropped = INF;
     int elig = 0;
+    ChunkPts cp;
+    load_chunk<64>(cp, pts, n, (unsigned)wv);
     for (unsigned c = (unsigned)wv; c < nchunk; c += kWaves) {
-        ChunkPts cp;
-        load_chunk<64>(cp, pts, n, c);
+        ChunkPts nx;  // the next chunk is in flight while this one is ranked (this is the first, cold touch of the patch)
+        load_chunk<64>(nx, pts, n, c + kWaves);
         const unsigned act = chunk_act(cp);
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
@@ -1559,12 +1571,21 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsi
             dropped = x < dropped ? x : dropped;
             elig += e ? 1 : 0;
         }
+        cp = nx;
     }
     const int total_w = Row<64>::sum_i32(elig);
     const int keff_w = total_w < num_lpr ? total_w : num_lpr;
+    const bool single = nchunk <= 1u;  // only wave 0 holds points (most patches): its list is the result, no merge
+    double sum_w = 0.0;
+    unsigned T_w = 0;
     for (int r = 0; r < keff_w; ++r) {  // this wave's keff_w smallest kept keys, ascending (wave-uniform trip count)
         const unsigned m = Row<64>::min_u32(k0);
-        if (ln == 0) sh.keys[wv][r] = m;
+        if (single) {
+            sum_w += (double)key_z(m);  // ascending, as the reference adds them up (ref :99-101)
+            T_w = m;
+        } else if (ln == 0) {
+            sh.keys[wv][r] = m;
+        }
         const int lowest = __ffsll((long long)__ballot(k0 == m)) - 1;
         if (ln == lowest) {
             k0 = k1;
@@ -1577,8 +1598,20 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsi
     if (ln == 0) {
         sh.dropped[wv] = dmin;
         sh.elig[wv] = total_w;
+        if (single && wv == 0) {
+            sh.single_sum = sum_w;
+            sh.single_T = T_w;
+        }
     }
     __syncthreads();
+    if (single) {
+        const int keff1 = sh.elig[0] < num_lpr ? sh.elig[0] : num_lpr;
+        const unsigned d1 = sh.dropped[0], T1 = sh.single_T;
+        const double s1 = sh.single_sum;
+        __syncthreads();
+        if (keff1 > 0 && (d1 < T1 || force != 0)) return block_lpr(sh.fs, pts, n, use_cutoff, cutoff, num_lpr);
+        return keff1 ? s1 / (double)keff1 : 0.0;  // ref :103
+    }
     // merge the four ascending lists (every thread the same way)
     int total = 0;
     unsigned dall = INF;
@@ -1614,18 +1647,21 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsi
     return keff ? sum / (double)keff : 0.0;  // ref :103
 }
 
-__global__ __launch_bounds__(kBlock, 3) void k_fit_brows(PwppBatch Bt, int b_lo, int b_hi) {
-    __shared__ BRowShared sh;
+__device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &Bt, int b_lo, int b_hi, unsigned by /* block index among the patch blocks */) {
     const int f = blockIdx.x;
     const PwppDevParams &P = Bt.P;
     const int NB = P.num_bins + 2;
     const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
     const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
-    if (cbeg + blockIdx.y >= cend) return;            // workgroup-uniform
-    const unsigned slot = cend - 1u - blockIdx.y;     // largest patches first
+    if (cbeg + by >= cend) return;                    // workgroup-uniform
+    const unsigned slot = cend - 1u - by;             // largest patches first
     const int wv = wave_id(), ln = lane_id();
     const int bin = (int)Bt.cls_list[(size_t)f * P.num_bins + slot];
     const unsigned n = Bt.bin_count[(size_t)f * NB + bin];
+    // (only when this kernel is the plan's last class does it see more than 65535 points: the second
+    // moments of such a patch outgrow int64 once they are added up across lanes, so their 32-bit halves
+    // are reduced separately -- exact, like everything else here)
+    const bool wide = n > 65535u;
     const PwppFrameDesc fd = Bt.frames[f];
     const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
     const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + off);
@@ -1646,21 +1682,49 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_brows(PwppBatch Bt, int b_lo,
     bool lpr_valid = false;
     int kind = (P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED;  // everything below is workgroup-uniform
     int it = 0;
+    // Dual seed pass as in k_fit_w64 (an R-VPF round and the R-GPF seed stage pick their seeds from the
+    // same working set with two thresholds: the pass sums the points below the smaller one and the band
+    // up to the larger one), and because this kernel is a latency chain with four SIMDs to itself, the two
+    // planes are also SOLVED side by side: waves 0-1 fit the R-VPF seeds, waves 2-3 the R-GPF seeds.  If
+    // the R-VPF round removes nothing, the R-GPF seed stage is already done: no pass, no solve.
+    const bool v_is_hi = P.th_seeds_v >= P.th_seeds;
+    bool stash_valid = false;
+    long long stash_cnt = 0;
+    PlaneFit pl_seed = pl;
     if (threadIdx.x == 0) {
         sh.cnt_g = 0;
         sh.cnt_ng = 0;
     }
     __syncthreads();
+    // timing probes (PWPP_DEBUG_FLAGS & 4): the chain of the largest patch of frame 0, (code << 56) | 100 MHz ticks
+    // (PWPP_DEBUG_FLAGS = 4 | size << 16 follows the patch of that size instead of the largest one)
+    const bool probing = (Bt.debug & 4) && blockIdx.x == 0 && threadIdx.x == 0 && ((Bt.debug >> 16) ? n == (unsigned)(Bt.debug >> 16) : by == 0u);
+    if ((Bt.debug & 4) && threadIdx.x == 0) atomicMin(&Bt.dbg[60], wall_clock64());
+    int probe_i = 0;
+    auto probe = [&](unsigned long long code) {
+        if (probing && probe_i < 62) Bt.dbg[probe_i++] = (code << 56) | (wall_clock64() & 0x00FFFFFFFFFFFFFFull);
+    };
+    probe(1);
 
     for (int guard = 0; guard < 4 * P.num_iter + 8 && kind != ST_DONE; ++guard) {
+        if (kind == ST_SEED && stash_valid) {  // ref :513-517 on the unchanged working set: solved above
+            if (stash_cnt > 0) pl = pl_seed;   // an empty seed set leaves the R-VPF plane in place (ref :49)
+            stash_valid = false;
+            kind = ST_ITER;                    // (zone 0: never ST_LAZY)
+            continue;
+        }
         if ((kind == ST_VPF || kind == ST_SEED) && !lpr_valid) {
             lpr = brow_lpr(sh, pts, n, nchunk, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
             lpr_valid = true;
+            probe(2);
         }
-        const double thr_seed = lpr + ((kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds);
+        const bool dual_now = kind == ST_VPF;
+        const double thr_seed = lpr + (dual_now ? (v_is_hi ? P.th_seeds : P.th_seeds_v) : (kind == ST_LAZY ? P.th_seeds_v : P.th_seeds));
+        const double thr_band = lpr + (v_is_hi ? P.th_seeds_v : P.th_seeds);
         const bool last = kind == ST_ITER && it == P.num_iter - 1;
-        Moments m;
+        Moments m, m2;
         m.clear();
+        m2.clear();
         ChunkMoments cm;
         cm.clear();
         unsigned done = 0;
@@ -1675,6 +1739,12 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_brows(PwppBatch Bt, int b_lo,
             if (++done % kFlushChunks == 0u) {
                 cm.flush_into(m);
                 cm.clear();
+            }
+            if (dual_now) {  // the band [thr_seed, thr_band)
+                const unsigned rest = chunk_act(cp) & ~gmask;
+#pragma unroll
+                for (int k = 0; k < kPPT; ++k)
+                    if ((rest >> k & 1u) && (double)cp.lp.z[k] < thr_band) m2.add(cp.lp.x[k], cp.lp.y[k], cp.lp.z[k], qscale);
             }
             if (last) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                 const unsigned ngm = cp.valid & ~gmask;
@@ -1699,38 +1769,105 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_brows(PwppBatch Bt, int b_lo,
             cp = nx;
         }
         cm.flush_into(m);
+        probe(3);
         {   // the wave's sums -> LDS -> totals of the patch (every thread)
-            long long v[10];
-            v[0] = Row<64>::sum_i64(m.n);
+            auto wave_sums = [&](const Moments &mm, long long (*dst)[10], long long (*dst_hi)[6]) {
+                long long v[10];
+                v[0] = Row<64>::sum_i64(mm.n);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) v[1 + k] = Row<64>::sum_i64(m.s1[k]);
+                for (int k = 0; k < 3; ++k) v[1 + k] = Row<64>::sum_i64(mm.s1[k]);
+                if (!wide) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) v[4 + k] = Row<64>::sum_i64(m.s2[k]);
-            if (ln < 10) {
-                long long mine = v[0];
+                    for (int k = 0; k < 6; ++k) v[4 + k] = Row<64>::sum_i64(mm.s2[k]);
+                } else {  // lower halves here, upper halves below
 #pragma unroll
-                for (int k = 1; k < 10; ++k) mine = ln == k ? v[k] : mine;
-                sh.mom[wv][ln] = mine;
+                    for (int k = 0; k < 6; ++k) v[4 + k] = Row<64>::sum_i64(mm.s2[k] & 0xffffffffLL);
+                }
+                if (ln < 10) {
+                    long long mine = v[0];
+#pragma unroll
+                    for (int k = 1; k < 10; ++k) mine = ln == k ? v[k] : mine;
+                    dst[wv][ln] = mine;
+                }
+                if (wide) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) v[k] = Row<64>::sum_i64(mm.s2[k] >> 32);
+                    if (ln < 6) {
+                        long long mine = v[0];
+#pragma unroll
+                        for (int k = 1; k < 6; ++k) mine = ln == k ? v[k] : mine;
+                        dst_hi[wv][ln] = mine;
+                    }
+                }
+            };
+            wave_sums(m, sh.mom, sh.mom_hi);
+            if (dual_now) wave_sums(m2, sh.mom2, sh.mom2_hi);
+        }
+        __syncthreads();
+        const bool spec = dual_now && wv >= kWaves / 2;  // this wave solves the R-GPF seed fit
+        long long tot[4];
+        __int128 s2[6];
+        long long cnt = 0;
+        if (!wide) {  // the usual case: everything fits int64 (<= 65535 points), the solve is entered a few hundred instructions earlier
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                long long a = 0, b = 0;  // a: below the smaller threshold, a + b: below the larger one
+#pragma unroll
+                for (int w2 = 0; w2 < kWaves; ++w2) {
+                    a += sh.mom[w2][k];
+                    if (dual_now) b += sh.mom2[w2][k];
+                }
+                const long long t_vpf = dual_now ? (v_is_hi ? a + b : a) : a;
+                const long long t_seed = v_is_hi ? a : a + b;
+                const long long t = spec ? t_seed : t_vpf;
+                if (k < 4) tot[k] = t;
+                else s2[k - 4] = (__int128)t;
+                if (k == 0) {
+                    cnt = t_vpf;
+                    if (dual_now) stash_cnt = t_seed;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                __int128 a = 0, b = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < kWaves; ++w2) {
+                    a += (__int128)sh.mom[w2][k];
+                    if (dual_now) b += (__int128)sh.mom2[w2][k];
+                    if (k >= 4) {
+                        a += (__int128)sh.mom_hi[w2][k >= 4 ? k - 4 : 0] << 32;
+                        if (dual_now) b += (__int128)sh.mom2_hi[w2][k >= 4 ? k - 4 : 0] << 32;
+                    }
+                }
+                const __int128 t_vpf = dual_now ? (v_is_hi ? a + b : a) : a;
+                const __int128 t_seed = v_is_hi ? a : a + b;
+                const __int128 t = spec ? t_seed : t_vpf;
+                if (k < 4) tot[k] = (long long)t;  // count and first moments: int64 at any size
+                else s2[k - 4] = t;
+                if (k == 0) {
+                    cnt = (long long)t_vpf;
+                    if (dual_now) stash_cnt = (long long)t_seed;
+                }
             }
         }
         __syncthreads();
-        long long tot[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) {
-            long long t = 0;
-#pragma unroll
-            for (int w2 = 0; w2 < kWaves; ++w2) t += sh.mom[w2][k];
-            tot[k] = t;
-        }
-        __syncthreads();
-        const long long cnt = tot[0];
-        if (cnt > 0) {  // empty: ref :49
+        probe(4);
+        PlaneFit fitted = pl;
+        if (tot[0] > 0) {  // empty: ref :49
             const long long s1[3] = {tot[1], tot[2], tot[3]};
-            __int128 s2[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) s2[k] = (__int128)tot[4 + k];  // <= 65535 points: fits int64
-            plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);
+            plane_from_totals(tot[0], s1, s2, P.fxp_shift, Bt.debug, fitted);
         }
+        if (dual_now) {
+            if (ln == 0 && (wv == 0 || wv == kWaves / 2)) sh.plane[wv ? 1 : 0] = fitted;
+            __syncthreads();
+            pl = sh.plane[0];
+            pl_seed = sh.plane[1];
+            stash_valid = true;
+        } else {
+            pl = fitted;
+        }
+        probe(5);
         if (kind == ST_VPF) {
             const bool vertical = (double)pl.nz < P.uprightness_thr;  // ref :489
             if (vertical) {
@@ -1744,7 +1881,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_brows(PwppBatch Bt, int b_lo,
                         if (hit >> k & 1u) strip_point(pts, c * 512u + (unsigned)k * 64u + (unsigned)ln, it);
                     any |= hit != 0u;
                 }
-                if (__syncthreads_or(any)) lpr_valid = false;  // the working set changed (and the marks are visible)
+                if (__syncthreads_or(any)) {  // the working set changed (and the marks are visible)
+                    lpr_valid = false;
+                    stash_valid = false;
+                }
             }
             ++it;
             if (!vertical || it >= P.num_iter) {
@@ -1762,18 +1902,35 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_brows(PwppBatch Bt, int b_lo,
             }
             ++it;
         }
+        probe(6);
     }
+    if (probing) Bt.dbg[62] = n;
+    if ((Bt.debug & 4) && threadIdx.x == 0) atomicMax(&Bt.dbg[61], (wall_clock64() << 24) | (unsigned long long)n);
 }
 
-__global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
-    __shared__ FitShared sh;
-    const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
+__global__ __launch_bounds__(kBlock, 2) void k_fit_brows(PwppBatch Bt, int b_lo, int b_hi) {
+    __shared__ BRowShared sh;
+    fit_brows_body(sh, Bt, b_lo, b_hi, blockIdx.y);
+}
+
+// k_fit_hybrid: the single-frame kernel.  A SIMD retires one instruction every ~5 cycles whoever it
+// belongs to, so two workgroups sharing a CU stretch each other's solve chains (measured: 5.2 -> 9-12 us
+// per solve for the ~45 patches that had to double up when every patch had its own workgroup: a frame has
+// ~300 patches, the chip 256 CUs).  Here only the patches above `b_mid` get four waves (k_fit_brows'
+// body); the small ones, which fit one chunk of one wave anyway, go four to a workgroup, one wave each
+// (k_fit_srows<64>'s body) -- ~110 workgroups per frame, every one alone on its CU, in ONE launch.
+__global__ __launch_bounds__(kBlock, 1) void k_fit_hybrid(PwppBatch Bt, int b_mid, unsigned nb_big) {
+    __shared__ BRowShared sh;
+    if (blockIdx.y < nb_big)
+        fit_brows_body(sh, Bt, b_mid, PWPP_NUM_BUCKETS, blockIdx.y);
+    else
+        fit_srows_body<64>(Bt, 0, b_mid, blockIdx.y - nb_big);
+}
+
+// the whole fit chain of one patch of any size by one workgroup (k_fit_stream; k_fit_brows for what exceeds its rows)
+__device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch &Bt, int f, int bin) {
     const PwppDevParams &P = Bt.P;
     const int NB = P.num_bins + 2;
-    const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
-    const unsigned slot = cs[b_lo] + blockIdx.y;
-    if (slot >= cs[PWPP_NUM_BUCKETS]) return;
-    const int bin = Bt.cls_list[(size_t)f * P.num_bins + slot];
     const unsigned n = Bt.bin_count[(size_t)f * NB + bin];
     PwppPatchRec *rec = Bt.recs + (size_t)f * P.num_bins + bin;
     const PwppFrameDesc fd = Bt.frames[f];
@@ -1907,11 +2064,20 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
     }
 }
 
+__global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
+    __shared__ FitShared sh;
+    const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
+    const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
+    const unsigned slot = cs[b_lo] + blockIdx.y;
+    if (slot >= cs[PWPP_NUM_BUCKETS]) return;
+    fit_stream_patch(sh, Bt, f, (int)Bt.cls_list[(size_t)f * Bt.P.num_bins + slot]);
+}
+
 }  // namespace
 
 // launches of K4; ev (optional) = 7 events recorded around up to six launches
 #define PWPP_DEFAULT_FIT_PLAN "W16:1023,W64.2:65535"
-#define PWPP_LATENCY_FIT_PLAN "B64:65535"
+#define PWPP_LATENCY_FIT_PLAN "H64:1023"
 // `aux` (optional): a second stream + two events, for PWPP_FIT_CONCURRENT (classes of a plan side by side).
 extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
                                hipEvent_t aux_fork, hipEvent_t aux_join) {
@@ -1932,17 +2098,21 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     const char *plan = getenv("PWPP_FIT_PLAN");
     // The right granularity depends on how much work there is to spread over 1024 SIMDs (measured with
     // tools/plan_by_frames.sh on KITTI frames; "frames" below = points of the batch / 125 000):
-    //   <= 6    FOUR waves per patch, every patch at once (k_fit_brows)    (chain latency is what counts)
+    //   <= 9    k_fit_hybrid: four waves per patch above 1023 points, one wave per smaller patch, one launch,
+    //           one workgroup per CU                                         (chain latency is what counts;
+    //           tools/small_batches.py: 1 / 2 / 4 / 8 frames 128 / 133 / 201 / 218 us per call, against
+    //           174 / 184 / 229 / 229 us with the next plan and 134 / 167 / 225 / 323 us with four waves for
+    //           every patch, "B64:65535"; from 12 frames on the next plan wins, 236 vs 307 us)
     //   <= 48   one prefetching wave per patch, every patch at once
     //   <= 320  16 small patches per wave; big bins one wave each         (8 -> 32 waves per frame)
     //   <= 448  16 small patches per wave; big bins two per wave
     //   <= 640  32 small patches per wave; big bins two per wave
     //   more    64 small patches per wave; big bins two per wave          (fewest solve instances)
-    // e.g. 1 frame: 0.153 ms instead of 0.196 with the second plan; 32 frames: 93 k frames/s instead of
+    // e.g. 1 frame: 0.128 ms instead of 0.174 with the second plan; 32 frames: 93 k frames/s instead of
     // 44 k with the last plan; 256 frames: 237 k instead of 208 k.
     if (!plan) {
         const double eff = (double)F * (double)B.max_n / 125000.0;
-        plan = eff <= 6.0 ? PWPP_LATENCY_FIT_PLAN
+        plan = eff <= 9.0 ? PWPP_LATENCY_FIT_PLAN
              : eff <= 48.0 ? "S64:65535"
              : eff <= 320.0 ? "W16.16:1023,S64:65535"
              : eff <= 448.0 ? "W16.16:1023,W64.2:65535"
@@ -1961,6 +2131,7 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
         (void)hipStreamWaitEvent(aux, aux_fork, 0);
     }
     const char *p = plan;
+    bool rest_done = false;
     while (*p && slot < 5) {
         char mode = p[0];
         int g = 0, pw = 0;
@@ -1984,7 +2155,17 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
             else if (mode == 'S' && g == 16) hipLaunchKernelGGL(k_fit_srows<16>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'S' && g == 32) hipLaunchKernelGGL(k_fit_srows<32>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'S' && g == 64) hipLaunchKernelGGL(k_fit_srows<64>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-            else if (mode == 'B') hipLaunchKernelGGL(k_fit_brows, dim3(F, patches), dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            else if (mode == 'H') {  // "H64:<n>": up to n points a wave per patch, four waves above, everything in one launch
+                const unsigned nb_big = cap(pwpp_bucket_floor(k_hi));
+                hipLaunchKernelGGL(k_fit_hybrid, dim3(F, nb_big + (patches + kWaves - 1) / kWaves), dim3(kBlock), 0, ls, B, k_hi, nb_big);
+                rest_done = true;
+            }
+            else if (mode == 'B') {
+                // a B class that ends the ladder also takes the patches beyond it: one launch less on the latency path
+                const bool takes_rest = upper == 65535u;
+                hipLaunchKernelGGL(k_fit_brows, dim3(F, patches), dim3(kBlock), 0, ls, B, k_lo, takes_rest ? PWPP_NUM_BUCKETS : k_hi);
+                rest_done = takes_rest;
+            }
             else if (mode == 'W') {  // "W<lanes per patch>.<patches per wave>"
                 if (pw == 0) pw = 64;
                 const dim3 wgrid(F, (patches + (unsigned)pw * kWaves - 1) / ((unsigned)pw * kWaves));
@@ -2017,7 +2198,9 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     for (; slot < 5; ++slot)
         if (ev) (void)hipEventRecord(ev[slot], stream);
     if (ev) (void)hipEventRecord(ev[5], stream);
-    if (fork) {
+    if (rest_done) {
+        // nothing left
+    } else if (fork) {
         hipLaunchKernelGGL(k_fit_stream, dim3(F, cap(n_lo)), dim3(kBlock), 0, aux, B, k_lo);
         (void)hipEventRecord(aux_join, aux);
         (void)hipStreamWaitEvent(stream, aux_join, 0);

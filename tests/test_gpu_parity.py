@@ -368,7 +368,7 @@ def test_points_on_bin_boundaries(oracle):
 
 @pytest.mark.parametrize("plan", ["L16:127,L32:255,L64:511,S64:65535", "S8:63,S16:255,S32:1023,S64:4095", "S8:65535", "S64:65535",
                                   "W16:65535", "W16:255,P16:2047,P64:65535", "P16:65535", "S16:100",
-                                  "W16.16:1023,W64.2:65535", "W16.32:511,W64.4:65535", "S64:255,B64:65535", "B64:65535"])
+                                  "W16.16:1023,W64.2:65535", "W16.32:511,W64.4:65535", "S64:255,B64:65535", "B64:65535", "H64:511", "H64:63"])
 def test_every_fit_kernel_variant(kitti, oracle, plan, monkeypatch):
     """All fit kernels (LDS-parked rows, streaming rows of every width, 64-patch waves, the phase
     kernels with one-lane-per-patch solves, the workgroup kernel for whatever exceeds the plan) produce the same bit-exact result: the integer plane-fit sums do
@@ -606,14 +606,14 @@ def test_lowest_point_selection_fallbacks(kitti, oracle, flags, monkeypatch):
     frames = [kitti[0], kitti[4], kitti[2], kitti[1], kitti[5], kitti[3]]
     refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(p) for p in frames]
     h = pwpp_hip.Handle()
-    for plan in ("W16:1023,W64.2:65535", "S16:255,S64:65535", "B64:65535"):
+    for plan in ("W16:1023,W64.2:65535", "S16:255,S64:65535", "B64:65535", "H64:511"):
         monkeypatch.setenv("PWPP_FIT_PLAN", plan)
-        h.estimate_ground_batch(frames[:5] if plan.startswith("B") else frames, mode=pwpp_hip.MODE_FRESH)
+        h.estimate_ground_batch(frames[:5] if plan[0] in "BH" else frames, mode=pwpp_hip.MODE_FRESH)
         for i in range(5):
             assert_frame_equal(h, i, refs[i], frames[i].shape[0])
 
 
-def test_size_extremes(oracle):
+def test_size_extremes(oracle, monkeypatch):
     """The largest frame the C-ABI accepts (4 194 304 points: bins far beyond 65 535 points go to the
     workgroup kernel) and a batch of 60 tiny frames around one of 2 M points (the one-pass capacities
     follow the largest frame); bit-exact against the oracle."""
@@ -623,7 +623,13 @@ def test_size_extremes(oracle):
     big = np.concatenate([base + rng.normal(0, 0.01, base.shape).astype(np.float32) for _ in range(reps)])[:4194304]
     h = pwpp_hip.Handle()
     h.estimate_ground_batch([big], mode=pwpp_hip.MODE_FRESH)
-    assert_frame_equal(h, 0, ol.Estimator(oracle, arith=ol.ARITH_FXP).run(big), big.shape[0])
+    big_ref = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(big)
+    assert_frame_equal(h, 0, big_ref, big.shape[0])
+    for plan in ("H64:1023", "B64:65535"):  # the four-waves-per-patch body on bins of ~10^5 points: split second moments
+        monkeypatch.setenv("PWPP_FIT_PLAN", plan)
+        h.estimate_ground_batch([big], mode=pwpp_hip.MODE_FRESH)
+        assert_frame_equal(h, 0, big_ref, big.shape[0])
+    monkeypatch.delenv("PWPP_FIT_PLAN")
     tiny = [base[rng.choice(base.shape[0], 800, replace=False)] for _ in range(60)]
     mix = tiny[:30] + [big[:2000000]] + tiny[30:]
     h2 = pwpp_hip.Handle()
