@@ -1535,7 +1535,7 @@ __device__ __forceinline__ double point_to_plane(float nx, float ny, float nz, d
 // ------------------------------------------------------------------------------------------
 struct BRowShared {
     long long mom[kWaves][10];
-    unsigned keys[kWaves][PWPP_MAX_LPR];  // every wave's smallest keys, ascending
+    unsigned cand[kWaves][5][64];  // every lane's four smallest keys + the smallest it dropped, pooled lane by lane
     unsigned dropped[kWaves];
     int elig[kWaves];
     double single_sum;   // a patch of one chunk: wave 0's result
@@ -1573,19 +1573,53 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsi
         }
         cp = nx;
     }
+    // Every lane kept its four smallest keys (and the smallest one it dropped).  The waves pool them lane by
+    // lane: lane j of EVERY wave merges the sixteen keys the four lanes j hold into its four smallest (what
+    // falls out joins the dropped ones), then all waves extract the keff smallest of the pool the same way,
+    // adding them up in ascending order as the reference does (ref :99-101) -- no cross-wave list merge, and
+    // the result is in every thread.  A patch of one chunk lives in wave 0 alone and skips the pooling.
     const int total_w = Row<64>::sum_i32(elig);
-    const int keff_w = total_w < num_lpr ? total_w : num_lpr;
-    const bool single = nchunk <= 1u;  // only wave 0 holds points (most patches): its list is the result, no merge
-    double sum_w = 0.0;
-    unsigned T_w = 0;
-    for (int r = 0; r < keff_w; ++r) {  // this wave's keff_w smallest kept keys, ascending (wave-uniform trip count)
-        const unsigned m = Row<64>::min_u32(k0);
-        if (single) {
-            sum_w += (double)key_z(m);  // ascending, as the reference adds them up (ref :99-101)
-            T_w = m;
-        } else if (ln == 0) {
-            sh.keys[wv][r] = m;
+    const bool single = nchunk <= 1u;
+    int total = total_w;
+    if (!single) {
+        sh.cand[wv][0][ln] = k0;
+        sh.cand[wv][1][ln] = k1;
+        sh.cand[wv][2][ln] = k2;
+        sh.cand[wv][3][ln] = k3;
+        sh.cand[wv][4][ln] = dropped;
+        if (ln == 0) sh.elig[wv] = total_w;
+        __syncthreads();
+        k0 = k1 = k2 = k3 = dropped = INF;
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            total += sh.elig[w];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned x = sh.cand[w][q][ln];
+                ce(k0, x);
+                ce(k1, x);
+                ce(k2, x);
+                ce(k3, x);
+                dropped = x < dropped ? x : dropped;
+            }
+            const unsigned d = sh.cand[w][4][ln];
+            dropped = d < dropped ? d : dropped;
         }
+        __syncthreads();  // the pool is free again
+    } else {
+        total = __builtin_amdgcn_readfirstlane(total_w);
+        if (wv == 0 && ln == 0) sh.elig[0] = total_w;
+        __syncthreads();
+        total = sh.elig[0];  // (waves 1-3 hold nothing: they follow wave 0's count and extract INF keys; only wave 0's result is used)
+    }
+    const int keff = total < num_lpr ? total : num_lpr;
+    double sum = 0.0;
+    unsigned T = 0;
+    for (int r = 0; r < keff; ++r) {  // workgroup-uniform trip count
+        const unsigned m = Row<64>::min_u32(k0);
+        sum += (double)key_z(m);
+        T = m;
         const int lowest = __ffsll((long long)__ballot(k0 == m)) - 1;
         if (ln == lowest) {
             k0 = k1;
@@ -1594,56 +1628,20 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsi
             k3 = INF;
         }
     }
-    const unsigned dmin = Row<64>::min_u32(dropped);
-    if (ln == 0) {
-        sh.dropped[wv] = dmin;
-        sh.elig[wv] = total_w;
-        if (single && wv == 0) {
-            sh.single_sum = sum_w;
-            sh.single_T = T_w;
+    unsigned dall = Row<64>::min_u32(dropped);
+    if (single) {  // wave 0's result for everybody
+        if (wv == 0 && ln == 0) {
+            sh.single_sum = sum;
+            sh.single_T = T;
+            sh.dropped[0] = dall;
         }
-    }
-    __syncthreads();
-    if (single) {
-        const int keff1 = sh.elig[0] < num_lpr ? sh.elig[0] : num_lpr;
-        const unsigned d1 = sh.dropped[0], T1 = sh.single_T;
-        const double s1 = sh.single_sum;
         __syncthreads();
-        if (keff1 > 0 && (d1 < T1 || force != 0)) return block_lpr(sh.fs, pts, n, use_cutoff, cutoff, num_lpr);
-        return keff1 ? s1 / (double)keff1 : 0.0;  // ref :103
+        sum = sh.single_sum;
+        T = sh.single_T;
+        dall = sh.dropped[0];
+        __syncthreads();
     }
-    // merge the four ascending lists (every thread the same way)
-    int total = 0;
-    unsigned dall = INF;
-    int listed[kWaves], pos[kWaves];
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
-        total += sh.elig[w];
-        dall = sh.dropped[w] < dall ? sh.dropped[w] : dall;
-        listed[w] = sh.elig[w] < num_lpr ? sh.elig[w] : num_lpr;
-        pos[w] = 0;
-    }
-    const int keff = total < num_lpr ? total : num_lpr;
-    double sum = 0.0;
-    unsigned T = 0;
-    for (int r = 0; r < keff; ++r) {
-        unsigned best = INF;
-        int bw = 0;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            const unsigned head = pos[w] < listed[w] ? sh.keys[w][pos[w]] : INF;
-            if (head < best) {
-                best = head;
-                bw = w;
-            }
-        }
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) pos[w] += (w == bw) ? 1 : 0;
-        sum += (double)key_z(best);
-        T = best;
-    }
-    __syncthreads();  // the lists are free again
-    if (keff > 0 && (dall < T || force != 0)) return block_lpr(sh.fs, pts, n, use_cutoff, cutoff, num_lpr);  // a lane held > 4 of the lowest: exact path
+    if (keff > 0 && (dall < T || force != 0)) return block_lpr(sh.fs, pts, n, use_cutoff, cutoff, num_lpr);  // a lane (pool) held > 4 of the lowest: exact path
     return keff ? sum / (double)keff : 0.0;  // ref :103
 }
 
