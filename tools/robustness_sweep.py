@@ -16,7 +16,7 @@ for beams, steps in cases:
     plain = len(sys.argv) > 1 and sys.argv[1] == "plain"
     src = [pwpp_synth.make_cloud(100 + k, beams=beams, azimuth_steps=steps) if plain else pwpp_synth.add_edge_cases(pwpp_synth.make_cloud(100 + k, beams=beams, azimuth_steps=steps), k) for k in range(3)]
     refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(p) for p in src] if oracle is not None else None
-    for F in (3, 7, 40, 130):
+    for F in (1, 2, 3, 7, 40, 130):
         frames = [src[i % 3] for i in range(F)]
         h = pwpp_hip.Handle()
         t0 = time.perf_counter()
