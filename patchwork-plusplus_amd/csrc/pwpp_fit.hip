@@ -100,6 +100,63 @@ struct Row {
         const v2i pair = {tl, th};
         return v + __builtin_bit_cast(long long, pair);
     }
+    // ---- ten 64-bit row sums at once, as a reduce-SCATTER -------------------------------------------
+    // sum_i64 is a butterfly per value: every lane ends up with every total (10 x log2(G) exchanges).
+    // The kernels that park the totals in LDS only need each total ONCE, so the row is halved instead:
+    // at every step a lane keeps one half of its values, sends the other half to its partner and adds
+    // what the partner sends (5 + 3 + 2 + 1 exchanges for the first four steps), after which a lane of
+    // a 16-lane group owns one value summed over the group; the groups of a wider row are then added up
+    // on that one value.  The partners must agree on every side bit already used, hence the order:
+    // half-mirror (i <-> 7-i, side = bit 2), xor 1, xor 2, xor 8 (ds_swizzle), [xor 16, xor 32].
+    // `slot` = which of the ten values this lane owns (-1: none); integer sums, so the order is free.
+    template <int KIND>
+    __device__ static __forceinline__ long long xchg64(long long v) {
+        int lo = (int)(unsigned)(unsigned long long)v, hi = (int)((unsigned long long)v >> 32);
+        int tl, th;
+        if (KIND == 0) { tl = PWPP_DPP(lo, PWPP_DPP_HMIR); th = PWPP_DPP(hi, PWPP_DPP_HMIR); }
+        else if (KIND == 1) { tl = PWPP_DPP(lo, PWPP_DPP_XOR1); th = PWPP_DPP(hi, PWPP_DPP_XOR1); }
+        else if (KIND == 2) { tl = PWPP_DPP(lo, PWPP_DPP_XOR2); th = PWPP_DPP(hi, PWPP_DPP_XOR2); }
+        else if (KIND == 3) { tl = __builtin_amdgcn_ds_swizzle(lo, 0x201F); th = __builtin_amdgcn_ds_swizzle(hi, 0x201F); }  // xor 8
+        else if (KIND == 4) { tl = __builtin_amdgcn_ds_swizzle(lo, PWPP_SWZ16); th = __builtin_amdgcn_ds_swizzle(hi, PWPP_SWZ16); }
+        else { const int a = (lane_id() ^ 32) << 2; tl = __builtin_amdgcn_ds_bpermute(a, lo); th = __builtin_amdgcn_ds_bpermute(a, hi); }
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const v2i pair = {tl, th};
+        return __builtin_bit_cast(long long, pair);
+    }
+    __device__ static __forceinline__ long long reduce10_scatter(const long long (&v)[10], int &slot) {
+        static_assert(G == 16 || G == 64, "rows of 16 or 64 lanes");
+        const int ln = lane_id();
+        const bool s2 = (ln & 4) != 0, s0 = (ln & 1) != 0, s1 = (ln & 2) != 0, s3 = (ln & 8) != 0;
+        long long a[5], b[3], c[2], d;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const long long keep = s2 ? v[5 + i] : v[i], send = s2 ? v[i] : v[5 + i];
+            a[i] = keep + xchg64<0>(send);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const long long up = i < 2 ? a[3 + (i < 2 ? i : 0)] : 0ll;
+            const long long keep = s0 ? up : a[i], send = s0 ? a[i] : up;
+            b[i] = keep + xchg64<1>(send);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long up = i < 1 ? b[2] : 0ll;
+            const long long keep = s1 ? up : b[i], send = s1 ? b[i] : up;
+            c[i] = keep + xchg64<2>(send);
+        }
+        {
+            const long long keep = s3 ? c[1] : c[0], send = s3 ? c[0] : c[1];
+            d = keep + xchg64<3>(send);
+        }
+        if (G == 64) {
+            d += xchg64<4>(d);
+            d += xchg64<5>(d);
+        }
+        const int idx = s0 ? (s1 ? -1 : (s3 ? 4 : 3)) : (s1 ? (s3 ? -1 : 2) : (s3 ? 1 : 0));
+        slot = idx < 0 ? -1 : (s2 ? 5 : 0) + idx;
+        return d;
+    }
     __device__ static __forceinline__ long long sum_i64(long long v) {
         v = step64(v, 0);
         v = step64(v, 1);
@@ -1008,31 +1065,32 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
                 }
             }
             cm.flush_into(m);
-            long long v[10];
-            v[0] = Row<G>::sum_i64(m.n);
+            // the row's ten totals -> LDS.  64-lane rows: reduce-scatter, each total stored by the lane it ends
+            // up with (big-bin kernel 1.150 -> 1.129 ms); 16-lane rows: ten butterflies (four steps each;
+            // the selects of the scatter cost what its fewer exchanges save: 0.868 -> 0.884 ms)
+            auto row_totals = [&](const Moments &mm, long long (*dst)[10], bool store) {
+                if constexpr (G == 64) {
+                    const long long v[10] = {mm.n, mm.s1[0], mm.s1[1], mm.s1[2], mm.s2[0], mm.s2[1], mm.s2[2], mm.s2[3], mm.s2[4], mm.s2[5]};
+                    int slot;
+                    const long long mine = Row<G>::reduce10_scatter(v, slot);
+                    if (store && slot >= 0 && j < 16) dst[q][slot] = mine;
+                } else {
+                    long long v[10];
+                    v[0] = Row<G>::sum_i64(mm.n);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) v[1 + k] = Row<G>::sum_i64(m.s1[k]);
+                    for (int k = 0; k < 3; ++k) v[1 + k] = Row<G>::sum_i64(mm.s1[k]);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) v[4 + k] = Row<G>::sum_i64(m.s2[k]);
-            if (on && j < 10) {  // lane j of the row stores moment j
-                long long mine = v[0];
+                    for (int k = 0; k < 6; ++k) v[4 + k] = Row<G>::sum_i64(mm.s2[k]);
+                    if (store && j < 10) {  // lane j of the row stores moment j
+                        long long mine = v[0];
 #pragma unroll
-                for (int k = 1; k < 10; ++k) mine = j == k ? v[k] : mine;
-                sh.mom[q][j] = mine;
-            }
-            if (DUAL && __any(dual)) {
-                v[0] = Row<G>::sum_i64(m2.n);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) v[1 + k] = Row<G>::sum_i64(m2.s1[k]);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) v[4 + k] = Row<G>::sum_i64(m2.s2[k]);
-                if (dual && j < 10) {
-                    long long mine = v[0];
-#pragma unroll
-                    for (int k = 1; k < 10; ++k) mine = j == k ? v[k] : mine;
-                    sh.mom2[DUAL ? q : 0][j] = mine;
+                        for (int k = 1; k < 10; ++k) mine = j == k ? v[k] : mine;
+                        dst[q][j] = mine;
+                    }
                 }
-            }
+            };
+            row_totals(m, sh.mom, on);
+            if (DUAL && __any(dual)) row_totals(m2, sh.mom2, dual);
         }
         wave_lds_sync();
 
@@ -1770,32 +1828,32 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         probe(3);
         {   // the wave's sums -> LDS -> totals of the patch (every thread)
             auto wave_sums = [&](const Moments &mm, long long (*dst)[10], long long (*dst_hi)[6]) {
+                if (!wide) {  // reduce-scatter: each total is stored by the lane it ends up with
+                    const long long t[10] = {mm.n, mm.s1[0], mm.s1[1], mm.s1[2], mm.s2[0], mm.s2[1], mm.s2[2], mm.s2[3], mm.s2[4], mm.s2[5]};
+                    int slot;
+                    const long long mine = Row<64>::reduce10_scatter(t, slot);
+                    if (slot >= 0 && ln < 16) dst[wv][slot] = mine;
+                    return;
+                }
                 long long v[10];
                 v[0] = Row<64>::sum_i64(mm.n);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) v[1 + k] = Row<64>::sum_i64(mm.s1[k]);
-                if (!wide) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) v[4 + k] = Row<64>::sum_i64(mm.s2[k]);
-                } else {  // lower halves here, upper halves below
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) v[4 + k] = Row<64>::sum_i64(mm.s2[k] & 0xffffffffLL);
-                }
+                for (int k = 0; k < 6; ++k) v[4 + k] = Row<64>::sum_i64(mm.s2[k] & 0xffffffffLL);  // lower halves here, upper halves below
                 if (ln < 10) {
                     long long mine = v[0];
 #pragma unroll
                     for (int k = 1; k < 10; ++k) mine = ln == k ? v[k] : mine;
                     dst[wv][ln] = mine;
                 }
-                if (wide) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) v[k] = Row<64>::sum_i64(mm.s2[k] >> 32);
-                    if (ln < 6) {
-                        long long mine = v[0];
+                for (int k = 0; k < 6; ++k) v[k] = Row<64>::sum_i64(mm.s2[k] >> 32);
+                if (ln < 6) {
+                    long long mine = v[0];
 #pragma unroll
-                        for (int k = 1; k < 6; ++k) mine = ln == k ? v[k] : mine;
-                        dst_hi[wv][ln] = mine;
-                    }
+                    for (int k = 1; k < 6; ++k) mine = ln == k ? v[k] : mine;
+                    dst_hi[wv][ln] = mine;
                 }
             };
             wave_sums(m, sh.mom, sh.mom_hi);
