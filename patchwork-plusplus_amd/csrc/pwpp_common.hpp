@@ -142,7 +142,11 @@ __device__ void jacobi_svd3(const float a[9], float u[9], float sv[3]) {
                         const float tt = (tau > 0.0f) ? 1.0f / (tau + ww) : 1.0f / (tau - ww);
                         const float sign_t = tt > 0.0f ? 1.0f : -1.0f;
                         const float nn = 1.0f / sqrtf(tt * tt + 1.0f);
-                        sr = -sign_t * (b01 / f_abs(b01)) * f_abs(tt) * nn;
+                        // b01 / |b01| (Eigen's sign factor) is exactly +-1 for every finite non-zero b01 and NaN
+                        // otherwise (inf / inf): no need for the ten instructions of an IEEE division
+                        const float unit = f_abs(b01) <= FLT_MAX ? __uint_as_float(0x3f800000u | (__float_as_uint(b01) & 0x80000000u))
+                                                                 : __uint_as_float(0x7fc00000u);
+                        sr = -sign_t * unit * f_abs(tt) * nn;
                         cr = nn;
                     }
                     const float cl = c1 * cr - s1 * (-sr);
@@ -310,7 +314,7 @@ struct PlaneFit {
 
 __device__ __forceinline__ void plane_from_totals(long long n, const long long s1[3], const __int128 s2[6], int shift,
                                                   int debug, PlaneFit &out) {
-    const double inv = 1.0 / (double)(1 << shift);
+    const double inv = __longlong_as_double((long long)(1023 - shift) << 52);  // 2^-shift, exactly what 1.0 / (1 << shift) gives, without the division
     const double den = (double)n * (double)(n - 1);
     float mean[3], cov[9];
 #pragma unroll
