@@ -367,14 +367,13 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     bt.centers = h->d_centers.p;
     bt.normals = h->d_normals.p;
     bt.results = h->d_results.p;
+    bt.results_host = h->h_results.p;  // hipHostMalloc'ed: the same address on the device
     bt.dbg = h->d_dbg.p;
 
     bt.cap_off = one_pass ? h->d_cap_off.p : nullptr;
     HIPCHK(hipEventRecord(h->ev_begin, h->stream));
-    // zero the histogram, the scatter cursors and the per-frame result counters
-    // (count, off, cursor are adjacent slabs: the two-pass path zeroes all three with one call)
-    HIPCHK(hipMemsetAsync(bt.bin_count, 0, (one_pass ? 1 : 3) * slab * sizeof(uint32_t), h->stream));
-    HIPCHK(hipMemsetAsync(bt.results, 0, (size_t)frames * sizeof(PwppFrameResult), h->stream));
+    // (the histogram, the scatter cursors and the per-frame result counters are zeroed by the pipeline's
+    // first kernel, k_clear)
     if (bt.debug & 4) {
         HIPCHK(hipMemsetAsync(bt.dbg, 0, 64 * sizeof(unsigned long long), h->stream));
         HIPCHK(hipMemsetAsync(bt.dbg + 60, 0xFF, sizeof(unsigned long long), h->stream));  // slot 60 is a minimum
@@ -384,7 +383,6 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
                                          ordered ? h->d_ord_a.p : nullptr, ordered ? h->d_ord_b.p : nullptr);
     if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_results.p, h->d_results.p, (size_t)frames * sizeof(PwppFrameResult), hipMemcpyDeviceToHost, h->stream));
     h->profile_pending = h->profiling;
     h->one_pass = one_pass;
     g_slot0_one_pass = one_pass;

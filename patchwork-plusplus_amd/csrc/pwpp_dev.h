@@ -125,6 +125,7 @@ struct PwppBatch {
     float *centers;              // [frames][B][3] compacted to n_patches rows
     float *normals;              // [frames][B][3]
     PwppFrameResult *results;    // [frames]
+    PwppFrameResult *results_host;  // [frames] pinned host mirror, written by K6 (no D2H copy command behind the pipeline)
     unsigned long long *dbg;     // [64] timing probes, only written when debug & 4
 };
 

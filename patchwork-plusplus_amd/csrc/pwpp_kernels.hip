@@ -1322,6 +1322,9 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
 constexpr int kEmitBlock = 64;
 __global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt, bool keep_cat) {
     const int f = blockIdx.y, seg = blockIdx.x;
+    // the frame's counters are final since K5: hand them to the host through its pinned mirror (eight posted
+    // PCIe writes) instead of a copy command behind the pipeline (a dispatch of its own, ~9 us of a single frame)
+    if (seg == 0 && threadIdx.x == 0) Bt.results_host[f] = Bt.results[f];
     const PwppDevParams &P = Bt.P;
     const int B = P.num_bins, NB = B + 2;
     const unsigned n = Bt.bin_count[(size_t)f * NB + seg];
@@ -1495,6 +1498,18 @@ extern "C" int pwpp_launch_gather_xyz(const PwppFrameDesc *fd, const int *idx, i
 extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
                                hipEvent_t aux_fork, hipEvent_t aux_join);
 
+// K0: the per-launch zeroing (histogram / cursor slabs and the frame counters) in ONE dispatch; two
+// hipMemsetAsync calls were three fill kernels of the runtime, ~6 us apart on the queue
+__global__ __launch_bounds__(kBlock) void k_clear(uint4 *slabs, size_t n16, PwppFrameResult *results, int frames) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n16) slabs[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < (size_t)frames) {
+        PwppFrameResult z;
+        z.n_ground = z.n_nonground = z.n_patches = z.n_rnr = z.n_oor = z.n_dropped = z.pad0 = z.overflow = 0;
+        results[i] = z;
+    }
+}
+
 extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev /* PWPP_NUM_KERNELS + 1 events or null */,
                                     hipStream_t aux, hipEvent_t aux_fork, hipEvent_t aux_join,
                                     unsigned long long *order_a /* reference-order mode: two scratch arrays, else null */,
@@ -1504,6 +1519,13 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     if (F <= 0) return 0;
     const int NB = B.P.num_bins + 2;
     const unsigned gx = (unsigned)((B.max_n + kPtsPerBlock - 1) / kPtsPerBlock);
+    {   // count (+ off, cursor on the two-pass path: adjacent slabs) and the result counters start at zero
+        const size_t words = (size_t)(B.cap_off ? 1 : 3) * (size_t)F * (size_t)NB;
+        const size_t n16 = (words + 3) / 4;  // the slabs are followed by dst_a / dst_b, which K5 rewrites: rounding up is harmless
+        const size_t items = n16 > (size_t)F ? n16 : (size_t)F;
+        hipLaunchKernelGGL(k_clear, dim3((unsigned)((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                           reinterpret_cast<uint4 *>(B.bin_count), n16, B.results, F);
+    }
     if (ev) (void)hipEventRecord(ev[0], stream);
     if (B.cap_off) {  // one-pass binning (fixed bin segments)
         const unsigned gx1 = (unsigned)((B.max_n + kOnePassPts - 1) / kOnePassPts);
