@@ -2,7 +2,7 @@
 from a rocprofv3 --kernel-trace csv: trace_all.py <kernel_trace.csv> [run index]"""
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "k_czm_bin" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "k_clear" in r["Kernel_Name"]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
 lo = starts[k - 1] if k > 0 else 0
 # from the end of the previous run's last library kernel to this run's last library kernel

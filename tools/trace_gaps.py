@@ -4,10 +4,11 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows = [r for r in rows if "k_" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a pipeline run starts with k_czm_bin*
+# a pipeline run starts with k_clear (k_czm_bin* in builds before it existed)
+head = "k_clear" if any("k_clear" in r["Kernel_Name"] for r in rows) else "k_czm_bin"
 runs, cur = [], []
 for r in rows:
-    if "k_czm_bin" in r["Kernel_Name"] and cur:
+    if head in r["Kernel_Name"] and cur:
         runs.append(cur); cur = []
     cur.append(r)
 runs.append(cur)
