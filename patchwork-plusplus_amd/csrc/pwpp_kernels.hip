@@ -849,6 +849,10 @@ __device__ __forceinline__ void block_excl_scan(unsigned v[K], unsigned (*s_wave
     __syncthreads();
 }
 
+// LAT (a few dozen frames: every workgroup has a CU and its 160 KB of LDS to itself): the staging tile of
+// the threshold statistics holds a whole 1000-entry history per row, so each of the two passes is ONE
+// stage instead of three; otherwise the tile lives in the retired prefix arrays (32 KB).
+template <bool LAT>
 __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     __shared__ uint8_t s_dec[PWPP_MAX_BINS];
     __shared__ __attribute__((aligned(16))) unsigned s_e[4][PWPP_MAX_BINS + 1];   // exclusive prefixes: gmain, gtail, nmain, ntail;
@@ -1057,9 +1061,10 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     // The histories are complete now (this frame's pushes included): start fetching their first tile
     // for the threshold statistics at the end of the kernel, the loads fly while TGR and the list
     // offsets are worked out.
-    constexpr int kHistTile = 496, kHistStride = 498;  // 8 rows, 16-byte aligned, on distinct LDS banks
+    constexpr int kHistTile = LAT ? 1056 : 496, kHistStride = kHistTile + 2;  // 8 rows, 16-byte aligned, on distinct LDS banks
     constexpr int kHistPer = (kHistTile + kBlock - 1) / kBlock;
-    static_assert(sizeof(s_e) >= sizeof(double) * 8 * kHistStride, "history tile must fit into the retired s_e");
+    static_assert(LAT || sizeof(s_e) >= sizeof(double) * 8 * kHistStride, "history tile must fit into the retired s_e");
+    __shared__ __attribute__((aligned(16))) double s_tile_lat[LAT ? 8 * kHistStride : 2];
     int len_w[8], maxlen = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
@@ -1075,6 +1080,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         for (int w = 0; w < 8; ++w)
 #pragma unroll
             for (int q = 0; q < kHistPer; ++q) {
+                if (base + q * kBlock >= maxlen) continue;  // (uniform) nothing that far in any history
                 const int i = base + q * kBlock + (int)threadIdx.x;
                 v[w][q] = hist_out[(size_t)w * P.hist_cap + (i < len_w[w] ? i : 0)];
             }
@@ -1195,7 +1201,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     // (the next tile's loads are in flight while the current one is summed), and for the second pass
     // they also square the deviations, so the summing lanes execute one add per value.
     {
-        double *tile = reinterpret_cast<double *>(&s_e[0][0]);
+        double *tile = LAT ? s_tile_lat : reinterpret_cast<double *>(&s_e[0][0]);
         double acc = 0.0, mean = 0.0;
         for (int step = 0; step < 2 * ntiles; ++step) {
             const int pass = step >= ntiles ? 1 : 0;
@@ -1206,6 +1212,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
                 const double m = s_mean[w];
 #pragma unroll
                 for (int q = 0; q < kHistPer; ++q) {
+                    if (base + q * kBlock >= maxlen) continue;
                     const int i = q * kBlock + (int)threadIdx.x;
                     if (i < kHistTile) tile[w * kHistStride + i] = pass ? (v[w][q] - m) * (v[w][q] - m) : v[w][q];  // ref :564
                 }
@@ -1544,8 +1551,10 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     if (frc) return frc;
     if (B.P.min_pts == 0)
         hipLaunchKernelGGL(k_gle_tgr_seq, dim3(F), dim3(64), 0, stream, B);  // empty bins inherit planes: serial
+    else if (F <= 64)  // every workgroup alone on a CU: the big-LDS variant
+        hipLaunchKernelGGL(k_gle_tgr<true>, dim3(F), dim3(kBlock), 0, stream, B);
     else
-        hipLaunchKernelGGL(k_gle_tgr, dim3(F), dim3(kBlock), 0, stream, B);
+        hipLaunchKernelGGL(k_gle_tgr<false>, dim3(F), dim3(kBlock), 0, stream, B);
     if (ev) (void)hipEventRecord(ev[10], stream);
     hipLaunchKernelGGL(k_emit, dim3(NB, F), dim3(kEmitBlock), 0, stream, B, order_a != nullptr);
     if (ev) (void)hipEventRecord(ev[11], stream);
