@@ -1,0 +1,65 @@
+/* capi_demo.c -- the C-ABI from plain C99 (what a cgo / JNI / ctypes-style binding sees): one KITTI-layout
+ * .bin frame through pwpp_estimate_ground(), counts and the first indices printed.
+ *   gcc -std=c99 -Wall -Werror -I ../../include capi_demo.c -o capi_demo -L ../lib -lpwpp_hip -Wl,-rpath,'$ORIGIN/../lib'
+ *   ./capi_demo <frame.bin>
+ * Mirrors the read loop of the reference demo (cpp/patchworkpp/examples/demo_visualize.cpp:18-34) and its
+ * use of the object (:60-72), through the C entry points that replace each call. */
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "pwpp.h"
+
+static int fail(const char *what) {
+    fprintf(stderr, "%s: %s\n", what, pwpp_last_error());
+    return 1;
+}
+
+int main(int argc, char **argv) {
+    pwpp_params params;
+    pwpp_handle *h = NULL;
+    FILE *f;
+    long bytes;
+    int n;
+    float *pts;
+    int32_t n_ground = 0, n_nonground = 0, n_patches = 0;
+    int32_t *ground;
+
+    if (pwpp_params_default(&params) != PWPP_OK) return fail("pwpp_params_default"); /* Params(), patchworkpp.h:79-111 */
+    params.verbose = 0;
+    if (pwpp_create(&params, 0, &h) != PWPP_OK) {  /* PatchWorkpp(Params), patchworkpp.h:120 */
+        /* no GPU: the library says so and does NOT fall back to a CPU path */
+        fprintf(stderr, "pwpp_create: %s\n", pwpp_last_error());
+        return 2;
+    }
+    if (argc < 2) {
+        fprintf(stderr, "usage: %s <frame.bin>\n", argv[0]);
+        pwpp_destroy(h);
+        return 1;
+    }
+    f = fopen(argv[1], "rb");
+    if (!f) {
+        perror(argv[1]);
+        return 1;
+    }
+    fseek(f, 0, SEEK_END);
+    bytes = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    n = (int)(bytes / (4 * (long)sizeof(float)));  /* x, y, z, intensity */
+    pts = (float *)malloc((size_t)n * 4 * sizeof(float));
+    if (!pts || fread(pts, 4 * sizeof(float), (size_t)n, f) != (size_t)n) {
+        fprintf(stderr, "short read\n");
+        return 1;
+    }
+    fclose(f);
+
+    if (pwpp_estimate_ground(h, pts, n, 4, PWPP_LAYOUT_ROW_MAJOR) != PWPP_OK) return fail("pwpp_estimate_ground"); /* estimateGround(), patchworkpp.cpp:151 */
+    if (pwpp_get_counts(h, 0, &n_ground, &n_nonground, &n_patches) != PWPP_OK) return fail("pwpp_get_counts");
+    ground = (int32_t *)malloc((size_t)(n_ground > 0 ? n_ground : 1) * sizeof(int32_t));
+    if (pwpp_get_ground_indices(h, 0, ground) != PWPP_OK) return fail("pwpp_get_ground_indices");   /* getGroundIndices(), patchworkpp.h:159 */
+    printf("points %d ground %d nonground %d patches %d height %.6f time_us %.1f\n", n, (int)n_ground, (int)n_nonground,
+           (int)n_patches, pwpp_get_height(h), pwpp_get_time_us(h));
+    free(ground);
+    free(pts);
+    pwpp_destroy(h);
+    return 0;
+}

@@ -117,3 +117,17 @@ def test_cpp_demo_builds_against_the_class_mirror():
     if not _has_gpu():
         r = subprocess.run([exe], capture_output=True, text=True)
         assert r.returncode == 1 and "no CPU path" in r.stdout
+
+
+def test_c_abi_from_plain_c99():
+    """include/pwpp.h is C, not C++ in disguise: a C99 program (gcc -std=c99 -pedantic -Werror) builds against
+    it and links with the library alone; without a GPU it reports that there is no device and exits (no CPU
+    path), with one it is exercised by the GPU suite."""
+    exe = os.path.join(ROOT, "patchwork-plusplus_amd", "examples", "capi_demo")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "patchwork-plusplus_amd"), "examples/capi_demo"], check=True,
+                   stdout=subprocess.DEVNULL)
+    assert os.path.exists(exe)
+    if _has_gpu():
+        return
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "no CPU path" in r.stderr

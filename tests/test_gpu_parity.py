@@ -461,6 +461,26 @@ def test_cpp_class_demo_program(kitti, golden, tmp_path):
         assert abs(height - golden["f32/seq/%d/state" % k][0]) < 1e-4
 
 
+def test_c_abi_demo_program(kitti, golden, tmp_path):
+    """The C-ABI driven from plain C99 (examples/capi_demo.c): a fresh handle on frame 0 gives the reference's
+    counts (golden: reference build, fresh state)."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "patchwork-plusplus_amd", "examples", "capi_demo")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "patchwork-plusplus_amd"), "examples/capi_demo"], check=True)
+    p = tmp_path / "000000.bin"
+    kitti[0].tofile(p)
+    out = subprocess.run([exe, str(p)], capture_output=True, text=True, check=True).stdout
+    m = re.search(r"points (\d+) ground (\d+) nonground (\d+) patches (\d+) height ([-0-9.]+)", out)
+    assert m, out
+    assert int(m.group(1)) == kitti[0].shape[0]
+    assert [int(m.group(2)), int(m.group(3)), int(m.group(4))] == list(golden["f32/seq/0/counts"])
+    assert abs(float(m.group(5)) - golden["f32/seq/0/state"][0]) < 1e-4
+
+
 def test_one_pass_binning_and_its_overflow_fallback(kitti, oracle, monkeypatch):
     """Batches of independent frames bin in one pass into fixed bin segments (k_czm_bin_scatter).
     (1) the default capacities hold KITTI frames: the one-pass path is taken and nothing is redone;
