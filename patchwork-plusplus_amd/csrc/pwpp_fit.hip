@@ -1786,11 +1786,13 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         unsigned done = 0;
         ChunkPts cp;
         load_chunk<64>(cp, pts, n, (unsigned)wv);
+        int w[kPPT];
+        if (last) load_chunk_idx<64>(w, pts, n, (unsigned)wv);
         for (unsigned c = (unsigned)wv; c < nchunk; c += kWaves) {
-            ChunkPts nx;  // this wave's next chunk is in flight while this one is accumulated
+            ChunkPts nx;  // this wave's next chunk (and, in the round that writes the split, its cloud indices) is in flight while this one is accumulated
             load_chunk<64>(nx, pts, n, c + kWaves);
-            int w[kPPT];
-            if (last) load_chunk_idx<64>(w, pts, n, c);
+            int wnx[kPPT];
+            if (last) load_chunk_idx<64>(wnx, pts, n, c + kWaves);
             const unsigned gmask = lane_stage_accum(cp.lp, chunk_act(cp), kind, thr_seed, P.th_dist, pl, qscale, cm);
             if (++done % kFlushChunks == 0u) {
                 cm.flush_into(m);
@@ -1823,6 +1825,10 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
                 }
             }
             cp = nx;
+            if (last) {
+#pragma unroll
+                for (int k = 0; k < kPPT; ++k) w[k] = wnx[k];
+            }
         }
         cm.flush_into(m);
         probe(3);
