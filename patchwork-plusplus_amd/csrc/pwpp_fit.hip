@@ -178,6 +178,24 @@ struct Row {
     }
     // exclusive prefix sum over the row; total = row sum
     __device__ static __forceinline__ unsigned excl_scan(unsigned v, unsigned &total) {
+        if constexpr (G == 16 || G == 64) {
+            // DPP scan: row_shr 1, 2, 4, 8 inside the 16-lane rows (lanes without a source add 0), then for a
+            // 64-lane row the two broadcasts of a row's last lane into the rows behind it -- six adds and no LDS
+            // round trips, where the shuffle version below waits for a ds_bpermute at every step
+            int x = (int)v;
+            x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+            x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+            x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+            x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+            if constexpr (G == 64) {
+                x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+                x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+                total = (unsigned)__builtin_amdgcn_readlane(x, 63);
+            } else {
+                total = (unsigned)__shfl(x, G - 1, G);
+            }
+            return (unsigned)x - v;
+        }
         const int j = lane_id() & (G - 1);
         unsigned incl = v;
 #pragma unroll
