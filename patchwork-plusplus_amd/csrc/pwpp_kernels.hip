@@ -55,6 +55,23 @@ __device__ __forceinline__ double czm_atan2(double y, double x) {
     return atan2(y, x);
 }
 
+// Cross-lane moves on the VALU (DPP) instead of through the LDS crossbar (ds_bpermute): lane i reads lane
+// i - 1 of the wave (lane 0 gets `first`), and the inclusive prefix sum of a wave in six adds
+// (row_shr 1/2/4/8 inside the 16-lane rows, then the rows' last lanes broadcast into the rows behind).
+__device__ __forceinline__ unsigned wave_prev_lane(unsigned x, unsigned first) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)first, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31
+    return (unsigned)x;
+}
+
 // Consecutive points of a scan mostly fall into the same bin, so a wave's LDS atomics pile up
 // on one address (PMC: 78 % of the LDS cycles of k_czm_bin were bank-conflict cycles).  Lanes
 // are grouped into runs of equal code; only the first lane of a run touches the LDS counter,
@@ -63,8 +80,8 @@ __device__ __forceinline__ double czm_atan2(double y, double x) {
 __device__ __forceinline__ unsigned wave_run_add(unsigned *counters, unsigned code, bool active, unsigned &pos_in_run) {
     const int ln = lane_id();
     const unsigned key = active ? code : (0x80000000u | (unsigned)ln);  // inactive lanes never join a run
-    const unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
-    const bool head = ln == 0 || key != prev;
+    const unsigned prev = wave_prev_lane(key, ~key);
+    const bool head = key != prev;  // (lane 0 reads ~key: always a head)
     const unsigned long long heads = __ballot(head);
     const unsigned long long le = (ln == 63) ? ~0ull : ((1ull << (ln + 1)) - 1ull);
     const int h = 63 - __clzll((long long)(heads & le));            // first lane of my run
@@ -82,8 +99,8 @@ __device__ __forceinline__ unsigned wave_run_add(unsigned *counters, unsigned co
 __device__ __forceinline__ void wave_run_count(unsigned *counters, unsigned code, bool active) {
     const int ln = lane_id();
     const unsigned key = active ? code : (0x80000000u | (unsigned)ln);
-    const unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
-    const bool head = ln == 0 || key != prev;
+    const unsigned prev = wave_prev_lane(key, ~key);
+    const bool head = key != prev;  // (lane 0 reads ~key: always a head)
     const unsigned long long heads = __ballot(head);
     if (head && active) {
         const unsigned long long above = (heads >> ln) >> 1;  // run heads after this lane
@@ -367,18 +384,10 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
             local[j] = b < NB ? cnt[b] : 0u;
             sum += local[j];
         }
-        // inclusive scan inside the wave (shuffles), then the four wave totals through LDS: one barrier
+        // inclusive scan inside the wave (DPP), then the four wave totals through LDS: one barrier
         // instead of the sixteen of a Hillis-Steele scan over 256 partials (a single frame waits for this)
-        unsigned incl = sum;
-        {
-            const int ln = lane_id();
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned t = (unsigned)__shfl_up((int)incl, o, 64);
-                if (ln >= o) incl += t;
-            }
-            if (ln == 63) s_part[wave_id()] = incl;
-        }
+        const unsigned incl = wave_incl_scan(sum);
+        if (lane_id() == 63) s_part[wave_id()] = incl;
         __syncthreads();
         unsigned before = 0;
         for (int w = 0; w < wave_id(); ++w) before += s_part[w];
@@ -826,12 +835,7 @@ __device__ __forceinline__ void block_excl_scan(unsigned v[K], unsigned (*s_wave
     unsigned incl[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) {
-        incl[q] = v[q];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned t = (unsigned)__shfl_up((int)incl[q], o, 64);
-            if (ln >= o) incl[q] += t;
-        }
+        incl[q] = wave_incl_scan(v[q]);
         if (ln == 63) s_wave[wv][q] = incl[q];
     }
     __syncthreads();
