@@ -14,10 +14,13 @@
 //   k_fit_w64<64,2>         big bins, two per wave: 64 lanes stream one patch at a time, the
 //                           two solves share an instruction stream; dual seed pass
 //   k_fit_srows<G>          one row of G lanes per patch, next chunk prefetched (mid-size batches)
-//   k_fit_brows             four waves per patch (a handful of frames: chain latency)
+//   k_fit_brows             four waves per patch; an R-VPF round and the R-GPF seed fit solved side by side
+//   k_fit_hybrid            the single-frame kernel: k_fit_brows' body for the big patches, k_fit_srows<64>'s
+//                           for the small ones (four per workgroup), one launch, one workgroup per CU
 //   k_fit_rows<G>           points parked in lane-private LDS slots (patches up to 8 G points)
 //   k_ph_rows + k_ph_solve  the chain cut into phase kernels, state in HBM
-//   k_fit_stream            whatever exceeds the plan (> 65535 points): workgroup per patch
+//   k_fit_stream            whatever exceeds the plan (> 65535 points): workgroup per patch (the hybrid kernel
+//                           fits such patches in place)
 //
 // The streamed kernels re-read a patch once per stage (12-byte records, 5 passes for a zone-0
 // patch); DESIGN.md section 3 has the measurements that led here.

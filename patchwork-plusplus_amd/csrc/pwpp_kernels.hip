@@ -1,9 +1,10 @@
 // pwpp_kernels.hip -- the Patchwork++ estimateGround() hot path as hand-written HIP for
 // gfx950 (MI355X, CDNA4: wave64, 256 CUs in 8 XCDs, 160 KiB LDS/CU, HBM3E).
 //
-// One batch of F independent frames goes through six or seven launches; every launch covers
-// all frames, so a 1024-frame batch is 6 launches, not 6144:
+// One batch of F independent frames goes through seven or eight launches; every launch covers
+// all frames, so a 1024-frame batch is 7 launches, not 7168, and nothing else is enqueued per call:
 //
+//   K0  k_clear            zeroes the histogram / cursor slabs and the frame counters
 //   K1' k_czm_bin_scatter  RNR + CZM code per point, straight into the bin's FIXED segment   (ref :377-400, :578-622)
 //       (or K1 k_czm_bin + K3 k_czm_scatter: histogram, then scatter -- the exact two-pass path
 //        for <= 4 frames and for the redo after a segment overflow)
@@ -11,7 +12,8 @@
 //   K4  k_fit_*            per patch: LPR seeds, R-VPF, R-GPF, final plane       (ref :77-149, :47-75, :467-554)
 //                          one or two launches by patch size, see pwpp_fit.hip
 //   K5  k_gle_tgr          per frame: GLE ladder, A-GLE history, TGR, thresholds (ref :211-309, :338-375, :402-464)
-//   K6  k_emit             ground / non-ground index lists                       (ref :28-31, :18-26)
+//   K6  k_emit             ground / non-ground index lists                       (ref :28-31, :18-26);
+//                          mirrors the frame counters into pinned host memory
 //   K7  k_order_sublists   optional: the reference's order inside every part of the lists
 //
 // All reference citations are /root/reference/cpp/patchworkpp/src/patchworkpp.cpp unless a
