@@ -215,6 +215,12 @@ int pwpp_get_fxp_shift(pwpp_handle *h);
  * Applies to the batches launched after the call. */
 enum { PWPP_ORDER_SCATTER = 0, PWPP_ORDER_REFERENCE = 1 };
 int pwpp_set_output_order(pwpp_handle *h, int order);
+
+/* Overlap mode (off by default): batches of 128 frames or more are processed as two frame ranges with
+ * their own launches on the handle's two streams, so that the memory-bound stages of one range (binning,
+ * index lists) run under the VALU-bound plane fits of the other.  Same results; per-kernel profiling
+ * (pwpp_set_profiling) and PWPP_ORDER_REFERENCE fall back to the single-stream schedule. */
+int pwpp_set_overlap(pwpp_handle *h, int on);
 /* one-pass binning (fixed bin segments; DESIGN.md 3, K1'): batches launched that way and how many of
  * them had to be redone on the exact two-pass path because a bin outgrew its segment.  Finishes the
  * batch in flight first.  No reference counterpart. */

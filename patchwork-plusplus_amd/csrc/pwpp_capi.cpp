@@ -21,6 +21,7 @@
 
 extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
                                     hipEvent_t aux_fork, hipEvent_t aux_join, unsigned long long *order_a, unsigned long long *order_b);
+extern "C" int pwpp_launch_clear(const PwppBatch *batch, hipStream_t stream);
 extern "C" int pwpp_launch_gather_xyz(const PwppFrameDesc *fd, const int *idx, int count, float *out, hipStream_t stream);
 
 static_assert(sizeof(pwpp_state) == sizeof(PwppStateScalar), "pwpp_state must mirror PwppStateScalar");
@@ -103,6 +104,7 @@ struct pwpp_handle {
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;  // second stream for the latency plan (few frames)
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+    bool overlap = false;  // pwpp_set_overlap: big batches as two frame ranges on the two streams
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     hipEvent_t ev_k[PWPP_NUM_KERNELS + 1] = {};
     bool profiling = false;
@@ -379,8 +381,46 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
         HIPCHK(hipMemsetAsync(bt.dbg + 60, 0xFF, sizeof(unsigned long long), h->stream));  // slot 60 is a minimum
     }
     const bool ordered = h->output_order == PWPP_ORDER_REFERENCE;
-    const int lrc = pwpp_launch_pipeline(&bt, h->stream, h->profiling ? h->ev_k : nullptr, h->aux_stream, h->aux_fork, h->aux_join,
-                                         ordered ? h->d_ord_a.p : nullptr, ordered ? h->d_ord_b.p : nullptr);
+    int lrc;
+    // Overlap mode: the pipeline alternates memory-bound stages (binning, emit) and VALU-bound ones (the
+    // fits).  Two halves of the batch, each with its own launches on its own stream, put one kind under the
+    // other (tools/two_handles.py: +7.5 % on 1024 KITTI frames).  Every per-frame array is indexed by the
+    // frame, so the halves are two views of the same workspaces with shifted base pointers.
+    if (h->overlap && !h->profiling && !ordered && frames >= 128 && bt.debug == 0) {
+        auto half = [&](int f0, int nf) {
+            PwppBatch v = bt;
+            const int B = h->dp.num_bins;
+            v.frames += f0;
+            v.num_frames = nf;
+            v.no_clear = 1;
+            v.bin_count += (size_t)f0 * NB;
+            v.bin_off += (size_t)f0 * NB;
+            v.bin_cursor += (size_t)f0 * NB;
+            v.dst_a += (size_t)f0 * NB;
+            v.dst_b += (size_t)f0 * NB;
+            v.cls_start += (size_t)f0 * PWPP_CLS_STRIDE;
+            v.cls_list += (size_t)f0 * B;
+            v.recs += (size_t)f0 * B;
+            v.fit += (size_t)f0 * B;
+            v.centers += (size_t)f0 * B * 3;
+            v.normals += (size_t)f0 * B * 3;
+            v.results += f0;
+            v.results_host += f0;
+            return v;
+        };
+        const int fa = ((frames / 2) + 7) / 8 * 8;  // whole groups of eight frames (K1' deals frames to the 8 XCDs)
+        const PwppBatch a = half(0, fa), b = half(fa, frames - fa);
+        lrc = pwpp_launch_clear(&bt, h->stream);
+        HIPCHK(hipEventRecord(h->aux_fork, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->aux_stream, h->aux_fork, 0));
+        if (lrc == 0) lrc = pwpp_launch_pipeline(&a, h->stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (lrc == 0) lrc = pwpp_launch_pipeline(&b, h->aux_stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        HIPCHK(hipEventRecord(h->aux_join, h->aux_stream));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->aux_join, 0));
+    } else {
+        lrc = pwpp_launch_pipeline(&bt, h->stream, h->profiling ? h->ev_k : nullptr, h->aux_stream, h->aux_fork, h->aux_join,
+                                   ordered ? h->d_ord_a.p : nullptr, ordered ? h->d_ord_b.p : nullptr);
+    }
     if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
     h->profile_pending = h->profiling;
@@ -988,6 +1028,15 @@ int pwpp_set_output_order(pwpp_handle *h, int order) {
     if (rc) return rc;
     if ((rc = finish_pending(h))) return rc;
     h->output_order = order;
+    return PWPP_OK;
+}
+
+int pwpp_set_overlap(pwpp_handle *h, int on) {
+    if (!h) return fail(PWPP_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    h->overlap = on != 0;
     return PWPP_OK;
 }
 

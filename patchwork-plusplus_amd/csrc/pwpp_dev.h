@@ -103,7 +103,7 @@ struct PwppBatch {
     int32_t num_frames;
     int32_t max_n;               // largest frame of the batch
     int32_t debug;               // ablation switches for timing experiments only (PWPP_DEBUG_FLAGS); 0 in production
-    int32_t pad_;
+    int32_t no_clear;            // the caller already launched k_clear for these frames (overlap mode: two frame ranges, two streams)
     const uint32_t *cap_off;     // one-pass binning: [B+3] first slot of every bin's fixed segment inside a frame
                                  // (cap_off[B+2] = slots per frame); null on the two-pass path
     PwppStateScalar *st_scalar;  // [num_states]

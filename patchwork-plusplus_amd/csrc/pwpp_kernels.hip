@@ -1523,6 +1523,20 @@ __global__ __launch_bounds__(kBlock) void k_clear(uint4 *slabs, size_t n16, Pwpp
     }
 }
 
+// count (+ off, cursor on the two-pass path: adjacent slabs) and the result counters start at zero
+static void launch_clear(const PwppBatch &B, hipStream_t stream) {
+    const int F = B.num_frames, NB = B.P.num_bins + 2;
+    const size_t words = (size_t)(B.cap_off ? 1 : 3) * (size_t)F * (size_t)NB;
+    const size_t n16 = (words + 3) / 4;  // the slabs are followed by dst_a / dst_b, which K5 rewrites: rounding up is harmless
+    const size_t items = n16 > (size_t)F ? n16 : (size_t)F;
+    hipLaunchKernelGGL(k_clear, dim3((unsigned)((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                       reinterpret_cast<uint4 *>(B.bin_count), n16, B.results, F);
+}
+extern "C" int pwpp_launch_clear(const PwppBatch *batch, hipStream_t stream) {
+    if (batch->num_frames > 0) launch_clear(*batch, stream);
+    return (int)hipGetLastError();
+}
+
 extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev /* PWPP_NUM_KERNELS + 1 events or null */,
                                     hipStream_t aux, hipEvent_t aux_fork, hipEvent_t aux_join,
                                     unsigned long long *order_a /* reference-order mode: two scratch arrays, else null */,
@@ -1532,13 +1546,7 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     if (F <= 0) return 0;
     const int NB = B.P.num_bins + 2;
     const unsigned gx = (unsigned)((B.max_n + kPtsPerBlock - 1) / kPtsPerBlock);
-    {   // count (+ off, cursor on the two-pass path: adjacent slabs) and the result counters start at zero
-        const size_t words = (size_t)(B.cap_off ? 1 : 3) * (size_t)F * (size_t)NB;
-        const size_t n16 = (words + 3) / 4;  // the slabs are followed by dst_a / dst_b, which K5 rewrites: rounding up is harmless
-        const size_t items = n16 > (size_t)F ? n16 : (size_t)F;
-        hipLaunchKernelGGL(k_clear, dim3((unsigned)((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                           reinterpret_cast<uint4 *>(B.bin_count), n16, B.results, F);
-    }
+    if (!B.no_clear) launch_clear(B, stream);
     if (ev) (void)hipEventRecord(ev[0], stream);
     if (B.cap_off) {  // one-pass binning (fixed bin segments)
         const unsigned gx1 = (unsigned)((B.max_n + kOnePassPts - 1) / kOnePassPts);

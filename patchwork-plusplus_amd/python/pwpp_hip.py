@@ -100,6 +100,7 @@ def load():
         L.pwpp_get_fxp_shift.argtypes = [vp]
         L.pwpp_get_one_pass_stats.argtypes = [vp, vp, vp]
         L.pwpp_set_output_order.argtypes = [vp, ci]
+        L.pwpp_set_overlap.argtypes = [vp, ci]
         L.pwpp_kernel_name.argtypes = [ci]
         _lib = L
     return _lib
@@ -329,6 +330,10 @@ class Handle:
     def set_output_order(self, reference):
         """True: the points of a patch come out in the reference's order (z-sorted bins); False: scatter order."""
         self._check(self._L.pwpp_set_output_order(self._h, 1 if reference else 0))
+
+    def set_overlap(self, on):
+        """True: batches of 128+ frames run as two frame ranges on the handle's two streams (same results)."""
+        self._check(self._L.pwpp_set_overlap(self._h, 1 if on else 0))
 
     def one_pass_stats(self):
         """(batches launched with one-pass binning, batches redone on the two-pass path after an overflow)"""

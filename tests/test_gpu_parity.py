@@ -768,6 +768,37 @@ def test_handles_on_concurrent_host_threads(kitti, oracle):
             assert np.array_equal(nrm, fresh_refs[k].normals, equal_nan=True)
 
 
+def test_overlap_mode_two_frame_ranges_on_two_streams(kitti, oracle):
+    """pwpp_set_overlap: a batch of 128+ frames runs as two frame ranges with their own launches on the handle's
+    two streams (shared workspaces, shifted base pointers).  Fresh batch (one-pass binning, odd frame count)
+    and lock-step streams over several steps: every sampled frame bit-exact against the oracle, every frame
+    partitioned, replays agree."""
+    F = 301
+    frames = [kitti[i % 6] for i in range(F)]
+    refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(k) for k in kitti]
+    h = pwpp_hip.Handle()
+    h.set_overlap(True)
+    h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+    counts = h.all_counts()
+    for i in range(F):
+        assert tuple(counts[i, :3]) == tuple(counts[i % 6, :3])
+        assert counts[i, 0] + counts[i, 1] + counts[i, 5] == frames[i].shape[0]
+    for i in (0, 5, 150, 151, 152, 159, 160, 161, 299, 300):   # both sides of the split (152 = 19 groups of eight)
+        assert_frame_equal(h, i, refs[i % 6], frames[i].shape[0], check_state=False)
+    assert h.one_pass_stats()[1] == 0
+    S = 130
+    hs = pwpp_hip.Handle()
+    hs.set_num_streams(S)
+    hs.set_overlap(True)
+    sample = (0, 63, 64, 71, 72, 129)
+    ests = {s: ol.Estimator(oracle, arith=ol.ARITH_FXP) for s in sample}
+    for t in range(3):
+        fr = [kitti[(s + t) % 6] for s in range(S)]
+        hs.estimate_ground_batch(fr, mode=pwpp_hip.MODE_STREAMS)
+        for s in sample:
+            assert_frame_equal(hs, s, ests[s].run(fr[s]), fr[s].shape[0], state_index=s)
+
+
 def test_error_reporting_on_the_device(kitti):
     """Misuse comes back as an error code + message (RuntimeError in Python), never as a wrong result:
     more frames than streams, a misaligned device buffer, unsupported parameters, reading results

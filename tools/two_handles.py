@@ -14,8 +14,11 @@ for i in range(F):  # distinct buffers, as bench.py
 torch.cuda.synchronize()
 def batch(h, lo, hi):
     return h.make_device_batch([big[i].data_ptr() for i in range(lo, hi)], [big[i].shape[0] for i in range(lo, hi)])
-for parts in (1, 2, 4):
+for parts in (1, 0, 2, 4):  # 0 = one handle in overlap mode
+    overlap = parts == 0
+    parts = max(parts, 1)
     hs = [pwpp_hip.Handle() for _ in range(parts)]
+    if overlap: hs[0].set_overlap(True)
     per = F // parts
     bs = [batch(hs[p], p * per, (p + 1) * per) for p in range(parts)]
     def step():
@@ -27,5 +30,5 @@ for parts in (1, 2, 4):
     t0 = time.perf_counter()
     for _ in range(10): step()
     dt = (time.perf_counter() - t0) / 10
-    print("%d handle(s) x %4d frames: %.3f ms per 1024 frames, %.0f frames/s" % (parts, per, dt * 1e3, F / dt))
+    print("%d handle(s) x %4d frames%s: %.3f ms per 1024 frames, %.0f frames/s" % (parts, per, " (overlap mode)" if overlap else "", dt * 1e3, F / dt))
     for h in hs: h.close()
