@@ -565,6 +565,7 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
     const int storage = p->max_elevation_storage > p->max_flatness_storage ? p->max_elevation_storage : p->max_flatness_storage;
     h->stream_hist_cap = storage + max_near_sectors + 1024;
     h->fresh_hist_cap = max_near_sectors + 2;
+    h->overlap = std::getenv("PWPP_OVERLAP") != nullptr;  // (pwpp_set_overlap; the variable is for running existing programs and the test suite in that mode)
     hipError_t se = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&h->aux_fork, hipEventDisableTiming);
