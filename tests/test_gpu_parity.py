@@ -786,6 +786,21 @@ def test_overlap_mode_two_frame_ranges_on_two_streams(kitti, oracle):
     for i in (0, 5, 150, 151, 152, 159, 160, 161, 299, 300):   # both sides of the split (152 = 19 groups of eight)
         assert_frame_equal(h, i, refs[i % 6], frames[i].shape[0], check_state=False)
     assert h.one_pass_stats()[1] == 0
+    # a wedge-shaped cloud in the second range overflows its bin segments: the whole batch is redone on the two-pass
+    # path, again as two ranges; and lock-step streams whose state must be restored before the redo
+    rng = np.random.default_rng(5)
+    wedge = kitti[0].copy()
+    sel = rng.random(wedge.shape[0]) < 0.7
+    r = np.hypot(wedge[sel, 0], wedge[sel, 1])
+    a = rng.uniform(0.1, 0.27, sel.sum())
+    wedge[sel, 0] = (r * np.cos(a)).astype(np.float32)
+    wedge[sel, 1] = (r * np.sin(a)).astype(np.float32)
+    odd = frames[:200] + [wedge] + frames[:39]
+    h.estimate_ground_batch(odd, mode=pwpp_hip.MODE_FRESH)
+    assert h.one_pass_stats() == (2, 1)
+    assert_frame_equal(h, 200, ol.Estimator(oracle, arith=ol.ARITH_FXP).run(wedge), wedge.shape[0], check_state=False)
+    for i in (0, 119, 120, 199, 201, 239):
+        assert_frame_equal(h, i, refs[(i if i < 200 else i - 201) % 6], odd[i].shape[0], check_state=False)
     S = 130
     hs = pwpp_hip.Handle()
     hs.set_num_streams(S)
