@@ -787,7 +787,7 @@ def test_overlap_mode_two_frame_ranges_on_two_streams(kitti, oracle):
         assert_frame_equal(h, i, refs[i % 6], frames[i].shape[0], check_state=False)
     assert h.one_pass_stats()[1] == 0
     # a wedge-shaped cloud in the second range overflows its bin segments: the whole batch is redone on the two-pass
-    # path, again as two ranges; and lock-step streams whose state must be restored before the redo
+    # path, again as two ranges
     rng = np.random.default_rng(5)
     wedge = kitti[0].copy()
     sel = rng.random(wedge.shape[0]) < 0.7
