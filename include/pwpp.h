@@ -150,7 +150,14 @@ int pwpp_set_num_streams(pwpp_handle *h, int streams); /* (re)creates `streams` 
 /* sizes of getGround()/getNonground()/getCenters(), reference patchworkpp.h:157-163 */
 int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32_t *n_nonground, int32_t *n_patches);
 /* getGroundIndices()/getNongroundIndices(), reference patchworkpp.h:159-160, patchworkpp.cpp:18-26.
- * Same index SETS as the reference; order inside a list is not the reference's. */
+ * The index SETS are those of the reference's control flow evaluated with the plane-fit sums of
+ * patchworkpp.cpp:56-60 in exact arithmetic: bit-identical to the CPU restatement of that
+ * contract (oracle/), and on every cloud of the test suite identical to the "exact-f64" build of the
+ * reference.  A float build of the reference (Eigen) adds those sums up in float; its own rounding then
+ * moves a point that lies within ~1e-4 m of a threshold now and then (measured: 0-2 of 480 000 indices on
+ * dense synthetic clouds, none on the KITTI samples; plane normals agree to 1e-4 except for ill-conditioned
+ * patches, where a float build departs from exact arithmetic by more than this library does).
+ * The order inside a list is not the reference's unless pwpp_set_output_order asks for it. */
 int pwpp_get_ground_indices(pwpp_handle *h, int frame, int32_t *out);
 int pwpp_get_nonground_indices(pwpp_handle *h, int frame, int32_t *out);
 /* getGround()/getNonground(), reference patchworkpp.h:157-158: row-major (count,3) float32,
@@ -203,8 +210,10 @@ int pwpp_set_profiling(pwpp_handle *h, int enable);
 int pwpp_get_kernel_profile(pwpp_handle *h, double *sum_ms /*[PWPP_NUM_KERNELS]*/, int64_t *launches /*[PWPP_NUM_KERNELS]*/);
 int pwpp_reset_kernel_profile(pwpp_handle *h);
 const char *pwpp_kernel_name(int k);
-/* fixed-point shift s of the plane-fit arithmetic contract for this handle */
+/* the fixed-point contract of the plane-fit sums for this handle: the shift s (grid 2^-s m) ... */
 int pwpp_get_fxp_shift(pwpp_handle *h);
+/* ... and every bin's origin (its polar centre rounded to 1/8 m): out_xy = B x {x, y}; returns B */
+int pwpp_get_fxp_origins(pwpp_handle *h, float *out_xy, int capacity_bins);
 /* Order of the points INSIDE a patch's part of the index lists (the parts themselves always follow the
  * reference: bin traversal order, TGR candidates at the end of their ring).
  *   PWPP_ORDER_SCATTER   (default) whatever the binning atomics produced -- same sets, fastest;
@@ -225,6 +234,25 @@ int pwpp_set_overlap(pwpp_handle *h, int on);
  * them had to be redone on the exact two-pass path because a bin outgrew its segment.  Finishes the
  * batch in flight first.  No reference counterpart. */
 int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone);
+
+
+/* Tuning and test switches (no reference counterpart).  The environment variables PWPP_DEBUG_FLAGS,
+ * PWPP_FIT_PLAN, PWPP_FIT_CONCURRENT, PWPP_NO_ONE_PASS, PWPP_ONE_PASS_MIN_FRAMES, PWPP_ONE_PASS_SCALE and
+ * PWPP_OVERLAP set the same options ONCE, in pwpp_create (which says so on stderr); nothing reads the
+ * environment afterwards.  None of them changes a result.
+ *   "fit_plan"            which fit kernel handles which patch sizes, e.g. "W16:1023,W64.2:65535"; "" = automatic
+ *   "fit_concurrent"      "1": the classes of a plan side by side on two streams
+ *   "one_pass"            "0": always the two-pass binning
+ *   "one_pass_min_frames" smallest batch that takes the one-pass binning (default 5)
+ *   "one_pass_scale"      segment size of a bin in multiples of its even share of a frame (default 4)
+ *   "debug_flags"         4: timing probes of the fit chain; 16: exact binning arithmetic only;
+ *                         16384 / 32768: force the fall-back paths of the lowest-point selection
+ * Returns PWPP_E_ARG for an unknown name or a value out of range. */
+int pwpp_set_option(pwpp_handle *h, const char *name, const char *value);
+/* Frees the per-batch workspaces (a handle that processed one large batch otherwise keeps them, e.g. 52 GB
+ * after 1024 KITTI frames with one-pass binning); streams' state and results of the last call are kept
+ * only as far as they live outside those buffers: fetch results first.  The next call allocates again. */
+int pwpp_trim_workspace(pwpp_handle *h);
 
 #ifdef __cplusplus
 }

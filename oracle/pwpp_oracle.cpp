@@ -10,17 +10,23 @@
 // golden vector or known-answer fixture for this path, and the
 // arithmetic of PatchWorkpp::estimate_plane lives in Eigen 3.4.0
 // (cpp/cmake/eigen.cmake:31), which is absent from /root/reference and from this image.
-// What pins this file instead: tests/test_oracle_vs_ref.py requires it to agree
-// BIT FOR BIT -- index lists in the reference's own output order, centres, normals,
-// adaptive thresholds and histories -- with the reference's unmodified patchworkpp.cpp
-// compiled against oracle/eigen_shim (oracle/_ref/libpwpp_ref*.so), on all six KITTI
-// sample frames, in both arithmetic flavours, stateless and as a six-frame sequence.
+// What pins this file instead: tests/test_oracle.py requires it to agree BIT FOR BIT --
+// index lists in the reference's own output order, centres, normals, adaptive thresholds
+// and histories -- with the reference's unmodified patchworkpp.cpp compiled against
+// oracle/eigen_shim (oracle/_ref/libpwpp_ref*.so), on the six KITTI sample frames and on
+// synthetic clouds, in every flavour the shim has, stateless and as a sequence.
 //
 // Arithmetic flavours for the plane fit (the only place where the reference defers to
 // Eigen); everything else follows the reference's own float/double expressions:
 //   PWO_ARITH_EIGEN_F32  float accumulators in storage order (plain reading of Eigen)
 //   PWO_ARITH_FXP        fixed-point, order-independent contract;
 //                        this is the flavour the HIP kernels must match bit for bit.
+//   PWO_ARITH_EXACT_F64  reference-neutral arbiter: what :56-60 give in (near-)exact
+//                        arithmetic -- double accumulation of the unquantised floats, one
+//                        rounding to float per output.  Neither the product nor the
+//                        reference computes this; both are measured against it.
+//   PWO_ARITH_F32_PACKET4 float again, four partial sums: a witness of how far float
+//                        results move with the summation order alone.
 #include <algorithm>
 #include <chrono>
 #include <cfloat>
@@ -65,19 +71,84 @@ struct Candidate {  // reference patchworkpp.h:29-40 (RevertCandidate)
 float f_abs(float v) { return v < 0.0f ? -v : v; }
 float f_max(float a, float b) { return a < b ? b : a; }
 
-int fxp_shift_for(double max_range) {
-    int s = 20;
-    while (s > 0 && max_range * (double)(1 << s) > 8388607.0) --s;
-    return s;
+// ---------------------------------------------------------------------------------
+// The fixed-point contract of the plane-fit sums, version 2.
+//   * every CZM bin has an ORIGIN (ox, oy): its polar centre rounded to 1/8 m; R = the largest
+//     distance of any bin corner from its origin;
+//   * s = the largest shift <= 21 with (R + 0.01) * 2^s <= 2^26; ZR = 2^(26 - s) metres;
+//   * every visit of a bin (ref :206) has a z origin z0: the first lowest-point representative
+//     the visit computes (ref :103), rounded to 1/8 m (0 if it is not finite, +-4096 at most);
+//   * Q_x(v) = rint(double(v) * 2^s - ox * 2^s), Q_y alike, Q_z(v) the same around z0 after
+//     clamping v to [z0 - ZR, z0 + ZR] in float (fmaxf, then fminf);
+//   * exact integer moments n, S1_a = sum Q_a, S2_ab = sum Q_a Q_b;
+//   * mean_a = float(double(S1_a) / double(n) * 2^-s + origin_a);
+//     cov_ab = float(double(n S2_ab - S1_a S1_b) / (double(n) double(n-1)) * 2^-2s), numerator exact.
+// ---------------------------------------------------------------------------------
+constexpr int kFxpMaxShift = 21;
+constexpr double kFxpQMax = 67108864.0;  // 2^26
+
+struct FxpGeom {
+    int shift = 0;
+    double scale = 1.0;  // 2^shift
+    double zr = 0.0;     // 2^(26 - shift)
+    std::vector<float> ox, oy;
+};
+
+// geometry in double, exactly as the reference's constructor computes it (patchworkpp.h:122-134)
+FxpGeom fxp_geometry(const double min_ranges[4], const double ring_sizes[4], const double sector_sizes[4],
+                     const int rings[4], const int sectors[4], double max_range) {
+    FxpGeom g;
+    double rmax = 0.0;
+    for (int z = 0; z < 4; ++z)
+        for (int r = 0; r < rings[z]; ++r)
+            for (int k = 0; k < sectors[z]; ++k) {
+                const double r0 = min_ranges[z] + r * ring_sizes[z];
+                const double r1 = (z == 3 && r == rings[z] - 1) ? max_range : r0 + ring_sizes[z];
+                const double t0 = k * sector_sizes[z], t1 = (k + 1) * sector_sizes[z];
+                double cx = 0.0, cy = 0.0;
+                if (sectors[z] >= 4) {  // (a sector wider than a quarter turn keeps the sensor as origin)
+                    const double rc = 0.5 * (r0 + r1), tc = 0.5 * (t0 + t1);
+                    cx = std::rint(rc * std::cos(tc) * 8.0) / 8.0;
+                    cy = std::rint(rc * std::sin(tc) * 8.0) / 8.0;
+                }
+                g.ox.push_back((float)cx);
+                g.oy.push_back((float)cy);
+                double far = 0.0;
+                if (sectors[z] >= 4) {
+                    const double cr[2] = {r0, r1}, ct[2] = {t0, t1};
+                    for (int a = 0; a < 2; ++a)
+                        for (int b = 0; b < 2; ++b) {
+                            const double dx = cr[a] * std::cos(ct[b]) - cx, dy = cr[a] * std::sin(ct[b]) - cy;
+                            far = std::max(far, std::sqrt(dx * dx + dy * dy));
+                        }
+                } else {
+                    far = r1;
+                }
+                rmax = std::max(rmax, far);
+            }
+    int s = kFxpMaxShift;
+    while (s > 0 && (rmax + 0.01) * (double)(1 << s) > kFxpQMax) --s;
+    g.shift = s;
+    g.scale = (double)(1 << s);
+    g.zr = kFxpQMax / g.scale;
+    return g;
 }
 
-int32_t fxp_quantise(float v, int s) {  // Q(v)
-    float t = v * (float)(1 << s);
-    if (!(t == t)) return 0;
-    t = std::rint(t);
-    if (t > 8388607.0f) t = 8388607.0f;
-    if (t < -8388607.0f) t = -8388607.0f;
-    return (int32_t)t;
+double fxp_z_origin(double lpr) {
+    if (!(std::fabs(lpr) <= DBL_MAX)) return 0.0;  // NaN, +-inf
+    double t = std::rint(lpr * 8.0) / 8.0;
+    if (t > 4096.0) t = 4096.0;
+    if (t < -4096.0) t = -4096.0;
+    return t;
+}
+
+int64_t fxp_quantise(float v, double origin, double scale) {  // Q_x, Q_y
+    return (int64_t)std::rint((double)v * scale - origin * scale);
+}
+int64_t fxp_quantise_z(float v, double z0, double zr, double scale) {
+    const float lo = (float)(z0 - zr), hi = (float)(z0 + zr);
+    const float c = std::fmin(std::fmax(v, lo), hi);  // NaN -> lo, as v_max_f32 / v_min_f32 do
+    return (int64_t)std::rint((double)c * scale - z0 * scale);
 }
 
 // ---------------------------------------------------------------------------------
@@ -214,7 +285,8 @@ public:
         num_bins = base;
         bins.resize((size_t)num_bins);
         std::memset(&plane, 0, sizeof(plane));
-        shift = fxp_shift_for(prm.max_range);
+        fxp = fxp_geometry(min_ranges, ring_sizes, sector_sizes, prm.num_rings_each_zone, prm.num_sectors_each_zone,
+                           prm.max_range);
     }
 
     pwo_params prm;  // params_ of the reference; sensor_height / thresholds mutate (:347-350,368)
@@ -223,6 +295,14 @@ public:
     std::vector<pwo_patch_record> records;
     long time_taken = 0;
     long fits = 0, sweeps = 0;
+    void get_fxp(int *shift, double *zr, float *ox, float *oy) const {
+        *shift = fxp.shift;
+        *zr = fxp.zr;
+        for (int b = 0; b < num_bins; ++b) {
+            if (ox) ox[b] = fxp.ox[(size_t)b];
+            if (oy) oy[b] = fxp.oy[(size_t)b];
+        }
+    }
 
     // ------------------------------------------------------------------ estimateGround
     void estimate_ground(const float *pts, int n, int cols) {  // reference :151-336
@@ -255,6 +335,8 @@ public:
                         continue;
                     }
                     std::sort(cell.begin(), cell.end(), z_less);  // :199
+                    cur_bin = bin;
+                    z0_set = false;
                     extract_piecewiseground(zone, cell, rg, rng);  // :206
 
                     centers.push_back(Pt{plane.mean[0], plane.mean[1], plane.mean[2], -1});     // :211
@@ -344,7 +426,10 @@ public:
 
 private:
     int arith_;
-    int shift;
+    FxpGeom fxp;
+    int cur_bin = 0;          // the bin extract_piecewiseground is working on
+    bool z0_set = false;      // fxp: z origin of this visit (first LPR, ref :103)
+    double z0 = 0.0;
     double min_ranges[4], ring_sizes[4], sector_sizes[4];
     int bin_base[4];
     int num_bins;
@@ -425,6 +510,10 @@ private:
             cnt++;
         }
         const double lpr_height = cnt != 0 ? sum / cnt : 0;
+        if (!z0_set) {  // fxp contract: the visit's z origin
+            z0 = fxp_z_origin(lpr_height);
+            z0_set = true;
+        }
         for (size_t i = 0; i < sorted.size(); ++i)
             if (sorted[i].z < lpr_height + th_seed) seeds.push_back(sorted[i]);
     }
@@ -451,22 +540,60 @@ private:
                         acc += (coord(g[(size_t)i], a) - mean[a]) * (coord(g[(size_t)i], b) - mean[b]);
                     cov[a * 3 + b] = acc / den;
                 }
+        } else if (arith_ == PWO_ARITH_EXACT_F64) {
+            // reference-neutral arbiter: double accumulation of the unquantised floats (two passes,
+            // the products are centred on the double mean), one rounding to float per output
+            double md[3];
+            for (int j = 0; j < 3; ++j) {
+                double acc = 0.0;
+                for (int i = 0; i < n; ++i) acc += (double)coord(g[(size_t)i], j);
+                md[j] = acc / (double)n;
+                mean[j] = (float)md[j];
+            }
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    double acc = 0.0;
+                    for (int i = 0; i < n; ++i)
+                        acc += ((double)coord(g[(size_t)i], a) - md[a]) * ((double)coord(g[(size_t)i], b) - md[b]);
+                    cov[a * 3 + b] = (float)(acc / (double)(n - 1));
+                }
+        } else if (arith_ == PWO_ARITH_F32_PACKET4) {
+            // float, four partial sums (lane = row mod 4, combined pairwise, then the tail): what a
+            // 4-wide SIMD reduction forms.  Not a claim about real Eigen's order.
+            auto sum4 = [&](auto term) {
+                float lane[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                const int n4 = n & ~3;
+                for (int i = 0; i < n4; i += 4)
+                    for (int l = 0; l < 4; ++l) lane[l] += term(i + l);
+                float acc = (lane[0] + lane[2]) + (lane[1] + lane[3]);
+                for (int i = n4; i < n; ++i) acc += term(i);
+                return acc;
+            };
+            for (int j = 0; j < 3; ++j) mean[j] = sum4([&](int i) { return coord(g[(size_t)i], j); }) / (float)n;
+            const float den = (float)(double)(n - 1);
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b)
+                    cov[a * 3 + b] = sum4([&](int i) {
+                                         return (coord(g[(size_t)i], a) - mean[a]) * (coord(g[(size_t)i], b) - mean[b]);
+                                     }) / den;
         } else {
-            // exact integer moments of the quantised coordinates
+            // the fixed-point contract (top of this file): exact integer moments around the bin's origin
+            const double org[3] = {(double)fxp.ox[(size_t)cur_bin], (double)fxp.oy[(size_t)cur_bin], z0};
             int64_t s1[3] = {0, 0, 0};
             __int128 s2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (int i = 0; i < n; ++i) {
-                int32_t q[3];
-                for (int j = 0; j < 3; ++j) q[j] = fxp_quantise(coord(g[(size_t)i], j), shift);
+                const Pt &p = g[(size_t)i];
+                const int64_t q[3] = {fxp_quantise(p.x, org[0], fxp.scale), fxp_quantise(p.y, org[1], fxp.scale),
+                                      fxp_quantise_z(p.z, z0, fxp.zr, fxp.scale)};
                 for (int a = 0; a < 3; ++a) {
                     s1[a] += q[a];
-                    for (int b = 0; b < 3; ++b) s2[a * 3 + b] += (int64_t)q[a] * (int64_t)q[b];
+                    for (int b = 0; b < 3; ++b) s2[a * 3 + b] += (__int128)q[a] * (__int128)q[b];
                 }
             }
-            const double inv = 1.0 / (double)(1 << shift);
+            const double inv = 1.0 / fxp.scale;
             const double den = (double)n * (double)(n - 1);
             for (int a = 0; a < 3; ++a) {
-                mean[a] = (float)(((double)s1[a] / (double)n) * inv);
+                mean[a] = (float)(((double)s1[a] / (double)n) * inv + org[a]);
                 for (int b = 0; b < 3; ++b) {
                     const __int128 num = (__int128)n * s2[a * 3 + b] - (__int128)s1[a] * (__int128)s1[b];
                     cov[a * 3 + b] = (float)(((double)num / den) * (inv * inv));
@@ -649,7 +776,7 @@ void pwo_default_params(pwo_params *p) {  // reference patchworkpp.h:79-111
     p->max_elevation_storage = 1000;
 }
 
-int pwo_arith_supported(int arith) { return arith == PWO_ARITH_EIGEN_F32 || arith == PWO_ARITH_FXP; }
+int pwo_arith_supported(int arith) { return arith >= PWO_ARITH_EIGEN_F32 && arith <= PWO_ARITH_F32_PACKET4; }
 
 void *pwo_create(const pwo_params *p, int arith) {
     if (!pwo_arith_supported(arith)) return nullptr;
@@ -720,13 +847,19 @@ void pwo_ext_set_state(void *h, double sensor_height, const double *elev, const 
     }
 }
 void pwo_ext_jacobi(const float *cov9, float *u9, float *sv3) { jacobi_svd3(cov9, u9, sv3, nullptr); }
-int pwo_ext_fxp_shift(double max_range) { return fxp_shift_for(max_range); }
+void pwo_ext_fxp_geometry(void *h, int *shift, double *zr, float *ox, float *oy) {
+    ((Oracle *)h)->get_fxp(shift, zr, ox, oy);
+}
 long pwo_ext_max_sweeps(int reset) {
     const long v = g_max_sweeps;
     if (reset) g_max_sweeps = 0;
     return v;
 }
-int32_t pwo_ext_quantise(float v, int shift) { return fxp_quantise(v, shift); }
+long long pwo_ext_quantise(float v, double origin, int shift) { return fxp_quantise(v, origin, (double)(1 << shift)); }
+long long pwo_ext_quantise_z(float v, double z0, int shift) {
+    return fxp_quantise_z(v, z0, kFxpQMax / (double)(1 << shift), (double)(1 << shift));
+}
+double pwo_ext_z_origin(double lpr) { return fxp_z_origin(lpr); }
 
 double pwo_bench(const pwo_params *p, int arith, const float *const *frames, const int *n_points, int cols,
                  int num_distinct, int total, int threads, double *sum_call_seconds) {

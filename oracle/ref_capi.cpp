@@ -3,8 +3,9 @@
 // C wrapper (oracle/oracle_api.h) around the reference's own class
 // patchwork::PatchWorkpp.  Built by oracle/Makefile together with the
 // UNMODIFIED /root/reference/cpp/patchworkpp/src/patchworkpp.cpp and the
-// Eigen stand-in oracle/eigen_shim into oracle/_ref/libpwpp_ref.so
-// (eigen-f32 flavour) and oracle/_ref/libpwpp_ref_fxp.so (fxp flavour).
+// Eigen stand-in oracle/eigen_shim into oracle/_ref/libpwpp_ref.so (eigen-f32
+// flavour), libpwpp_ref_exact.so (exact-f64 arbiter) and libpwpp_ref_pk4.so
+// (float, 4-lane summation order).
 // No reference source is copied: the compiler reads it where it lies.
 #include <chrono>
 #include <cstdint>
@@ -29,12 +30,6 @@
 #include "oracle_api.h"
 
 namespace {
-
-int fxp_shift_for(double max_range) {  // DESIGN.md section 4, same rule as the product
-    int s = 20;
-    while (s > 0 && max_range * (double)(1 << s) > 8388607.0) --s;
-    return s;
-}
 
 patchwork::Params to_ref_params(const pwo_params &p) {
     patchwork::Params r;
@@ -88,7 +83,6 @@ struct MuteCout {
 
 struct Handle {
     patchwork::PatchWorkpp *pw;
-    int shift;
 };
 
 }  // namespace
@@ -128,13 +122,12 @@ void pwo_default_params(pwo_params *p) {
     p->max_elevation_storage = d.max_elevation_storage;
 }
 
-int pwo_arith_supported(int arith) { return arith == (PWPP_SHIM_FXP ? PWO_ARITH_FXP : PWO_ARITH_EIGEN_F32); }
+int pwo_arith_supported(int arith) { return arith == PWPP_SHIM_ARITH; }  // flavours are compile-time here
 
 void *pwo_create(const pwo_params *p, int arith) {
     if (!pwo_arith_supported(arith)) return nullptr;
     MuteCout mute;
     Handle *h = new Handle;
-    h->shift = fxp_shift_for(p->max_range);
     h->pw = new patchwork::PatchWorkpp(to_ref_params(*p));
     return h;
 }
@@ -148,7 +141,6 @@ void pwo_destroy(void *hv) {
 
 int pwo_estimate_ground(void *hv, const float *pts, int n, int cols) {
     Handle *h = (Handle *)hv;
-    Eigen::shim::fxp_shift() = h->shift;
     h->pw->estimateGround(to_matrix(pts, n, cols));
     return 0;
 }
@@ -198,7 +190,6 @@ void pwo_get_counters(long *plane_fits, long *jacobi_sweeps) {
 double pwo_bench(const pwo_params *p, int arith, const float *const *frames, const int *n_points, int cols,
                  int num_distinct, int total, int threads, double *sum_call_seconds) {
     if (!pwo_arith_supported(arith) || threads < 1) return -1.0;
-    Eigen::shim::fxp_shift() = fxp_shift_for(p->max_range);
     std::vector<Eigen::MatrixXf> mats;
     for (int k = 0; k < num_distinct; ++k) mats.push_back(to_matrix(frames[k], n_points[k], cols));
     const patchwork::Params rp = to_ref_params(*p);

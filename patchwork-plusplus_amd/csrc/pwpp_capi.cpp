@@ -105,6 +105,13 @@ struct pwpp_handle {
     hipStream_t aux_stream = nullptr;  // second stream for the latency plan (few frames)
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     bool overlap = false;  // pwpp_set_overlap: big batches as two frame ranges on the two streams
+    // tuning / test options (pwpp_set_option; the PWPP_* environment variables are read ONCE, in pwpp_create)
+    int debug_flags = 0;
+    std::string fit_plan;
+    bool fit_concurrent = false;
+    bool no_one_pass = false;
+    int one_pass_min_frames = 5;
+    double one_pass_scale = 4.0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     hipEvent_t ev_k[PWPP_NUM_KERNELS + 1] = {};
     bool profiling = false;
@@ -137,8 +144,10 @@ struct pwpp_handle {
     PinnedBuf<int64_t> h_base;
     DevBuf<float> d_in;  // staging for host inputs
     DevBuf<uint16_t> d_codes;
-    DevBuf<PwppXyz> d_sorted_xyz;
+    DevBuf<float> d_sorted_z;     // the bin-ordered planes (pwpp_dev.h): z, {x, y}, cloud index
+    DevBuf<float2> d_sorted_xy;
     DevBuf<int> d_sorted_idx;
+    DevBuf<float2> d_bin_origin;  // [B] origins of the fixed-point plane-fit sums
     DevBuf<int32_t> d_plist;
     DevBuf<int32_t> d_out;
     DevBuf<unsigned long long> d_ord_a, d_ord_b;  // scratch of the reference-order mode (long sub-lists)
@@ -148,7 +157,6 @@ struct pwpp_handle {
     DevBuf<uint32_t> d_cap_off;    // B + 3 segment starts of the one-pass path
     DevBuf<uint16_t> d_cls_list;   // frames * B
     DevBuf<PwppPatchRec> d_recs;
-    DevBuf<PwppFitState> d_fit;
     DevBuf<float> d_centers, d_normals;
     DevBuf<PwppFrameResult> d_results;
     PinnedBuf<PwppFrameResult> h_results;
@@ -168,10 +176,37 @@ struct pwpp_handle {
 
 namespace {
 
-int fxp_shift_for(double max_range) {
-    int s = 20;
-    while (s > 0 && max_range * (double)(1 << s) > 8388607.0) --s;
-    return s;
+// The fixed-point contract of the plane-fit sums: every bin sums its points around an
+// ORIGIN, its polar centre rounded to 1/8 m (a sector wider than a quarter turn keeps the sensor), and the
+// shift s is the largest one <= 21 that keeps every point of every bin within 2^26 grid steps of its origin.
+void fxp_geometry(const PwppDevParams &d, std::vector<float2> &origin, int &shift) {
+    double rmax = 0.0;
+    origin.clear();
+    for (int z = 0; z < 4; ++z)
+        for (int r = 0; r < d.rings[z]; ++r)
+            for (int k = 0; k < d.sectors[z]; ++k) {
+                const double r0 = d.min_ranges[z] + r * d.ring_sizes[z];
+                const double r1 = (z == 3 && r == d.rings[z] - 1) ? d.max_range : r0 + d.ring_sizes[z];
+                const double t0 = k * d.sector_sizes[z], t1 = (k + 1) * d.sector_sizes[z];
+                double cx = 0.0, cy = 0.0, far = r1;
+                if (d.sectors[z] >= 4) {
+                    const double rc = 0.5 * (r0 + r1), tc = 0.5 * (t0 + t1);
+                    cx = std::rint(rc * std::cos(tc) * 8.0) / 8.0;
+                    cy = std::rint(rc * std::sin(tc) * 8.0) / 8.0;
+                    far = 0.0;
+                    const double cr[2] = {r0, r1}, ct[2] = {t0, t1};
+                    for (int a = 0; a < 2; ++a)
+                        for (int b = 0; b < 2; ++b) {
+                            const double dx = cr[a] * std::cos(ct[b]) - cx, dy = cr[a] * std::sin(ct[b]) - cy;
+                            far = std::max(far, std::sqrt(dx * dx + dy * dy));
+                        }
+                }
+                origin.push_back(make_float2((float)cx, (float)cy));
+                rmax = std::max(rmax, far);
+            }
+    int s = 21;
+    while (s > 0 && (rmax + 0.01) * (double)(1 << s) > 67108864.0) --s;
+    shift = s;
 }
 
 int build_dev_params(const pwpp_params &p, PwppDevParams &d) {
@@ -182,7 +217,7 @@ int build_dev_params(const pwpp_params &p, PwppDevParams &d) {
     if (p.num_rings_of_interest < 0 || p.num_rings_of_interest > PWPP_MAX_ROI)
         return fail(PWPP_E_ARG, "num_rings_of_interest=%d: the reference keeps update_*_[4] (patchworkpp.h:174-175)", p.num_rings_of_interest);
     if (!(p.max_range > p.min_range)) return fail(PWPP_E_ARG, "max_range must exceed min_range");
-    if (!(p.max_range <= 8388607.0)) return fail(PWPP_E_UNSUPPORTED, "max_range=%g: the fixed-point plane-fit sums hold coordinates up to 2^23 - 1 m", p.max_range);
+    if (!(p.max_range <= 8388607.0)) return fail(PWPP_E_UNSUPPORTED, "max_range=%g: at most 2^23 - 1 m supported", p.max_range);
     if (p.max_flatness_storage < 0 || p.max_elevation_storage < 0) return fail(PWPP_E_ARG, "negative history storage");
     std::memset(&d, 0, sizeof(d));
     int bins = 0, total_rings = 0, near = 0, max_near_sectors = 0;
@@ -236,7 +271,7 @@ int build_dev_params(const pwpp_params &p, PwppDevParams &d) {
     d.min_range = p.min_range;
     d.uprightness_thr = p.uprightness_thr;
     d.margin = p.adaptive_seed_selection_margin;
-    d.fxp_shift = fxp_shift_for(p.max_range);
+    d.fxp_shift = 0;  // (pwpp_create: fxp_geometry)
     d.f_min_range = (float)p.min_range;
     d.f_max_range = (float)p.max_range;
     d.f_margin_r = (float)(p.max_range * 1.5e-6 + 5e-5);  // metres; ~5x the float error budget of the radius
@@ -279,9 +314,7 @@ int finish_pending(pwpp_handle *h);
 int build_capacity_table(pwpp_handle *h, int max_n) {
     const PwppDevParams &P = h->dp;
     const int B = P.num_bins, NB = B + 2;
-    double scale = 4.0;
-    if (const char *e = std::getenv("PWPP_ONE_PASS_SCALE")) scale = std::atof(e);
-    if (!(scale > 0.0)) scale = 4.0;
+    const double scale = h->one_pass_scale;
     std::vector<uint32_t> off((size_t)NB + 1);
     uint64_t run = 0;
     for (int b = 0; b < NB; ++b) {
@@ -338,10 +371,9 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     bt.frames = h->d_frames.p;
     bt.num_frames = h->frames;
     bt.max_n = h->max_n;
-    {
-        const char *dbg = std::getenv("PWPP_DEBUG_FLAGS");  // timing ablations only; results are wrong when set
-        bt.debug = dbg ? std::atoi(dbg) : 0;
-    }
+    bt.debug = h->debug_flags;
+    bt.fit_plan = h->fit_plan.empty() ? nullptr : h->fit_plan.c_str();
+    bt.fit_concurrent = h->fit_concurrent ? 1 : 0;
     if (h->mode == PWPP_MODE_FRESH) {
         bt.P.hist_cap = h->fresh_hist_cap;
         bt.st_scalar = h->d_st_fresh.p;
@@ -360,11 +392,12 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     bt.dst_b = h->d_bins.p + 4 * slab;
     bt.cls_start = h->d_cls_start.p;
     bt.cls_list = h->d_cls_list.p;
-    bt.sorted_xyz = h->d_sorted_xyz.p;
+    bt.sorted_z = h->d_sorted_z.p;
+    bt.sorted_xy = h->d_sorted_xy.p;
     bt.sorted_idx = h->d_sorted_idx.p;
+    bt.bin_origin = h->d_bin_origin.p;
     bt.plist = h->d_plist.p;
     bt.recs = h->d_recs.p;
-    bt.fit = h->d_fit.p;
     bt.out_idx = h->d_out.p;
     bt.centers = h->d_centers.p;
     bt.normals = h->d_normals.p;
@@ -401,7 +434,6 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
             v.cls_start += (size_t)f0 * PWPP_CLS_STRIDE;
             v.cls_list += (size_t)f0 * B;
             v.recs += (size_t)f0 * B;
-            v.fit += (size_t)f0 * B;
             v.centers += (size_t)f0 * B * 3;
             v.normals += (size_t)f0 * B * 3;
             v.results += f0;
@@ -558,10 +590,29 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
                     e != hipSuccess ? hipGetErrorString(e) : "0 devices");
     if (device < 0 || device >= ndev) return fail(PWPP_E_ARG, "device %d out of range [0,%d)", device, ndev);
     HIPCHK(hipSetDevice(device));
+    std::vector<float2> origin;
+    fxp_geometry(dp, origin, dp.fxp_shift);
+    dp.fxp_zr = (float)(67108864.0 / (double)(1 << dp.fxp_shift));
     pwpp_handle *h = new pwpp_handle;
     h->params = *p;
     h->dp = dp;
     h->device = device;
+    // The tuning / test switches: read once, here (not in the launch path), and said out loud.
+    if (const char *e = std::getenv("PWPP_DEBUG_FLAGS")) h->debug_flags = std::atoi(e);
+    if (const char *e = std::getenv("PWPP_FIT_PLAN")) h->fit_plan = e;
+    h->fit_concurrent = std::getenv("PWPP_FIT_CONCURRENT") != nullptr;
+    h->no_one_pass = std::getenv("PWPP_NO_ONE_PASS") != nullptr;
+    if (const char *e = std::getenv("PWPP_ONE_PASS_MIN_FRAMES")) h->one_pass_min_frames = std::atoi(e);
+    if (const char *e = std::getenv("PWPP_ONE_PASS_SCALE")) {
+        const double v = std::atof(e);
+        if (v > 0.0 && v <= 1024.0) h->one_pass_scale = v;
+        else std::fprintf(stderr, "pwpp: ignoring PWPP_ONE_PASS_SCALE=%s (a positive number up to 1024 expected)\n", e);
+    }
+    if (h->debug_flags || !h->fit_plan.empty() || h->fit_concurrent || h->no_one_pass || std::getenv("PWPP_ONE_PASS_MIN_FRAMES") ||
+        std::getenv("PWPP_ONE_PASS_SCALE") || std::getenv("PWPP_OVERLAP"))
+        std::fprintf(stderr, "pwpp: tuning options taken from the environment (PWPP_*): debug_flags=%d fit_plan='%s' fit_concurrent=%d "
+                             "no_one_pass=%d one_pass_min_frames=%d one_pass_scale=%g overlap=%d\n", h->debug_flags, h->fit_plan.c_str(),
+                     (int)h->fit_concurrent, (int)h->no_one_pass, h->one_pass_min_frames, h->one_pass_scale, std::getenv("PWPP_OVERLAP") != nullptr);
     const int storage = p->max_elevation_storage > p->max_flatness_storage ? p->max_elevation_storage : p->max_flatness_storage;
     h->stream_hist_cap = storage + max_near_sectors + 1024;
     h->fresh_hist_cap = max_near_sectors + 2;
@@ -578,6 +629,9 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
         return fail(PWPP_E_HIP, "stream/event creation failed: %s", hipGetErrorString(se));
     }
     int rc = pwpp_set_num_streams(h, 1);
+    if (!rc) rc = h->d_bin_origin.ensure(origin.size());
+    if (!rc && hipMemcpy(h->d_bin_origin.p, origin.data(), origin.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(PWPP_E_HIP, "uploading the bin origins failed");
     if (rc) {
         pwpp_destroy(h);
         return rc;
@@ -596,15 +650,16 @@ int pwpp_destroy(pwpp_handle *h) {
     h->h_base.release();
     h->d_in.release();
     h->d_codes.release();
-    h->d_sorted_xyz.release();
+    h->d_sorted_z.release();
+    h->d_sorted_xy.release();
     h->d_sorted_idx.release();
+    h->d_bin_origin.release();
     h->d_plist.release();
     h->d_out.release();
     h->d_ord_a.release();
     h->d_ord_b.release();
     h->d_bins.release();
     h->d_recs.release();
-    h->d_fit.release();
     h->d_cls_start.release();
     h->d_cap_off.release();
     h->d_cls_list.release();
@@ -636,6 +691,7 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
                                int layout, int mem, int mode) {
     if (!h || !points || !n) return fail(PWPP_E_ARG, "null argument");
     if (frames < 1) return fail(PWPP_E_ARG, "frames must be >= 1");
+    if (frames > 65535) return fail(PWPP_E_ARG, "%d frames: at most 65535 per call (the frame is a grid dimension of the kernels)", frames);
     if (cols != 3 && cols != 4) return fail(PWPP_E_ARG, "cols=%d: 3 or 4 expected", cols);
     if (layout != PWPP_LAYOUT_ROW_MAJOR && layout != PWPP_LAYOUT_COL_MAJOR) return fail(PWPP_E_ARG, "bad layout %d", layout);
     if (mem != PWPP_MEM_HOST && mem != PWPP_MEM_DEVICE && mem != PWPP_MEM_HOST_PINNED) return fail(PWPP_E_ARG, "bad mem %d", mem);
@@ -668,8 +724,8 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     bool one_pass = false;
     size_t bin_slots = tp;
     {
-        static const bool env_off = std::getenv("PWPP_NO_ONE_PASS") != nullptr;
-        static const int min_frames = std::getenv("PWPP_ONE_PASS_MIN_FRAMES") ? std::atoi(std::getenv("PWPP_ONE_PASS_MIN_FRAMES")) : 5;
+        const bool env_off = h->no_one_pass;
+        const int min_frames = h->one_pass_min_frames;
         if (h->one_pass_holdoff > 0) {
             --h->one_pass_holdoff;
         } else if (!env_off && frames >= min_frames && max_n > 0) {
@@ -680,9 +736,9 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
             }
             const size_t want = (size_t)frames * (size_t)h->slots_per_frame;
             size_t free_b = 0, total_b = 0;
-            const size_t per_slot = sizeof(PwppXyz) + 2 * sizeof(int32_t);
-            const size_t held = (h->d_sorted_xyz.cap + h->d_sorted_idx.cap + h->d_plist.cap) * sizeof(int32_t) + h->d_sorted_xyz.cap * 2 * sizeof(int32_t);
-            const bool have = h->d_sorted_xyz.cap >= want + 16 && h->d_sorted_idx.cap >= want && h->d_plist.cap >= want;  // already allocated
+            const size_t per_slot = 3 * sizeof(float) + 2 * sizeof(int32_t);  // z, {x, y}, cloud index, plist
+            const size_t held = (h->d_sorted_z.cap + h->d_sorted_idx.cap + h->d_plist.cap) * sizeof(int32_t) + h->d_sorted_xy.cap * sizeof(float2);
+            const bool have = h->d_sorted_z.cap >= want + 16 && h->d_sorted_xy.cap >= want + 16 && h->d_sorted_idx.cap >= want && h->d_plist.cap >= want;  // already allocated
             if (have || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (want + want / 8 + 64) * per_slot * 21 / 20 <= free_b + held &&
                          want < ((size_t)1 << 40))) {
                 one_pass = true;
@@ -696,12 +752,13 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     if ((rc = h->h_base.ensure((size_t)frames + 1))) return rc;
     if ((rc = h->d_codes.ensure(tp))) return rc;
     // (slack: load_chunk reads record 0 of a patch beyond its end)
-    if (one_pass && (h->d_sorted_xyz.ensure(bin_slots + 16) || h->d_sorted_idx.ensure(bin_slots) || h->d_plist.ensure(bin_slots))) {
+    if (one_pass && (h->d_sorted_z.ensure(bin_slots + 16) || h->d_sorted_xy.ensure(bin_slots + 16) || h->d_sorted_idx.ensure(bin_slots) || h->d_plist.ensure(bin_slots))) {
         one_pass = false;  // the big allocation failed after all (fragmentation): compact layout, two-pass binning
         bin_slots = tp;
         (void)hipGetLastError();
     }
-    if ((rc = h->d_sorted_xyz.ensure(bin_slots + 16))) return rc;
+    if ((rc = h->d_sorted_z.ensure(bin_slots + 16))) return rc;
+    if ((rc = h->d_sorted_xy.ensure(bin_slots + 16))) return rc;
     if ((rc = h->d_sorted_idx.ensure(bin_slots))) return rc;
     if ((rc = h->d_plist.ensure(bin_slots))) return rc;
     if ((rc = h->d_out.ensure(tp))) return rc;
@@ -711,7 +768,6 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     }
     if ((rc = h->d_bins.ensure((size_t)frames * NB * 5))) return rc;
     if ((rc = h->d_recs.ensure((size_t)frames * B))) return rc;
-    if ((rc = h->d_fit.ensure((size_t)frames * B))) return rc;
     if ((rc = h->d_cls_start.ensure((size_t)frames * PWPP_CLS_STRIDE))) return rc;
     if ((rc = h->d_cls_list.ensure((size_t)frames * B))) return rc;
     if ((rc = h->d_centers.ensure((size_t)frames * B * 3))) return rc;
@@ -1021,6 +1077,67 @@ int pwpp_reset_kernel_profile(pwpp_handle *h) {
     return PWPP_OK;
 }
 int pwpp_get_fxp_shift(pwpp_handle *h) { return h ? h->dp.fxp_shift : PWPP_E_ARG; }
+
+int pwpp_get_fxp_origins(pwpp_handle *h, float *out_xy, int capacity_bins) {
+    if (!h || !out_xy) return fail(PWPP_E_ARG, "null argument");
+    const int B = h->dp.num_bins;
+    if (capacity_bins < B) return fail(PWPP_E_ARG, "room for %d bins, %d needed", capacity_bins, B);
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out_xy, h->d_bin_origin.p, (size_t)B * sizeof(float2), hipMemcpyDeviceToHost));
+    return B;
+}
+
+int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
+    if (!h || !name || !value) return fail(PWPP_E_ARG, "null argument");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    const std::string k = name;
+    if (k == "fit_plan") {
+        for (const char *c = value; *c; ++c)
+            if (!std::strchr("SWBH0123456789.:,", *c)) return fail(PWPP_E_ARG, "fit_plan '%s': unexpected character '%c'", value, *c);
+        h->fit_plan = value;
+    } else if (k == "fit_concurrent") {
+        h->fit_concurrent = std::atoi(value) != 0;
+    } else if (k == "one_pass") {
+        h->no_one_pass = std::atoi(value) == 0;
+    } else if (k == "one_pass_min_frames") {
+        const int v = std::atoi(value);
+        if (v < 1) return fail(PWPP_E_ARG, "one_pass_min_frames=%s: >= 1 expected", value);
+        h->one_pass_min_frames = v;
+    } else if (k == "one_pass_scale") {
+        const double v = std::atof(value);
+        if (!(v > 0.0 && v <= 1024.0)) return fail(PWPP_E_ARG, "one_pass_scale=%s: a positive number up to 1024 expected", value);
+        h->one_pass_scale = v;
+        h->cap_max_n = -1;  // rebuild the capacity table
+    } else if (k == "debug_flags") {
+        h->debug_flags = std::atoi(value);
+    } else {
+        return fail(PWPP_E_ARG, "unknown option '%s'", name);
+    }
+    return PWPP_OK;
+}
+
+int pwpp_trim_workspace(pwpp_handle *h) {
+    if (!h) return fail(PWPP_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    h->d_in.release();
+    h->d_codes.release();
+    h->d_sorted_z.release();
+    h->d_sorted_xy.release();
+    h->d_sorted_idx.release();
+    h->d_plist.release();
+    h->d_out.release();
+    h->d_ord_a.release();
+    h->d_ord_b.release();
+    h->d_xyz.release();
+    h->have_results = false;  // the index lists lived in d_out
+    h->descs_on_device.clear();
+    return PWPP_OK;
+}
 
 int pwpp_set_output_order(pwpp_handle *h, int order) {
     if (!h) return fail(PWPP_E_ARG, "null handle");

@@ -211,11 +211,41 @@ __device__ void jacobi_svd3(const float a[9], float u[9], float sv[3]) {
     }
 }
 
-// Q(v) = clamp(rint(v * 2^s), +-(2^23 - 1)), Q(NaN) = 0.
-// Branch-free: v_rndne_f32, v_cvt_i32_f32 (saturating; NaN -> 0), v_med3_i32.
-__device__ __forceinline__ int fxp_quantise(float v, float scale) {
-    const int q = __float2int_rn(v * scale);
-    return min(max(q, -8388607), 8388607);
+// ------------------------------------------------------------------------------------------
+// The fixed-point contract of the plane-fit sums (restated for the checker
+// in oracle/pwpp_oracle.cpp):
+//   Q_x(v) = rint(double(v) * 2^s - ox * 2^s), Q_y alike        (ox, oy: the bin's origin, multiples of 1/8 m)
+//   Q_z(v) = the same around z0 after clamping v to [z0 - ZR, z0 + ZR] in float
+//            (z0: the patch's first lowest-point representative rounded to 1/8 m, ZR = 2^(26-s) m)
+// |Q| <= 2^26 by construction of s (pwpp_capi.cpp, build_dev_params).
+// One v_fma_f64 does the scaling, the subtraction and the rounding: added to 2^52 + 2^51 the exact
+// value double(v) * 2^s - O is rounded to an integer (ties to even, as rint) by the FMA itself, and
+// the low 32 bits of the result are that integer in two's complement.
+// ------------------------------------------------------------------------------------------
+struct FxpOrg {
+    double cx, cy, cz;  // 2^52 + 2^51 - origin * 2^s
+    float zlo, zhi;     // z0 -+ ZR (exact in float: multiples of 1/8 m below 2^13)
+};
+__device__ __forceinline__ FxpOrg fxp_org(float ox, float oy, float z0, double scale, float zr) {
+    const double magic = 6755399441055744.0;
+    FxpOrg o;
+    o.cx = magic - (double)ox * scale;
+    o.cy = magic - (double)oy * scale;
+    o.cz = magic - (double)z0 * scale;
+    o.zlo = z0 - zr;
+    o.zhi = z0 + zr;
+    return o;
+}
+__device__ __forceinline__ int fxp_q(float v, double scale, double c) {
+    return (int)(unsigned)(unsigned long long)__double_as_longlong(__builtin_fma((double)v, scale, c));
+}
+// z origin of a patch from its first lowest-point representative (ref :103)
+__device__ __forceinline__ float fxp_z_origin(double lpr) {
+    if (!(fabs(lpr) <= DBL_MAX)) return 0.0f;  // NaN, +-inf
+    double t = rint(lpr * 8.0) * 0.125;
+    t = t > 4096.0 ? 4096.0 : t;
+    t = t < -4096.0 ? -4096.0 : t;
+    return (float)t;
 }
 
 // order-preserving map float -> uint32 (for the lowest-point selection)
@@ -227,7 +257,12 @@ __device__ __forceinline__ float key_z(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-struct Moments {  // per-lane partial sums of the quantised coordinates
+// Per-lane partial sums of the quantised coordinates.  Every product and every sum is a 64-bit integer
+// multiply-add (v_mad_i64_i32, full rate on gfx950 like v_fma_f64: tools/ubench/valu_rates.hip): exact
+// whatever the order, no conversion back and forth, no chunk-wise flush.  |Q| <= 2^26, so a lane may add up
+// 2^11 - 1 points before a second moment could leave int64; the kernels deal at most that many to a lane
+// (pwpp_launch_fit caps the classes) and k_fit_stream, which takes whatever is larger, sums in 128 bits.
+struct Moments {
     long long n, s1[3], s2[6];
     __device__ __forceinline__ void clear() {
         n = 0;
@@ -235,9 +270,10 @@ struct Moments {  // per-lane partial sums of the quantised coordinates
 #pragma unroll
         for (int k = 0; k < 6; ++k) s2[k] = 0;
     }
-    __device__ __forceinline__ void add(float x, float y, float z, float scale) {
-        const int qx = fxp_quantise(x, scale), qy = fxp_quantise(y, scale), qz = fxp_quantise(z, scale);
-        n += 1;
+    // (the caller adds the number of points itself, e.g. the population count of a chunk's mask)
+    __device__ __forceinline__ void add_uncounted(float x, float y, float z, double scale, const FxpOrg &o) {
+        const int qx = fxp_q(x, scale, o.cx), qy = fxp_q(y, scale, o.cy);
+        const int qz = fxp_q(__builtin_amdgcn_fmed3f(z, o.zlo, o.zhi), scale, o.cz);  // (a NaN z never gets here: every test on it fails)
         s1[0] += qx;
         s1[1] += qy;
         s1[2] += qz;
@@ -248,63 +284,19 @@ struct Moments {  // per-lane partial sums of the quantised coordinates
         s2[4] += (long long)qy * qz;
         s2[5] += (long long)qz * qz;
     }
+    __device__ __forceinline__ void add(float x, float y, float z, double scale, const FxpOrg &o) {
+        n += 1;
+        add_uncounted(x, y, z, scale, o);
+    }
 };
-
 
 // ------------------------------------------------------------------------------------------
 // plane of ref :47-75 from the exact integer moments of a point set:
-//   mean_a = float( (S1_a / n) * 2^-s )
+//   mean_a = float( (S1_a / n) * 2^-s + origin_a )
 //   cov_ab = float( ((n*S2_ab - S1_a*S1_b) / (n*(n-1))) * 2^-2s )     numerator exact in 128 bits
 // then Eigen's JacobiSVD on the float covariance, normal = U.col(2) flipped to z >= 0 (:66-68),
 // d = -(normal . mean) as a float dot product widened to double (:74).
 // ------------------------------------------------------------------------------------------
-// Moments of at most 8 points per lane (one chunk), accumulated with double FMAs: the products
-// of 24-bit integers (< 2^46) and their sum over 8 points (< 2^49) are exact in double, and a
-// v_fma_f64 costs half of the quarter-rate 64-bit integer multiply-add.  Flushed into the int64
-// totals after every chunk, so the totals stay exact integers.
-struct ChunkMoments {
-    int n, s1z;
-    double s1x, s1y;
-    double s2[6];
-    __device__ __forceinline__ void clear() {
-        n = 0;
-        s1z = 0;
-        s1x = s1y = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s2[k] = 0.0;
-    }
-    // x and y of a binned point lie within max_range, and max_range * 2^s <= 2^23 - 1 (validated at
-    // create time), so their clamp can never act and the rounded product is converted float ->
-    // double directly (v_rndne_f32, v_cvt_f64_f32); z is unbounded and may be NaN: integer path.
-    __device__ __forceinline__ void add(float x, float y, float z, float scale) {
-        n += 1;
-        add_uncounted(x, y, z, scale);
-    }
-    // (the caller adds the number of points itself, e.g. the population count of a chunk's mask)
-    __device__ __forceinline__ void add_uncounted(float x, float y, float z, float scale) {
-        const double dx = (double)__builtin_rintf(x * scale), dy = (double)__builtin_rintf(y * scale);
-        const int qz = fxp_quantise(z, scale);
-        const double dz = (double)qz;
-        s1x += dx;
-        s1y += dy;
-        s1z += qz;
-        s2[0] = __builtin_fma(dx, dx, s2[0]);
-        s2[1] = __builtin_fma(dx, dy, s2[1]);
-        s2[2] = __builtin_fma(dx, dz, s2[2]);
-        s2[3] = __builtin_fma(dy, dy, s2[3]);
-        s2[4] = __builtin_fma(dy, dz, s2[4]);
-        s2[5] = __builtin_fma(dz, dz, s2[5]);
-    }
-    __device__ __forceinline__ void flush_into(Moments &m) const {
-        m.n += n;
-        m.s1[0] += (long long)s1x;
-        m.s1[1] += (long long)s1y;
-        m.s1[2] += s1z;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) m.s2[k] += (long long)s2[k];
-    }
-};
-
 struct PlaneFit {
     float nx, ny, nz;
     float mean[3];
@@ -313,12 +305,13 @@ struct PlaneFit {
 };
 
 __device__ __forceinline__ void plane_from_totals(long long n, const long long s1[3], const __int128 s2[6], int shift,
-                                                  int debug, PlaneFit &out) {
+                                                  float ox, float oy, float z0, int debug, PlaneFit &out) {
     const double inv = __longlong_as_double((long long)(1023 - shift) << 52);  // 2^-shift, exactly what 1.0 / (1 << shift) gives, without the division
     const double den = (double)n * (double)(n - 1);
     float mean[3], cov[9];
+    const double org[3] = {(double)ox, (double)oy, (double)z0};
 #pragma unroll
-    for (int a = 0; a < 3; ++a) mean[a] = (float)(((double)s1[a] / (double)n) * inv);
+    for (int a = 0; a < 3; ++a) mean[a] = (float)(((double)s1[a] / (double)n) * inv + org[a]);
     const int map[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {

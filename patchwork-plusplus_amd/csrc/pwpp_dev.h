@@ -30,7 +30,8 @@ struct PwppDevParams {
     int32_t rings[4], sectors[4];
     int32_t bin_base[5];  // first bin of zone k; [4] = B
     int32_t num_bins;     // B
-    int32_t fxp_shift;    // s of the plane-fit arithmetic contract
+    int32_t fxp_shift;    // s of the plane-fit arithmetic contract (DESIGN.md section 4)
+    float fxp_zr;         // 2^(26 - s) metres: a fit's z coordinates are clamped to z0 +- fxp_zr before they are quantised
     int32_t max_elev_storage, max_flat_storage;
     int32_t hist_cap;     // doubles per (state, which, ring) history slab
     int32_t near_bins;    // bins with concentric_idx < num_rings_of_interest
@@ -73,17 +74,6 @@ struct PwppPatchRec {  // one per (frame, bin); written by k_patch_fit, finished
     int32_t valid;  // 0: no fit ran in this bin (empty bin let through by num_min_pts <= 0)
 };
 
-struct PwppFitState {  // per (frame, bin): the fit chain of a patch between the phase kernels
-    long long mom[10];  // integer moments left by the points phase: n, S1[3], S2[6]
-    double lpr;
-    double d;
-    float nx, ny, nz;
-    float mean[3];
-    float sv[3];
-    int32_t kind, it, lpr_valid, need_strip;
-    int32_t pad_;
-};
-
 struct PwppFrameResult {
     int32_t n_ground, n_nonground, n_patches, n_rnr, n_oor, n_dropped;
     int32_t pad0;      // history slab full (flag)
@@ -91,18 +81,17 @@ struct PwppFrameResult {
 };
 
 // everything a launch needs, by value in the kernarg segment
-// The fit passes re-read a patch 5-6 times and are bound by that traffic: the records they stream
-// hold the coordinates only (12 B), the cloud index lives in its own array.
-struct __attribute__((aligned(4))) PwppXyz {
-    float x, y, z;
-};
+// The fit passes re-read a patch 5-6 times and are bound by that traffic, so the bin-ordered records are
+// planes: z (all a lowest-point pass needs, 4 B), {x, y} (8 B) and the cloud index (4 B, read by the pass
+// that writes the split only).
 
 struct PwppBatch {
     PwppDevParams P;
     const PwppFrameDesc *frames;
     int32_t num_frames;
     int32_t max_n;               // largest frame of the batch
-    int32_t debug;               // ablation switches for timing experiments only (PWPP_DEBUG_FLAGS); 0 in production
+    int32_t debug;               // option "debug_flags": 4 = timing probes of the fit chain, 16 = exact binning only, 16384 / 32768 =
+                                 // force the fall-back paths of the lowest-point selection (tests); results never depend on it
     int32_t no_clear;            // the caller already launched k_clear for these frames (overlap mode: two frame ranges, two streams)
     const uint32_t *cap_off;     // one-pass binning: [B+3] first slot of every bin's fixed segment inside a frame
                                  // (cap_off[B+2] = slots per frame); null on the two-pass path
@@ -114,11 +103,13 @@ struct PwppBatch {
     uint32_t *bin_cursor;        // [frames][B+2]
     uint32_t *cls_start;         // [frames][PWPP_CLS_STRIDE] first entry of each size bucket in cls_list
     uint16_t *cls_list;          // [frames][B] patch bins sorted by size bucket
-    PwppXyz *sorted_xyz;         // [total points | frames x slots per frame] 12-byte {x,y,z} records grouped by bin; x = NaN: stripped by R-VPF
-    int *sorted_idx;             // [total points] cloud index of the record (read by the last fit pass and K6 only)
+    float *sorted_z;             // [total points | frames x slots per frame] z of the points grouped by bin.  A NaN z of the cloud is
+                                 // stored as 0x7fc00000; 0x7fc00000 | (round + 1) marks a point an R-VPF round removed
+    float2 *sorted_xy;           // same slots: {x, y}
+    int *sorted_idx;             // same slots: cloud index of the point (read by the last fit pass and K6 only)
+    const float2 *bin_origin;    // [B] origin of every bin's fixed-point plane-fit sums (its polar centre rounded to 1/8 m)
     int32_t *plist;              // [total points] per patch: ground candidates from the front, non-ground from the back
     PwppPatchRec *recs;          // [frames][B]
-    PwppFitState *fit;           // [frames][B]
     uint32_t *dst_a;             // [frames][B+2] output offset of sub-list A (candidates / whole bin)
     uint32_t *dst_b;             // [frames][B+2] output offset of sub-list B (regionwise non-ground)
     int32_t *out_idx;            // [total points] per frame: ground list then non-ground list
@@ -127,6 +118,10 @@ struct PwppBatch {
     PwppFrameResult *results;    // [frames]
     PwppFrameResult *results_host;  // [frames] pinned host mirror, written by K6 (no D2H copy command behind the pipeline)
     unsigned long long *dbg;     // [64] timing probes, only written when debug & 4
+    // host side only (the kernels never read these)
+    const char *fit_plan;        // option "fit_plan": overrides the plan pwpp_launch_fit would choose; null or empty = automatic
+    int32_t fit_concurrent;      // option "fit_concurrent": the classes of a plan side by side on two streams
+    int32_t pad1_;
 };
 
 #endif

@@ -11,19 +11,18 @@
 //
 //   k_fit_w64<16,64|32|16>  64/32/16 small patches per wave: points phases in rows of 16 lanes
 //                           (4 patches at a time), then ONE solve phase with a patch per lane
-//   k_fit_w64<64,2>         big bins, two per wave: 64 lanes stream one patch at a time, the
-//                           two solves share an instruction stream; dual seed pass
+//   k_fit_w64<64,p>         big bins, p per wave: 64 lanes stream one patch at a time, the
+//                           p solves share an instruction stream; dual seed pass
 //   k_fit_srows<G>          one row of G lanes per patch, next chunk prefetched (mid-size batches)
 //   k_fit_brows             four waves per patch; an R-VPF round and the R-GPF seed fit solved side by side
 //   k_fit_hybrid            the single-frame kernel: k_fit_brows' body for the big patches, k_fit_srows<64>'s
 //                           for the small ones (four per workgroup), one launch, one workgroup per CU
-//   k_fit_rows<G>           points parked in lane-private LDS slots (patches up to 8 G points)
-//   k_ph_rows + k_ph_solve  the chain cut into phase kernels, state in HBM
-//   k_fit_stream            whatever exceeds the plan (> 65535 points): workgroup per patch (the hybrid kernel
-//                           fits such patches in place)
+//   k_fit_stream            whatever exceeds the plan: workgroup per patch, 128-bit lane sums
 //
-// The streamed kernels re-read a patch once per stage (12-byte records, 5 passes for a zone-0
-// patch); DESIGN.md section 3 has the measurements that led here.
+// The bin-ordered records are planes (pwpp_dev.h): the lowest-point pass streams z alone (4 B per
+// point), every other pass z and {x, y} (12 B), the pass that writes the split also the cloud index.
+// DESIGN.md section 3 has the measurements that led here (and the variants that were dropped: points
+// parked in LDS, the chain cut into phase kernels).
 //
 // All reductions are integer, so every variant produces bit-identical
 // planes and the same index sets whatever the lane count.
@@ -103,15 +102,17 @@ struct Row {
         const v2i pair = {tl, th};
         return v + __builtin_bit_cast(long long, pair);
     }
-    // ---- ten 64-bit row sums at once, as a reduce-SCATTER -------------------------------------------
-    // sum_i64 is a butterfly per value: every lane ends up with every total (10 x log2(G) exchanges).
+    // ---- sixteen 64-bit row sums at once, as a reduce-SCATTER ---------------------------------------
+    // sum_i64 is a butterfly per value: every lane ends up with every total (16 x log2(G) exchanges).
     // The kernels that park the totals in LDS only need each total ONCE, so the row is halved instead:
     // at every step a lane keeps one half of its values, sends the other half to its partner and adds
-    // what the partner sends (5 + 3 + 2 + 1 exchanges for the first four steps), after which a lane of
-    // a 16-lane group owns one value summed over the group; the groups of a wider row are then added up
-    // on that one value.  The partners must agree on every side bit already used, hence the order:
-    // half-mirror (i <-> 7-i, side = bit 2), xor 1, xor 2, xor 8 (ds_swizzle), [xor 16, xor 32].
-    // `slot` = which of the ten values this lane owns (-1: none); integer sums, so the order is free.
+    // what the partner sends (8 + 4 + 2 + 1 exchanges for the first four steps), after which every lane
+    // of a 16-lane group owns one value summed over the group; the groups of a 64-lane row are then
+    // added up on that one value.  The partners must agree on every side bit already used, hence the
+    // order: half-mirror (i <-> 7-i, side = bit 2), xor 1, xor 2, xor 8 (ds_swizzle), [xor 16, xor 32].
+    // `slot` = which of the sixteen values this lane owns; integer sums, so the order is free.
+    // The sixteen values of a patch: n, S1[3], the lower and the upper 32-bit halves of S2[6] -- the halves
+    // because a second moment (|Q| <= 2^26: up to 2^52 per point) leaves int64 once 2^11 points are added up.
     template <int KIND>
     __device__ static __forceinline__ long long xchg64(long long v) {
         int lo = (int)(unsigned)(unsigned long long)v, hi = (int)((unsigned long long)v >> 32);
@@ -126,38 +127,33 @@ struct Row {
         const v2i pair = {tl, th};
         return __builtin_bit_cast(long long, pair);
     }
-    __device__ static __forceinline__ long long reduce10_scatter(const long long (&v)[10], int &slot) {
-        static_assert(G == 16 || G == 64, "rows of 16 or 64 lanes");
+    __device__ static __forceinline__ long long reduce16_scatter(const long long (&v)[16], int &slot) {
+        static_assert(G == 64, "rows of 64 lanes");
         const int ln = lane_id();
         const bool s2 = (ln & 4) != 0, s0 = (ln & 1) != 0, s1 = (ln & 2) != 0, s3 = (ln & 8) != 0;
-        long long a[5], b[3], c[2], d;
+        long long a[8], b[4], c[2], d;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const long long keep = s2 ? v[5 + i] : v[i], send = s2 ? v[i] : v[5 + i];
+        for (int i = 0; i < 8; ++i) {
+            const long long keep = s2 ? v[8 + i] : v[i], send = s2 ? v[i] : v[8 + i];
             a[i] = keep + xchg64<0>(send);
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const long long up = i < 2 ? a[3 + (i < 2 ? i : 0)] : 0ll;
-            const long long keep = s0 ? up : a[i], send = s0 ? a[i] : up;
+        for (int i = 0; i < 4; ++i) {
+            const long long keep = s0 ? a[4 + i] : a[i], send = s0 ? a[i] : a[4 + i];
             b[i] = keep + xchg64<1>(send);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const long long up = i < 1 ? b[2] : 0ll;
-            const long long keep = s1 ? up : b[i], send = s1 ? b[i] : up;
+            const long long keep = s1 ? b[2 + i] : b[i], send = s1 ? b[i] : b[2 + i];
             c[i] = keep + xchg64<2>(send);
         }
         {
             const long long keep = s3 ? c[1] : c[0], send = s3 ? c[0] : c[1];
             d = keep + xchg64<3>(send);
         }
-        if (G == 64) {
-            d += xchg64<4>(d);
-            d += xchg64<5>(d);
-        }
-        const int idx = s0 ? (s1 ? -1 : (s3 ? 4 : 3)) : (s1 ? (s3 ? -1 : 2) : (s3 ? 1 : 0));
-        slot = idx < 0 ? -1 : (s2 ? 5 : 0) + idx;
+        d += xchg64<4>(d);
+        d += xchg64<5>(d);
+        slot = (s2 ? 8 : 0) + (s0 ? 4 : 0) + (s1 ? 2 : 0) + (s3 ? 1 : 0);
         return d;
     }
     __device__ static __forceinline__ long long sum_i64(long long v) {
@@ -211,81 +207,11 @@ struct Row {
     }
 };
 
-// 8-key sorting network (19 compare-exchanges), ascending
+// compare-exchange of two keys, ascending
 __device__ __forceinline__ void ce(unsigned &a, unsigned &b) {
     const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
     a = lo;
     b = hi;
-}
-__device__ __forceinline__ void sort8(unsigned k[8]) {
-    ce(k[0], k[1]); ce(k[2], k[3]); ce(k[4], k[5]); ce(k[6], k[7]);
-    ce(k[0], k[2]); ce(k[1], k[3]); ce(k[4], k[6]); ce(k[5], k[7]);
-    ce(k[1], k[2]); ce(k[5], k[6]); ce(k[0], k[4]); ce(k[3], k[7]);
-    ce(k[1], k[5]); ce(k[2], k[6]);
-    ce(k[1], k[4]); ce(k[3], k[6]);
-    ce(k[2], k[4]); ce(k[3], k[5]);
-    ce(k[3], k[4]);
-}
-
-// Lowest-point representative, ref :84-103, without sorting the bin.  Every lane holds up to 8
-// candidate keys (0xFFFFFFFF = none), sorted; `total` candidates exist in the row.  The row
-// repeatedly extracts its minimum ("tournament"), which yields the min(num_lpr,total) smallest
-// z in ASCENDING order -- exactly the terms and the order of the reference's double sum (:99-102).
-// EMIT: also store the extracted keys (used by the block kernels to merge per-wave lists).
-template <int G, bool EMIT>
-__device__ __forceinline__ double tournament(unsigned key[8], int total, int num_lpr, unsigned *emit) {
-    const int j = lane_id() & (G - 1);
-    const int keff = total < num_lpr ? total : num_lpr;
-    double sum = 0.0;
-    for (int r = 0; r < num_lpr; ++r) {
-        const bool take = r < keff;  // row-uniform
-        if (!__any(take)) break;     // wave-uniform
-        const unsigned head = key[0];
-        const unsigned m = Row<G>::min_u32(head);
-        if (take) sum += (double)key_z(m);
-        const unsigned long long rb = Row<G>::ballot(take && head == m);
-        const int lowest = __ffsll((long long)rb) - 1;
-        if (EMIT && take && j == 0) emit[r] = m;
-        if (take && j == lowest) {  // pop
-#pragma unroll
-            for (int k = 0; k < 7; ++k) key[k] = key[k + 1];
-            key[7] = 0xFFFFFFFFu;
-        }
-    }
-    return keff ? sum / (double)keff : 0.0;  // ref :103
-}
-
-// The <= 8 points of a patch that one lane owns.  They are fetched from HBM/L2 once and parked
-// in a lane-private LDS slot (rows / 256-thread kernels: 128 B per lane) -- not in registers,
-// which the eigen-solve needs -- and re-read from there at every stage of the fit chain.
-struct LanePts {
-    float x[kPPT], y[kPPT], z[kPPT];
-};
-
-// base[k * stride] is point k of this lane (LDS slot or the bin record in global memory)
-__device__ __forceinline__ void load_lane_points(LanePts &lp, const float4 *base, unsigned stride, unsigned valid) {
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid >> k & 1u) v = base[(unsigned)k * stride];
-        lp.x[k] = v.x;
-        lp.y[k] = v.y;
-        lp.z[k] = v.z;
-    }
-}
-
-// keys of the points eligible for the LPR (active, not below the zone-0 cut-off of ref :88-96)
-__device__ __forceinline__ int lane_lpr_keys(const LanePts &lp, unsigned act, bool on, bool use_cutoff, double cutoff,
-                                             unsigned key[8]) {
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-        const bool e = on && (act >> k & 1u) && !(use_cutoff && (double)lp.z[k] < cutoff);
-        key[k] = e ? z_key(lp.z[k]) : 0xFFFFFFFFu;
-        cnt += e ? 1 : 0;
-    }
-    sort8(key);
-    return cnt;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -320,13 +246,96 @@ __device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &
     rec->valid = 1;
 }
 
-// per-lane part of one stage: which points enter the fit (and, for ST_ITER, which are ground)
-// Adds the points of one chunk that enter this stage's fit to `cm` and returns their mask.
-// `cm` holds exact integers in doubles (ChunkMoments); the caller flushes it into the int64
-// totals at least every kFlushChunks chunks (15 * 8 points * 2^46 < 2^53).
-constexpr unsigned kFlushChunks = 15;
-__device__ __forceinline__ unsigned lane_stage_accum(const LanePts &lp, unsigned act, int kind, double thr_seed,
-                                                     double th_dist, const PlaneFit &pl, float qscale, ChunkMoments &cm) {
+// a patch in the bin-ordered planes (pwpp_dev.h): z, {x, y}, cloud index
+struct PatchRef {
+    float *z;
+    const float2 *xy;
+    const int *idx;
+};
+__device__ __forceinline__ PatchRef patch_ref(const PwppBatch &Bt, size_t first) {
+    PatchRef r;
+    r.z = Bt.sorted_z + first;
+    r.xy = Bt.sorted_xy + first;
+    r.idx = Bt.sorted_idx + first;
+    return r;
+}
+// R-VPF removes a point from the patch's working set (ref :495-503) by overwriting its z with a NaN whose
+// payload is the R-VPF round (1-based): the coordinates of a removed point are not needed again, and k_czm_*
+// store a NaN z of the cloud as the payload-free 0x7fc00000, so the mark is unambiguous.  The round matters
+// to the reference-order output mode: the reference appends the points a round removes to
+// regionwise_nonground_ round by round (ref :500).
+__device__ __forceinline__ void strip_point(const PatchRef &pr, unsigned i, int round) {
+    pr.z[i] = __uint_as_float(0x7fc00000u | (unsigned)((round + 1) & 0xff));
+}
+__device__ __forceinline__ bool z_stripped(float z) { return (int)__float_as_uint(z) > 0x7fc00000; }
+// what the last R-GPF round writes for a non-ground point: its cloud index, plus in bits 24-31 the
+// R-VPF round that removed it (0: none) -- k_emit masks it off, k_order_sublists sorts by it
+__device__ __forceinline__ int nonground_entry(int idx, float z) {
+    return z_stripped(z) ? (idx | (int)((__float_as_uint(z) & 0xffu) << 24)) : idx;
+}
+
+// One chunk = 8 points per lane of a row.  The loads are unconditional (record 0 of the patch stands in
+// beyond the end; the buffers carry a few records of slack): the compiler can then keep a whole chunk in
+// flight behind the arithmetic of the previous one and wait with a counted s_waitcnt.
+struct ChunkZ {  // what the lowest-point pass needs
+    float z[kPPT];
+    unsigned valid;
+};
+struct ChunkPts {
+    float x[kPPT], y[kPPT], z[kPPT];
+    unsigned valid;
+};
+template <int G>
+__device__ __forceinline__ void load_chunk_z(ChunkZ &cp, const PatchRef &pr, unsigned n, unsigned c) {
+    cp.valid = 0;
+    const unsigned j = (unsigned)lane_id() & (G - 1);
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        const unsigned i = c * (8u * G) + (unsigned)k * G + j;
+        cp.z[k] = pr.z[i < n ? i : 0u];
+        if (i < n) cp.valid |= 1u << k;
+    }
+}
+template <int G>
+__device__ __forceinline__ void load_chunk(ChunkPts &cp, const PatchRef &pr, unsigned n, unsigned c) {
+    cp.valid = 0;
+    const unsigned j = (unsigned)lane_id() & (G - 1);
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        const unsigned i = c * (8u * G) + (unsigned)k * G + j;
+        const unsigned ii = i < n ? i : 0u;
+        const float2 v = pr.xy[ii];
+        cp.z[k] = pr.z[ii];
+        cp.x[k] = v.x;
+        cp.y[k] = v.y;
+        if (i < n) cp.valid |= 1u << k;
+    }
+}
+// the points of a chunk that are still in the patch's working set (not removed by R-VPF); evaluated
+// where the chunk is consumed, so that a chunk loaded ahead does not have to land early
+template <class C>
+__device__ __forceinline__ unsigned chunk_act(const C &cp) {
+    unsigned strip = 0;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k)
+        if (z_stripped(cp.z[k])) strip |= 1u << k;
+    return cp.valid & ~strip;
+}
+// the cloud indices of a chunk (only the pass that writes the split needs them)
+template <int G>
+__device__ __forceinline__ void load_chunk_idx(int w[kPPT], const PatchRef &pr, unsigned n, unsigned c) {
+    const unsigned j = (unsigned)lane_id() & (G - 1);
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        const unsigned i = c * (8u * G) + (unsigned)k * G + j;
+        w[k] = i < n ? pr.idx[i] : 0;
+    }
+}
+
+// per-lane part of one stage: adds the points of one chunk that enter this stage's fit to `m` (ground
+// set of an R-GPF round, seeds of a seed stage) and returns their mask.
+__device__ __forceinline__ unsigned lane_stage_accum(const ChunkPts &cp, unsigned act, int kind, double thr_seed, double th_dist,
+                                                     const PlaneFit &pl, double scale, const FxpOrg &org, Moments &m) {
     // One test for every stage: a seed pass (ref :108,145, "z < lpr + th_seeds") is the plane test
     // of ref :525 with normal (0,0,1), d = 0: 0*x + 0*y + 1*z + 0.0 == z for the finite x, y that
     // binning lets through, so the per-point code has no branch on the stage.
@@ -340,254 +349,43 @@ __device__ __forceinline__ unsigned lane_stage_accum(const LanePts &lp, unsigned
     for (int k = 0; k < kPPT; ++k) {
         // (no short circuit: the distance of a slot beyond the patch's end is computed on a stand-in record and
         // discarded -- one masked compare instead of a branch around the test)
-        const bool below = plane_dist(tx, ty, tz, td, lp.x[k], lp.y[k], lp.z[k]) < thr;  // one-sided
+        const bool below = plane_dist(tx, ty, tz, td, cp.x[k], cp.y[k], cp.z[k]) < thr;  // one-sided
         const bool inc = below & ((act >> k & 1u) != 0u);
-        if (inc) {  // (a branch on purpose: seed passes include only ~10 % of the points)
+        if (inc) {  // (a branch on purpose: a seed pass includes about half of the points, an R-GPF round ~60 %)
             gmask |= 1u << k;
-            cm.add_uncounted(lp.x[k], lp.y[k], lp.z[k], qscale);
+            m.add_uncounted(cp.x[k], cp.y[k], cp.z[k], scale, org);
         }
     }
-    cm.n += __popc(gmask);
-    return gmask;
-}
-__device__ __forceinline__ unsigned lane_stage_moments(const LanePts &lp, unsigned act, int kind, double thr_seed,
-                                                       double th_dist, const PlaneFit &pl, float qscale, Moments &m) {
-    ChunkMoments cm;
-    cm.clear();
-    const unsigned gmask = lane_stage_accum(lp, act, kind, thr_seed, th_dist, pl, qscale, cm);
-    m.clear();
-    cm.flush_into(m);
+    m.n += __popc(gmask);
     return gmask;
 }
 
 // returns the points of this lane that the R-VPF plane removes (ref :495-503)
-__device__ __forceinline__ unsigned lane_strip(const LanePts &lp, unsigned act, bool on, const PlaneFit &pl, double th_dist_v) {
+__device__ __forceinline__ unsigned lane_strip(const ChunkPts &cp, unsigned act, bool on, const PlaneFit &pl, double th_dist_v) {
     unsigned hit = 0;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
         if (on && (act >> k & 1u)) {
-            const double dist = plane_dist(pl.nx, pl.ny, pl.nz, pl.d, lp.x[k], lp.y[k], lp.z[k]);
+            const double dist = plane_dist(pl.nx, pl.ny, pl.nz, pl.d, cp.x[k], cp.y[k], cp.z[k]);
             if (fabs(dist) < th_dist_v) hit |= 1u << k;  // ref :499
         }
     }
     return hit;
 }
 
-// ------------------------------------------------------------------------------------------
-// classes 0-2: G lanes per patch, wave-local
-// ------------------------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(kBlock, 4) void k_fit_rows(PwppBatch Bt, int b_lo, int b_hi) {
-    // grid = (frames, blocks per frame): the frame is the FAST dimension.  Most blocks of a frame's
-    // worst-case grid are empty; with the frame in blockIdx.y the working blocks formed a pattern
-    // of period 32 = 8 XCDs x 4 SEs and landed on a quarter of the CUs (3x slower, measured).
-    const int f = blockIdx.x;
-    const PwppDevParams &P = Bt.P;
-    const int NB = P.num_bins + 2;
-    const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
-    const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
-    const unsigned tid = blockIdx.y * kBlock + threadIdx.x;
-    if (cbeg + (tid & ~63u) / G >= cend) return;  // this wave has no patch
-    const unsigned slot = cbeg + tid / G;
-    const bool alive = slot < cend;  // row-uniform
-    const int j = lane_id() & (G - 1);
-    const int bin = alive ? (int)Bt.cls_list[(size_t)f * P.num_bins + slot] : 0;
-    const unsigned n = alive ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
-    const PwppFrameDesc fd = Bt.frames[f];
-    const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    const PwppXyz *pts = Bt.sorted_xyz + fd.sbase + off;
-    const int *pidx = Bt.sorted_idx + fd.sbase + off;
-    int *plist = Bt.plist + fd.sbase + off;
-    const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
-    const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
-    const double cutoff = P.margin * sensor_height;  // ref :90
-    const bool use_cutoff = zone == 0;
-    const float qscale = (float)(1 << P.fxp_shift);
-
-    const unsigned long long t_begin = (Bt.debug & 4) ? wall_clock64() : 0ull;
-    // park this lane's points in its LDS slot
-    __shared__ float4 s_pts[kPPT][kBlock];
-    unsigned valid = 0, strip = 0;
+// the sixteen values Row<64>::reduce16_scatter adds up for a patch: n, S1[3], lower and upper halves of S2[6]
+__device__ __forceinline__ void moments_to_16(const Moments &mm, long long (&v)[16]) {
+    v[0] = mm.n;
+    v[1] = mm.s1[0];
+    v[2] = mm.s1[1];
+    v[3] = mm.s1[2];
 #pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-        const unsigned i = (unsigned)j + (unsigned)k * G;
-        if (i < n) {
-            const PwppXyz v = pts[i];
-            s_pts[k][threadIdx.x] = make_float4(v.x, v.y, v.z, __int_as_float(pidx[i]));
-            valid |= 1u << k;
-        }
-    }
-    const float4 *mine = &s_pts[0][threadIdx.x];
-
-    PlaneFit pl;
-    pl.nx = pl.ny = pl.nz = 0.0f;
-    pl.mean[0] = pl.mean[1] = pl.mean[2] = 0.0f;
-    pl.sv[0] = pl.sv[1] = pl.sv[2] = 0.0f;
-    pl.d = 0.0;
-    double lpr = 0.0;
-    bool lpr_valid = false;
-    int kind = !alive ? ST_DONE : ((P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED);  // row-uniform
-    int it = 0;
-
-    for (int guard = 0; guard < 4 * P.num_iter + 8; ++guard) {
-        if (!__any(kind != ST_DONE)) break;
-        long long cnt;
-        {
-            LanePts lp;
-            load_lane_points(lp, mine, kBlock, valid);
-            const unsigned act = valid & ~strip;
-            // ---- lowest-point representative (ref :84-103) where the working set is new
-            const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
-            if (__any(need_lpr)) {
-                unsigned key[8];
-                const int c = lane_lpr_keys(lp, act, need_lpr, use_cutoff, cutoff, key);
-                const int total = Row<G>::sum_i32(c);
-                const double l = tournament<G, false>(key, total, P.num_lpr, nullptr);
-                if (need_lpr) {
-                    lpr = l;
-                    lpr_valid = true;
-                }
-            }
-            // ---- the point set of this stage and its plane
-            const double thr_seed = lpr + ((kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds);
-            Moments m;
-            const unsigned gmask = lane_stage_moments(lp, act, kind, thr_seed, P.th_dist, pl, qscale, m);
-            cnt = Row<G>::sum_i64(m.n);
-            long long s1[3];
-            __int128 s2[6];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) s1[k] = Row<G>::sum_i64(m.s1[k]);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) s2[k] = (__int128)Row<G>::sum_i64(m.s2[k]);  // <= 512 points: fits int64
-            // the last R-GPF round writes the split BEFORE its plane is replaced (ref :529-541)
-            if (kind == ST_ITER && it == P.num_iter - 1) {
-                const unsigned ngm = valid & ~gmask;
-                unsigned tot_g, tot_n;
-                unsigned bg = Row<G>::excl_scan((unsigned)__popc(gmask), tot_g);
-                unsigned bn = Row<G>::excl_scan((unsigned)__popc(ngm), tot_n);
-#pragma unroll
-                for (int k = 0; k < kPPT; ++k) {
-                    if ((valid >> k & 1u) == 0) continue;
-                    const int idx = (int)(__float_as_uint(mine[k * kBlock].w) & 0x7fffffffu);
-                    if (gmask >> k & 1u)
-                        plist[bg++] = idx;  // regionwise_ground_ from the front
-                    else
-                        plist[n - 1u - (bn++)] = idx | ((strip >> k & 1u) ? (1 << 24) : 0);  // regionwise_nonground_ from the back (R-VPF strips marked; this kernel does not keep their round)
-                }
-            }
-            if (kind != ST_DONE && cnt > 0) plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);  // empty: ref :49
-        }
-        // ---- what comes next for this row
-        if (kind == ST_VPF) {
-            const bool vertical = (double)pl.nz < P.uprightness_thr;  // ref :489
-            if (__any(vertical)) {
-                asm volatile("" ::: "memory");  // re-read the points: they must not stay live across the solve
-                LanePts lp;
-                load_lane_points(lp, mine, kBlock, valid);
-                const unsigned hit = lane_strip(lp, valid & ~strip, vertical, pl, P.th_dist_v);
-                strip |= hit;
-                if (Row<G>::ballot(hit != 0) != 0ull) lpr_valid = false;  // the working set changed
-            }
-            ++it;
-            if (!vertical || it >= P.num_iter) {  // ref :506 / loop end
-                kind = ST_SEED;
-                it = 0;
-            }
-        } else if (kind == ST_SEED) {
-            kind = (cnt == 0 && P.enable_RVPF != 0 && zone != 0) ? ST_LAZY : ST_ITER;
-        } else if (kind == ST_LAZY) {
-            kind = ST_ITER;
-        } else if (kind == ST_ITER) {
-            if (it == P.num_iter - 1) {
-                if (j == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt);
-                kind = ST_DONE;
-            }
-            ++it;
-        }
-        asm volatile("" ::: "memory");
-    }
-    if ((Bt.debug & 4) && lane_id() == 0) {  // timing probe: wave lifetime in 100 MHz ticks
-        const unsigned long long dt = wall_clock64() - t_begin;
-        const int probe = G == 16 ? 0 : (G == 32 ? 1 : 2);
-        atomicMax(&Bt.dbg[probe * 4 + 0], dt);
-        atomicAdd(&Bt.dbg[probe * 4 + 1], dt);
-        atomicAdd(&Bt.dbg[probe * 4 + 2], 1ull);
+    for (int k = 0; k < 6; ++k) {
+        v[4 + k] = mm.s2[k] & 0xffffffffLL;
+        v[10 + k] = mm.s2[k] >> 32;
     }
 }
-
-// ------------------------------------------------------------------------------------------
-// Streaming rows: G lanes per patch (8, 16 or 64), the points are re-read from L2 at every
-// stage in chunks of 8 per lane.  Fewer lanes per patch = more patches per wave = the serial
-// eigen-solve (the dominant instruction count) is shared by more patches; the price is more
-// points per lane.  Patches of a frame are sorted by size (k_czm_scan), so the rows of one
-// wave have similar trip counts.  A workgroup per big patch was tried and rejected: all but
-// one wave idle during the solve (2.5 + 7.5 ms per 1024 frames vs 2.6 ms for one wave each).
-// ------------------------------------------------------------------------------------------
-struct ChunkPts {
-    LanePts lp;
-    unsigned valid;
-};
-// the points of a chunk that are still in the patch's working set (not removed by R-VPF); evaluated
-// where the chunk is consumed, so that a chunk loaded ahead does not have to land early
-__device__ __forceinline__ unsigned chunk_act(const ChunkPts &cp) {
-    unsigned strip = 0;
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k)
-        if (cp.lp.x[k] != cp.lp.x[k]) strip |= 1u << k;
-    return cp.valid & ~strip;
-}
-
-// a patch in the bin-ordered buffers: 12-byte coordinate records + their cloud indices
-struct PatchRef {
-    PwppXyz *xyz;
-    const int *idx;
-};
-__device__ __forceinline__ PatchRef patch_ref(const PwppBatch &Bt, size_t first) {
-    PatchRef r;
-    r.xyz = Bt.sorted_xyz + first;
-    r.idx = Bt.sorted_idx + first;
-    return r;
-}
-// R-VPF removes a point from the patch's working set (ref :495-503) by overwriting its x with NaN:
-// a binned point never has a NaN x, and the coordinates of a removed point are not needed again.
-// The NaN's payload is the R-VPF round (1-based): the reference appends the points a round removes to
-// regionwise_nonground_ round by round (ref :500), which the reference-order output mode reproduces.
-__device__ __forceinline__ void strip_point(const PatchRef &pr, unsigned i, int round) {
-    pr.xyz[i].x = __uint_as_float(0x7fc00000u | (unsigned)((round + 1) & 0xff));
-}
-// what the last R-GPF round writes for a non-ground point: its cloud index, plus in bits 24-31 the
-// R-VPF round that removed it (0: none) -- k_emit masks it off, k_order_sublists sorts by it
-__device__ __forceinline__ int nonground_entry(int idx, float x) {
-    return (x != x) ? (idx | (int)((__float_as_uint(x) & 0xffu) << 24)) : idx;
-}
-
-template <int G>
-__device__ __forceinline__ void load_chunk(ChunkPts &cp, const PatchRef &pr, unsigned n, unsigned c) {
-    cp.valid = 0;
-    const unsigned j = (unsigned)lane_id() & (G - 1);
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-        // unconditional loads (record 0 of the patch stands in beyond the end; the buffers carry a
-        // few records of slack): the compiler can then keep a whole chunk in flight behind the
-        // arithmetic of the previous one and wait with a counted s_waitcnt
-        const unsigned i = c * (8u * G) + (unsigned)k * G + j;
-        const PwppXyz v = pr.xyz[i < n ? i : 0u];
-        if (i < n) cp.valid |= 1u << k;
-        cp.lp.x[k] = v.x;
-        cp.lp.y[k] = v.y;
-        cp.lp.z[k] = v.z;
-    }
-}
-// the cloud indices of a chunk (only the pass that writes the split needs them)
-template <int G>
-__device__ __forceinline__ void load_chunk_idx(int w[kPPT], const PatchRef &pr, unsigned n, unsigned c) {
-    const unsigned j = (unsigned)lane_id() & (G - 1);
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-        const unsigned i = c * (8u * G) + (unsigned)k * G + j;
-        w[k] = i < n ? pr.idx[i] : 0;
-    }
-}
+__device__ __forceinline__ __int128 join_halves(long long lo, long long hi) { return ((__int128)hi << 32) + (__int128)lo; }
 
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~Row<64>::min_u32(~v); }
 
@@ -606,13 +404,13 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
     unsigned k0 = INF, k1 = INF, k2 = INF, k3 = INF, dropped = INF;
     int elig = 0;
     for (unsigned c = 0; c < nchunk_max; ++c) {
-        ChunkPts cp;
-        load_chunk<G>(cp, pts, need ? n : 0u, c);
+        ChunkZ cp;
+        load_chunk_z<G>(cp, pts, need ? n : 0u, c);
         const unsigned act = chunk_act(cp);
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
-            const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
-            unsigned x = e ? z_key(cp.lp.z[k]) : INF;
+            const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.z[k] < cutoff);
+            unsigned x = e ? z_key(cp.z[k]) : INF;
             ce(k0, x);
             ce(k1, x);
             ce(k2, x);
@@ -650,13 +448,13 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
         for (int q = 0; q < 8; ++q) key[q] = INF;
         bool overflow = false;
         for (unsigned c = 0; c < nchunk_max; ++c) {
-            ChunkPts cp;
-            load_chunk<G>(cp, pts, fast ? n : 0u, c);
+            ChunkZ cp;
+            load_chunk_z<G>(cp, pts, fast ? n : 0u, c);
             const unsigned act = chunk_act(cp);
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) {
-                const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
-                const unsigned kk = z_key(cp.lp.z[k]);
+                const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.z[k] < cutoff);
+                const unsigned kk = z_key(cp.z[k]);
                 const bool cand = fast && e && kk < U;
                 if (__any(cand)) {  // sorted insertion; whatever falls off the end must be "none"
                     unsigned x = cand ? kk : INF;
@@ -706,13 +504,13 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
             unsigned vmin = INF;
             int vcnt = 0;
             for (unsigned c = 0; c < nchunk_max; ++c) {
-                ChunkPts cp;
-                load_chunk<G>(cp, pts, remaining > 0 ? n : 0u, c);
+                ChunkZ cp;
+                load_chunk_z<G>(cp, pts, remaining > 0 ? n : 0u, c);
                 const unsigned act = chunk_act(cp);
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k) {
-                    const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
-                    const unsigned kk = z_key(cp.lp.z[k]);
+                    const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.z[k] < cutoff);
+                    const unsigned kk = z_key(cp.z[k]);
                     if (e && (first || kk > prev)) {
                         if (kk < vmin) {
                             vmin = kk;
@@ -743,11 +541,46 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
     return keff ? sum / (double)keff : 0.0;  // ref :103
 }
 
-template <int G>
-__device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, int b_hi, unsigned by /* block index among the row blocks */) {
-    const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
+
+// what every fit kernel needs of a patch before its chain starts
+struct PatchCtx {
+    int bin, zone;
+    unsigned n, off;
+    float ox, oy;  // origin of the bin's fixed-point sums
+};
+__device__ __forceinline__ PatchCtx patch_ctx(const PwppBatch &Bt, int f, unsigned slot, bool alive) {
     const PwppDevParams &P = Bt.P;
     const int NB = P.num_bins + 2;
+    PatchCtx c;
+    c.bin = alive ? (int)Bt.cls_list[(size_t)f * P.num_bins + slot] : 0;
+    c.n = alive ? Bt.bin_count[(size_t)f * NB + c.bin] : 0u;
+    c.off = alive ? Bt.bin_off[(size_t)f * NB + c.bin] : 0u;
+    c.zone = c.bin < P.bin_base[1] ? 0 : (c.bin < P.bin_base[2] ? 1 : (c.bin < P.bin_base[3] ? 2 : 3));
+    const float2 o = Bt.bin_origin[c.bin];
+    c.ox = o.x;
+    c.oy = o.y;
+    return c;
+}
+__device__ __forceinline__ void plane_clear(PlaneFit &pl) {
+    pl.nx = pl.ny = pl.nz = 0.0f;
+    pl.mean[0] = pl.mean[1] = pl.mean[2] = 0.0f;
+    pl.sv[0] = pl.sv[1] = pl.sv[2] = 0.0f;
+    pl.d = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Streaming rows: G lanes per patch (8, 16 or 64), the points are re-read from L2 at every
+// stage in chunks of 8 per lane.  Fewer lanes per patch = more patches per wave = the serial
+// eigen-solve (the dominant instruction count) is shared by more patches; the price is more
+// points per lane.  Patches of a frame are sorted by size (k_czm_scan), so the rows of one
+// wave have similar trip counts.  A workgroup per big patch was tried and rejected: all but
+// one wave idle during the solve (2.5 + 7.5 ms per 1024 frames vs 2.6 ms for one wave each).
+// ------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, int b_hi, unsigned by /* block index among the row blocks */) {
+    const int f = blockIdx.x;  // frame = fast grid dimension: most blocks of a frame's worst-case grid are empty, and with the
+                               // frame in blockIdx.y the working blocks formed a pattern of period 32 = 8 XCDs x 4 SEs (3x slower)
+    const PwppDevParams &P = Bt.P;
     const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
     const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
     const unsigned tid = by * kBlock + threadIdx.x;
@@ -757,26 +590,25 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
     // and the last waves to start should be the short ones
     const unsigned slot = cend - 1u - tid / G;
     const int j = lane_id() & (G - 1);
-    const int bin = alive ? (int)Bt.cls_list[(size_t)f * P.num_bins + slot] : 0;
-    const unsigned n = alive ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
+    const PatchCtx pc = patch_ctx(Bt, f, slot, alive);
+    const int bin = pc.bin, zone = pc.zone;
+    const unsigned n = pc.n;
     const PwppFrameDesc fd = Bt.frames[f];
-    const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + off);
-    int *plist = Bt.plist + fd.sbase + off;
-    const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
+    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + pc.off);
+    int *plist = Bt.plist + fd.sbase + pc.off;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;
     const bool use_cutoff = zone == 0;
-    const float qscale = (float)(1 << P.fxp_shift);
+    const double scale = (double)(1 << P.fxp_shift);
     const unsigned nchunk_max = wave_max_u32((n + 8u * G - 1u) / (8u * G));
+    const bool wide = __any(n > 2047u);  // wave-uniform: some row's second moments may leave int64 in the cross-lane sum
 
     PlaneFit pl;
-    pl.nx = pl.ny = pl.nz = 0.0f;
-    pl.mean[0] = pl.mean[1] = pl.mean[2] = 0.0f;
-    pl.sv[0] = pl.sv[1] = pl.sv[2] = 0.0f;
-    pl.d = 0.0;
+    plane_clear(pl);
     double lpr = 0.0;
-    bool lpr_valid = false;
+    bool lpr_valid = false, z0_set = false;
+    float z0 = 0.0f;
+    FxpOrg org = fxp_org(pc.ox, pc.oy, 0.0f, scale, P.fxp_zr);
     int kind = !alive ? ST_DONE : ((P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED);  // row-uniform
     int it = 0;
 
@@ -784,18 +616,21 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
         if (!__any(kind != ST_DONE)) break;
         const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
         if (__any(need_lpr)) {
-            const double l = (Bt.debug & 512) ? -1.7 : srow_lpr<G>(pts, n, nchunk_max, need_lpr, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
+            const double l = srow_lpr<G>(pts, n, nchunk_max, need_lpr, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
             if (need_lpr) {
                 lpr = l;
                 lpr_valid = true;
+                if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative
+                    z0 = fxp_z_origin(l);
+                    z0_set = true;
+                    org = fxp_org(pc.ox, pc.oy, z0, scale, P.fxp_zr);
+                }
             }
         }
         const double thr_seed = lpr + ((kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds);
         const bool last = kind == ST_ITER && it == P.num_iter - 1;
         Moments m;
         m.clear();
-        ChunkMoments cm;
-        cm.clear();
         unsigned run_g = 0, run_n = 0;
         ChunkPts cp;
         load_chunk<G>(cp, pts, kind != ST_DONE ? n : 0u, 0u);
@@ -804,11 +639,7 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
             load_chunk<G>(nx, pts, kind != ST_DONE ? n : 0u, c + 1u);
             int w[kPPT];
             if (__any(last)) load_chunk_idx<G>(w, pts, last ? n : 0u, c);
-            const unsigned gmask = lane_stage_accum(cp.lp, chunk_act(cp), kind, thr_seed, P.th_dist, pl, qscale, cm);
-            if ((c + 1u) % kFlushChunks == 0u) {
-                cm.flush_into(m);
-                cm.clear();
-            }
+            const unsigned gmask = lane_stage_accum(cp, chunk_act(cp), kind, thr_seed, P.th_dist, pl, scale, org, m);
             if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                 const unsigned gm = last ? gmask : 0u;
                 const unsigned ngm = last ? (cp.valid & ~gmask) : 0u;
@@ -822,32 +653,35 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
                     if (gm >> k & 1u)
                         plist[bg++] = w[k];
                     else if (ngm >> k & 1u)
-                        plist[n - 1u - (bn++)] = nonground_entry(w[k], cp.lp.x[k]);
+                        plist[n - 1u - (bn++)] = nonground_entry(w[k], cp.z[k]);
                 }
             }
             cp = nx;
         }
-        cm.flush_into(m);
         const long long cnt = Row<G>::sum_i64(m.n);
         {
             long long s1[3];
             __int128 s2[6];
 #pragma unroll
             for (int k = 0; k < 3; ++k) s1[k] = Row<G>::sum_i64(m.s1[k]);
+            if (!wide) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) s2[k] = (__int128)Row<G>::sum_i64(m.s2[k]);  // <= 65536 points: fits int64
-            if (Bt.debug & 256) {  // timing ablation only: no solve at all
-                pl.nx = 0.01f; pl.ny = 0.02f; pl.nz = 0.999f; pl.d = 1.7 + 1e-9 * (double)s1[0];
-            } else if (kind != ST_DONE && cnt > 0) plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);  // empty: ref :49
+                for (int k = 0; k < 6; ++k) s2[k] = (__int128)Row<G>::sum_i64(m.s2[k]);  // <= 2047 points: fits int64
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    s2[k] = join_halves(Row<G>::sum_i64(m.s2[k] & 0xffffffffLL), Row<G>::sum_i64(m.s2[k] >> 32));
+            }
+            if (kind != ST_DONE && cnt > 0) plane_from_totals(cnt, s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug, pl);  // empty: ref :49
         }
         if (kind == ST_VPF) {
             const bool vertical = (double)pl.nz < P.uprightness_thr;  // ref :489
             if (__any(vertical)) {
                 bool any = false;
                 for (unsigned c = 0; c < nchunk_max; ++c) {
-                    ChunkPts cp;
-                    load_chunk<G>(cp, pts, vertical ? n : 0u, c);
-                    const unsigned hit = lane_strip(cp.lp, chunk_act(cp), vertical, pl, P.th_dist_v);
+                    ChunkPts cs2;
+                    load_chunk<G>(cs2, pts, vertical ? n : 0u, c);
+                    const unsigned hit = lane_strip(cs2, chunk_act(cs2), vertical, pl, P.th_dist_v);
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k) {
                         if (hit >> k & 1u) {
@@ -884,20 +718,17 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo,
 }
 
 // ------------------------------------------------------------------------------------------
-// class 5: bins too large for registers, streamed from L2/HBM on every pass
-// ------------------------------------------------------------------------------------------
-// ------------------------------------------------------------------------------------------
-// k_fit_w64: one wave = 64 patches.  The VALU profile of the row kernels showed the serial
+// k_fit_w64: one wave = up to 64 patches.  The VALU profile of the row kernels showed the serial
 // eigen-solve (~1800 VALU instructions, executed by all 64 lanes of a wave for only 1-4 patches)
-// to be the largest single consumer of issue cycles of the fit stage.  Here a wave owns up to 64 patches of a frame:
-//   * points phases run 4 patches at a time in rows of 16 lanes (points streamed from L2) and
-//     leave the ten integer moments of every patch in LDS;
-//   * the solve phase runs ONCE per stage with lane p solving patch p -- 64 different 3x3
+// to be the largest single consumer of issue cycles of the fit stage.  Here a wave owns PW patches of a frame:
+//   * points phases run 64 / G patches at a time in rows of G lanes (points streamed from L2) and
+//     leave the integer moments of every patch in LDS;
+//   * the solve phase runs ONCE per stage with lane p solving patch p -- PW different 3x3
 //     problems per instruction stream instead of 1-4;
 //   * lane p ("owner") carries patch p's state machine (stage, LPR, plane) in registers and
-//     publishes what the rows need (plane, thresholds) through LDS.
+//     publishes what the rows need (plane, thresholds, origin) through LDS.
 // Patches are handed to the waves of a frame round-robin over the size-sorted list, so every
-// wave gets a similar mix and the 4 rows of a points phase have similar trip counts.
+// wave gets a similar mix and the rows of a points phase have similar trip counts.
 // Waves are independent: no workgroup barrier anywhere.
 // ------------------------------------------------------------------------------------------
 struct W64Patch {
@@ -909,12 +740,14 @@ struct W64Patch {
     double d;
     double thr_seed;
     double thr_band;  // dual seed pass: upper end of the band [thr_seed, thr_band)
+    float ox, oy, z0; // origin of the patch's fixed-point sums
+    float pad_;
 };
-template <int PW, bool DUAL>
+template <int PW, bool DUAL, int MW>
 struct W64Shared {
     W64Patch p[PW];
-    long long mom[PW][10];
-    long long mom2[DUAL ? PW : 1][10];  // dual seed pass: moments of the band; then the stashed seed totals of the R-GPF stage
+    long long mom[PW][MW];
+    long long mom2[DUAL ? PW : 1][MW];  // dual seed pass: moments of the band; then the stashed seed totals of the R-GPF stage
     double lpr[PW];
     int stripped[PW];
 };
@@ -927,16 +760,18 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // G = lanes per patch in the points phases (16: four patches at a time; 64: one at a time, for
 // big bins), PW = patches owned by the wave = lanes active in the solve phase.
+// Moments per patch in LDS: rows of 16 lanes only see patches below 2048 points, whose ten totals fit
+// int64; 64-lane rows leave sixteen values (second moments as 32-bit halves, Row<64>::reduce16_scatter).
 template <int G, int PW>
 __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, int b_lo, int b_hi) {
-    __shared__ W64Shared<PW, G == 64> sh_all[kWaves];
-    W64Shared<PW, G == 64> &sh = sh_all[wave_id()];
+    constexpr int MW = G == 64 ? 16 : 10;
+    __shared__ W64Shared<PW, G == 64, MW> sh_all[kWaves];
+    W64Shared<PW, G == 64, MW> &sh = sh_all[wave_id()];
     constexpr int R = 64 / G;      // patches per points-phase sub-batch
     constexpr int NSB = PW / R;    // sub-batches
     static_assert(PW % R == 0 && PW <= 64, "patches per wave");
-    const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
+    const int f = blockIdx.x;  // frame = fast grid dimension, see fit_srows_body
     const PwppDevParams &P = Bt.P;
-    const int NB = P.num_bins + 2;
     const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
     const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
     const unsigned npatch = cend - cbeg;
@@ -949,22 +784,19 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
     int *frame_plist = Bt.plist + fd.sbase;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;  // ref :90
-    const float qscale = (float)(1 << P.fxp_shift);
+    const double scale = (double)(1 << P.fxp_shift);
 
     // ---- owner lane: patch `ln` of this wave (lanes >= PW own nothing)
     const unsigned slot = cbeg + w + (unsigned)ln * nwaves;
     const bool alive = ln < PW && slot < cend;
-    const int bin = alive ? (int)Bt.cls_list[(size_t)f * P.num_bins + slot] : 0;
-    const unsigned n = alive ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
-    const unsigned off = alive ? Bt.bin_off[(size_t)f * NB + bin] : 0u;
-    const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
+    const PatchCtx pc = patch_ctx(Bt, f, slot, alive);
+    const int bin = pc.bin, zone = pc.zone;
+    const unsigned n = pc.n;
     PlaneFit pl;
-    pl.nx = pl.ny = pl.nz = 0.0f;
-    pl.mean[0] = pl.mean[1] = pl.mean[2] = 0.0f;
-    pl.sv[0] = pl.sv[1] = pl.sv[2] = 0.0f;
-    pl.d = 0.0;
+    plane_clear(pl);
     double lpr = 0.0;
-    bool lpr_valid = false;
+    bool lpr_valid = false, z0_set = false;
+    float z0 = 0.0f;
     int kind = !alive ? ST_DONE : ((P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED);
     int it = 0;
     // Dual seed pass (big bins, G == 64): the R-VPF round and the R-GPF seed stage of a zone-0 patch
@@ -977,10 +809,13 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
     const bool v_is_hi = P.th_seeds_v >= P.th_seeds;
     bool stash_valid = false, dual_now = false;
     if (ln < PW) {
-        sh.p[ln].off = off;
+        sh.p[ln].off = pc.off;
         sh.p[ln].n = n;
         sh.p[ln].kind = ST_DONE;
         sh.p[ln].flags = zone == 0 ? 2 : 0;
+        sh.p[ln].ox = pc.ox;
+        sh.p[ln].oy = pc.oy;
+        sh.p[ln].z0 = 0.0f;
         sh.stripped[ln] = 0;
     }
     wave_lds_sync();
@@ -988,7 +823,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
     for (int guard = 0; guard < 4 * P.num_iter + 8; ++guard) {
         if (!__any(kind != ST_DONE)) break;
 
-        // ---- A. lowest-point representative (ref :84-103) for the patches whose working set is new
+        // ---- A. lowest-point representative (ref :84-103) for the patches whose working set is new: z only
         const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
         const unsigned long long lpr_mask = __ballot(need_lpr);
         if (lpr_mask) {
@@ -1006,6 +841,10 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
             if (need_lpr) {
                 lpr = sh.lpr[ln];
                 lpr_valid = true;
+                if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative
+                    z0 = fxp_z_origin(lpr);
+                    z0_set = true;
+                }
             }
         }
 
@@ -1021,6 +860,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
             sh.p[ln].ny = pl.ny;
             sh.p[ln].nz = pl.nz;
             sh.p[ln].d = pl.d;
+            sh.p[ln].z0 = z0;
             const double th = (kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds;
             sh.p[ln].thr_seed = lpr + (dual_now ? (v_is_hi ? P.th_seeds : P.th_seeds_v) : th);
             sh.p[ln].thr_band = lpr + (v_is_hi ? P.th_seeds_v : P.th_seeds);
@@ -1040,6 +880,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
             qpl.ny = pp.ny;
             qpl.nz = pp.nz;
             qpl.d = pp.d;
+            const FxpOrg org = fxp_org(pp.ox, pp.oy, pp.z0, scale, P.fxp_zr);
             const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + pp.off);
             int *plist = frame_plist + pp.off;
             const unsigned qn = on ? pp.n : 0u;
@@ -1048,8 +889,6 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
             Moments m, m2;
             m.clear();
             m2.clear();
-            ChunkMoments cm;
-            cm.clear();
             unsigned run_g = 0, run_n = 0;
             for (unsigned c = 0; c < nchunk_max; ++c) {
                 ChunkPts cp;
@@ -1057,16 +896,12 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
                 int w[kPPT];
                 if (__any(last)) load_chunk_idx<G>(w, pts, last ? qn : 0u, c);
                 const unsigned act = chunk_act(cp);
-                const unsigned gmask = lane_stage_accum(cp.lp, act, pp.kind, pp.thr_seed, P.th_dist, qpl, qscale, cm);
-                if ((c + 1u) % kFlushChunks == 0u) {
-                    cm.flush_into(m);
-                    cm.clear();
-                }
+                const unsigned gmask = lane_stage_accum(cp, act, pp.kind, pp.thr_seed, P.th_dist, qpl, scale, org, m);
                 if (DUAL && __any(dual)) {  // the band [thr_seed, thr_band) of a dual seed pass
                     const unsigned rest = dual ? (act & ~gmask) : 0u;
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k)
-                        if ((rest >> k & 1u) && (double)cp.lp.z[k] < pp.thr_band) m2.add(cp.lp.x[k], cp.lp.y[k], cp.lp.z[k], qscale);
+                        if ((rest >> k & 1u) && (double)cp.z[k] < pp.thr_band) m2.add(cp.x[k], cp.y[k], cp.z[k], scale, org);
                 }
                 if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                     const unsigned gm = last ? gmask : 0u;
@@ -1081,20 +916,20 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
                         if (gm >> k & 1u)
                             plist[bg++] = w[k];
                         else if (ngm >> k & 1u)
-                            plist[qn - 1u - (bn++)] = nonground_entry(w[k], cp.lp.x[k]);
+                            plist[qn - 1u - (bn++)] = nonground_entry(w[k], cp.z[k]);
                     }
                 }
             }
-            cm.flush_into(m);
-            // the row's ten totals -> LDS.  64-lane rows: reduce-scatter, each total stored by the lane it ends
-            // up with (big-bin kernel 1.150 -> 1.129 ms); 16-lane rows: ten butterflies (four steps each;
-            // the selects of the scatter cost what its fewer exchanges save: 0.868 -> 0.884 ms)
-            auto row_totals = [&](const Moments &mm, long long (*dst)[10], bool store) {
+            // the row's totals -> LDS.  64-lane rows: reduce-scatter of sixteen values, each stored by the lane it
+            // ends up with; 16-lane rows: ten butterflies (four steps each; the selects of a scatter cost what its
+            // fewer exchanges save: 0.868 -> 0.884 ms)
+            auto row_totals = [&](const Moments &mm, long long (*dst)[MW], bool store) {
                 if constexpr (G == 64) {
-                    const long long v[10] = {mm.n, mm.s1[0], mm.s1[1], mm.s1[2], mm.s2[0], mm.s2[1], mm.s2[2], mm.s2[3], mm.s2[4], mm.s2[5]};
-                    int slot;
-                    const long long mine = Row<G>::reduce10_scatter(v, slot);
-                    if (store && slot >= 0 && j < 16) dst[q][slot] = mine;
+                    long long v[16];
+                    moments_to_16(mm, v);
+                    int slot16;
+                    const long long mine = Row<G>::reduce16_scatter(v, slot16);
+                    if (store && j < 16) dst[q][slot16] = mine;
                 } else {
                     long long v[10];
                     v[0] = Row<G>::sum_i64(mm.n);
@@ -1118,12 +953,12 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
         // ---- D. solve phase: lane p fits patch p (ref :47-75)
         long long cnt = 0;
         if (kind != ST_DONE) {
-            long long tot[10];
+            long long tot[MW];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) tot[k] = from_stash ? sh.mom2[DUAL ? ln : 0][k] : sh.mom[ln][k];
+            for (int k = 0; k < MW; ++k) tot[k] = from_stash ? sh.mom2[DUAL ? ln : 0][k] : sh.mom[ln][k];
             if (dual_now) {  // mom = below the smaller threshold (A), mom2 = the band (B)
 #pragma unroll
-                for (int k = 0; k < 10; ++k) {
+                for (int k = 0; k < MW; ++k) {
                     const long long a = tot[k], ab = a + sh.mom2[DUAL ? ln : 0][k];
                     tot[k] = v_is_hi ? ab : a;            // this round: the R-VPF seeds (th_seeds_v)
                     sh.mom2[DUAL ? ln : 0][k] = v_is_hi ? a : ab;    // stash: the R-GPF seeds (th_seeds)
@@ -1135,8 +970,8 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
                 const long long s1[3] = {tot[1], tot[2], tot[3]};
                 __int128 s2[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) s2[k] = (__int128)tot[4 + k];  // <= 65535 points: fits int64
-                plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);
+                for (int k = 0; k < 6; ++k) s2[k] = G == 64 ? join_halves(tot[4 + k], tot[MW == 16 ? 10 + k : 4 + k]) : (__int128)tot[4 + k];
+                plane_from_totals(cnt, s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug, pl);
             }
         }
 
@@ -1170,7 +1005,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
                 for (unsigned c = 0; c < nchunk_max; ++c) {
                     ChunkPts cp;
                     load_chunk<G>(cp, pts, qn, c);
-                    const unsigned hit = lane_strip(cp.lp, chunk_act(cp), vrow, qpl, P.th_dist_v);
+                    const unsigned hit = lane_strip(cp, chunk_act(cp), vrow, qpl, P.th_dist_v);
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k) {
                         if (hit >> k & 1u) {
@@ -1210,196 +1045,8 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Phase kernels ("P" plan): the fit chain cut at every plane fit.
-//   k_ph_rows   rows of 16 lanes: [R-VPF strip] -> [LPR] -> points phase -> ten integer moments
-//               per patch to global memory.  No eigen-solve in this kernel: few registers,
-//               eight waves per SIMD to hide the L2 latency of the streamed points.
-//   k_ph_solve  ONE LANE PER PATCH: plane from the moments + the state transition.  64 different
-//               3x3 problems per wave instruction stream instead of 1-4: the solve, a third of the
-//               instructions of the row kernels, shrinks to a few percent.
-// A batch runs 2*num_iter + 2 rounds of (rows, solve); patches that are finished exit at once.
-// ------------------------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(kBlock, 5) void k_ph_rows(PwppBatch Bt, int b_lo, int b_hi) {
-    const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
-    const PwppDevParams &P = Bt.P;
-    const int NB = P.num_bins + 2;
-    const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
-    const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
-    const unsigned tid = blockIdx.y * kBlock + threadIdx.x;
-    if (cbeg + (tid & ~63u) / G >= cend) return;  // this wave has no patch
-    const unsigned slot = cbeg + tid / G;
-    const bool alive = slot < cend;  // row-uniform
-    const int j = lane_id() & (G - 1);
-    const int bin = alive ? (int)Bt.cls_list[(size_t)f * P.num_bins + slot] : 0;
-    PwppFitState *st = Bt.fit + (size_t)f * P.num_bins + bin;
-    const int kind = alive ? st->kind : ST_DONE;
-    if (!__any(kind != ST_DONE)) return;
-    const unsigned n = kind != ST_DONE ? Bt.bin_count[(size_t)f * NB + bin] : 0u;
-    const PwppFrameDesc fd = Bt.frames[f];
-    const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + off);
-    int *plist = Bt.plist + fd.sbase + off;
-    const bool use_cutoff = bin < P.bin_base[1];  // zone 0
-    const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
-    const double cutoff = P.margin * sensor_height;  // ref :90
-    const float qscale = (float)(1 << P.fxp_shift);
-    const unsigned nchunk_max = wave_max_u32((n + 8u * G - 1u) / (8u * G));
-    PlaneFit pl;
-    pl.nx = st->nx;
-    pl.ny = st->ny;
-    pl.nz = st->nz;
-    pl.d = st->d;
-    bool lpr_valid = kind != ST_DONE && st->lpr_valid != 0;
-    double lpr = st->lpr;
-
-    // ---- R-VPF strip decided by the previous solve (ref :489-505)
-    const bool strip = kind != ST_DONE && st->need_strip != 0;
-    if (__any(strip)) {
-        bool any = false;
-        for (unsigned c = 0; c < nchunk_max; ++c) {
-            ChunkPts cp;
-            load_chunk<G>(cp, pts, strip ? n : 0u, c);
-            const unsigned hit = lane_strip(cp.lp, chunk_act(cp), strip, pl, P.th_dist_v);
-#pragma unroll
-            for (int k = 0; k < kPPT; ++k) {
-                if (hit >> k & 1u) {
-                    const unsigned i = c * (8u * G) + (unsigned)k * G + (unsigned)j;
-                    strip_point(pts, i, st->it);
-                }
-            }
-            any = any || hit != 0;
-        }
-        if (strip && Row<G>::ballot(any) != 0ull) lpr_valid = false;  // the working set changed
-        if (strip && j == 0) st->need_strip = 0;
-    }
-    // ---- lowest-point representative (ref :84-103)
-    const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
-    if (__any(need_lpr)) {
-        const double l = srow_lpr<G>(pts, n, nchunk_max, need_lpr, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
-        if (need_lpr) {
-            lpr = l;
-            if (j == 0) {
-                st->lpr = l;
-                st->lpr_valid = 1;
-            }
-        }
-    }
-    // ---- points phase
-    const double thr_seed = lpr + ((kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds);
-    const bool last = kind == ST_ITER && st->it == P.num_iter - 1;
-    Moments m;
-    m.clear();
-    unsigned run_g = 0, run_n = 0;
-    for (unsigned c = 0; c < nchunk_max; ++c) {
-        ChunkPts cp;
-        load_chunk<G>(cp, pts, n, c);
-        int w[kPPT];
-        if (__any(last)) load_chunk_idx<G>(w, pts, last ? n : 0u, c);
-        Moments mc;
-        const unsigned gmask = lane_stage_moments(cp.lp, chunk_act(cp), kind, thr_seed, P.th_dist, pl, qscale, mc);
-        m.n += mc.n;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) m.s1[k] += mc.s1[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) m.s2[k] += mc.s2[k];
-        if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
-            const unsigned gm = last ? gmask : 0u;
-            const unsigned ngm = last ? (cp.valid & ~gmask) : 0u;
-            unsigned tg, tn;
-            unsigned bg = run_g + Row<G>::excl_scan((unsigned)__popc(gm), tg);
-            unsigned bn = run_n + Row<G>::excl_scan((unsigned)__popc(ngm), tn);
-            run_g += tg;
-            run_n += tn;
-#pragma unroll
-            for (int k = 0; k < kPPT; ++k) {
-                if (gm >> k & 1u)
-                    plist[bg++] = w[k];
-                else if (ngm >> k & 1u)
-                    plist[n - 1u - (bn++)] = nonground_entry(w[k], cp.lp.x[k]);
-            }
-        }
-    }
-    long long v[10];
-    v[0] = Row<G>::sum_i64(m.n);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) v[1 + k] = Row<G>::sum_i64(m.s1[k]);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) v[4 + k] = Row<G>::sum_i64(m.s2[k]);
-    if (kind != ST_DONE && j < 10) {  // lane j of the row stores moment j
-        long long mine = v[0];
-#pragma unroll
-        for (int k = 1; k < 10; ++k) mine = j == k ? v[k] : mine;
-        st->mom[j] = mine;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_ph_solve(PwppBatch Bt, int b_lo, int b_hi) {
-    const int f = blockIdx.x;
-    const PwppDevParams &P = Bt.P;
-    const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
-    const unsigned slot = cs[b_lo] + blockIdx.y * kBlock + threadIdx.x;
-    if (slot >= cs[b_hi]) return;
-    const int bin = Bt.cls_list[(size_t)f * P.num_bins + slot];
-    PwppFitState *st = Bt.fit + (size_t)f * P.num_bins + bin;
-    int kind = st->kind;
-    if (kind == ST_DONE) return;
-    int it = st->it;
-    const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
-    PlaneFit pl;
-    pl.nx = st->nx;
-    pl.ny = st->ny;
-    pl.nz = st->nz;
-    pl.d = st->d;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        pl.mean[k] = st->mean[k];
-        pl.sv[k] = st->sv[k];
-    }
-    const long long cnt = st->mom[0];
-    if (cnt > 0) {  // empty set: the previous plane stays (ref :49)
-        const long long s1[3] = {st->mom[1], st->mom[2], st->mom[3]};
-        __int128 s2[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s2[k] = (__int128)st->mom[4 + k];  // <= 65535 points: fits int64
-        plane_from_totals(cnt, s1, s2, P.fxp_shift, Bt.debug, pl);
-        st->nx = pl.nx;
-        st->ny = pl.ny;
-        st->nz = pl.nz;
-        st->d = pl.d;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            st->mean[k] = pl.mean[k];
-            st->sv[k] = pl.sv[k];
-        }
-    }
-    if (kind == ST_VPF) {
-        const bool vertical = (double)pl.nz < P.uprightness_thr;  // ref :489
-        if (vertical) st->need_strip = 1;
-        ++it;
-        if (!vertical || it >= P.num_iter) {  // ref :506 / loop end
-            kind = ST_SEED;
-            it = 0;
-        }
-    } else if (kind == ST_SEED) {
-        kind = (cnt == 0 && P.enable_RVPF != 0 && zone != 0) ? ST_LAZY : ST_ITER;
-    } else if (kind == ST_LAZY) {
-        kind = ST_ITER;
-    } else if (kind == ST_ITER) {
-        if (it == P.num_iter - 1) {
-            const unsigned n = Bt.bin_count[(size_t)f * (P.num_bins + 2) + bin];
-            write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt);
-            kind = ST_DONE;
-        }
-        ++it;
-    }
-    st->kind = kind;
-    st->it = it;
-}
-
 struct FitShared {
-    long long part[kWaves][16];
+    long long part[kWaves][22];
     float normal[3];
     float mean[3];
     float sv[3];
@@ -1417,54 +1064,72 @@ struct FitShared {
     unsigned cnt_ng;
 };
 
+// per-lane sums of the workgroup-per-patch kernel: it takes patches of any size, so the second moments are
+// kept in 128 bits (a lane of the other kernels never sees more than 2047 points, see Moments)
+struct MomentsWide {
+    long long n, s1[3];
+    __int128 s2[6];
+    __device__ __forceinline__ void clear() {
+        n = 0;
+        s1[0] = s1[1] = s1[2] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s2[k] = 0;
+    }
+    __device__ __forceinline__ void add(float x, float y, float z, double scale, const FxpOrg &o) {
+        const long long qx = fxp_q(x, scale, o.cx), qy = fxp_q(y, scale, o.cy);
+        const long long qz = fxp_q(__builtin_amdgcn_fmed3f(z, o.zlo, o.zhi), scale, o.cz);
+        n += 1;
+        s1[0] += qx;
+        s1[1] += qy;
+        s1[2] += qz;
+        s2[0] += (__int128)(qx * qx);
+        s2[1] += (__int128)(qx * qy);
+        s2[2] += (__int128)(qx * qz);
+        s2[3] += (__int128)(qy * qy);
+        s2[4] += (__int128)(qy * qz);
+        s2[5] += (__int128)(qz * qz);
+    }
+};
+
 // Block-wide sum of the moments and, if the set is non-empty, the plane of ref :47-75.
-// An empty set leaves the previous plane in force, as ref :49 does.
-// `wide`: bins above 65536 points could overflow an int64 second moment in the cross-lane
-// sum; they are reduced as two 32-bit limbs and recombined in 128 bits (exact either way).
-__device__ void reduce_and_fit(FitShared &sh, const Moments &m, bool wide, int shift, int debug = 0) {
-    long long v[16];
+// An empty set leaves the previous plane in force, as ref :49 does.  The 128-bit second moments are
+// added up as three limbs (32 + 32 + 64 bits) and recombined: exact at any size.
+__device__ void reduce_and_fit(FitShared &sh, const MomentsWide &m, int shift, float ox, float oy, float z0, int debug = 0) {
+    long long v[22];
     v[0] = m.n;
     v[1] = m.s1[0];
     v[2] = m.s1[1];
     v[3] = m.s1[2];
-    const int nv = wide ? 16 : 10;
-    if (!wide) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v[4 + k] = m.s2[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            v[4 + k] = m.s2[k] & 0xffffffffll;
-            v[10 + k] = m.s2[k] >> 32;
-        }
+    for (int k = 0; k < 6; ++k) {
+        const unsigned long long lo = (unsigned long long)m.s2[k];
+        v[4 + k] = (long long)(lo & 0xffffffffull);
+        v[10 + k] = (long long)(lo >> 32);
+        v[16 + k] = (long long)(m.s2[k] >> 64);
     }
     const int wv = wave_id(), ln = lane_id();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if (k < nv) {
-            const long long t = wave_sum_i64(v[k]);
-            if (ln == 0) sh.part[wv][k] = t;
-        }
+    for (int k = 0; k < 22; ++k) {
+        const long long t = wave_sum_i64(v[k]);
+        if (ln == 0) sh.part[wv][k] = t;
     }
     __syncthreads();
     if (wv == 0) {
-        long long t[16];
+        long long t[22];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < 22; ++k) {
             t[k] = 0;
-            if (k < nv) {
 #pragma unroll
-                for (int q = 0; q < kWaves; ++q) t[k] += sh.part[q][k];
-            }
+            for (int q = 0; q < kWaves; ++q) t[k] += sh.part[q][k];
         }
         const long long n = t[0];
         if (n > 0) {
             __int128 s2[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) s2[k] = wide ? ((__int128)t[10 + k] * (__int128)4294967296ll + (__int128)t[4 + k]) : (__int128)t[4 + k];
+            for (int k = 0; k < 6; ++k) s2[k] = ((__int128)t[16 + k] << 64) + ((__int128)t[10 + k] << 32) + (__int128)t[4 + k];
             const long long s1[3] = {t[1], t[2], t[3]};
             PlaneFit pf;
-            plane_from_totals(n, s1, s2, shift, debug, pf);
+            plane_from_totals(n, s1, s2, shift, ox, oy, z0, debug, pf);
             if (ln == 0) {
                 sh.normal[0] = pf.nx;
                 sh.normal[1] = pf.ny;
@@ -1482,14 +1147,6 @@ __device__ void reduce_and_fit(FitShared &sh, const Moments &m, bool wide, int s
     __syncthreads();
 }
 
-__device__ __forceinline__ bool pt_stripped(const float4 &p) { return (__float_as_uint(p.w) & 0x80000000u) != 0; }
-// the workgroup kernel keeps the 16-byte view {x, y, z, bits(idx) | stripped << 31} of a record
-__device__ __forceinline__ float4 load_pt4(const PatchRef &pr, unsigned i) {
-    const PwppXyz v = pr.xyz[i];
-    const unsigned w = (unsigned)pr.idx[i] | (v.x != v.x ? 0x80000000u : 0u);
-    return make_float4(v.x, v.y, v.z, __uint_as_float(w));
-}
-
 // Lowest-point representative height, ref :84-103, without sorting the bin: the reference
 // needs (a) how many points lie below the adaptive cut-off (zone 0 only, :88-96), (b) the
 // num_lpr smallest z among the others, summed in ascending order in double (:99-102).
@@ -1504,10 +1161,10 @@ __device__ double block_lpr(FitShared &sh, const PatchRef &pts, unsigned n, bool
         if (threadIdx.x == 0 && pass == 3) sh.sel_count = 0;
         __syncthreads();
         for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-            const float4 p = load_pt4(pts, i);
-            if (pt_stripped(p)) continue;
-            if (use_cutoff && (double)p.z < cutoff) continue;  // init_idx prefix, ref :88-96
-            const unsigned key = z_key(p.z);
+            const float pz = pts.z[i];
+            if (z_stripped(pz)) continue;
+            if (use_cutoff && (double)pz < cutoff) continue;  // init_idx prefix, ref :88-96
+            const unsigned key = z_key(pz);
             if (pass > 0) {
                 const unsigned hp = key >> (bits + 8);
                 if (hp != prefix) {
@@ -1599,11 +1256,6 @@ __device__ double block_lpr(FitShared &sh, const PatchRef &pts, unsigned n, bool
     return sh.lpr;
 }
 
-// ref :551-554  (float products, float adds left to right, one double add)
-__device__ __forceinline__ double point_to_plane(float nx, float ny, float nz, double d, const float4 &p) {
-    return nx * p.x + ny * p.y + nz * p.z + d;
-}
-
 // ------------------------------------------------------------------------------------------
 // k_fit_brows: FOUR waves per patch -- the latency flavour of k_fit_srows<64>.  With a handful of
 // frames in flight the run time of the fit stage is the chain of its largest patch (~5000 points:
@@ -1613,15 +1265,14 @@ __device__ __forceinline__ double point_to_plane(float nx, float ny, float nz, d
 // solve the same 3x3 problem; the lowest points are selected per wave and merged.
 // ------------------------------------------------------------------------------------------
 struct BRowShared {
-    long long mom[kWaves][10];
+    long long mom[kWaves][16];   // per wave: n, S1[3], lower and upper halves of S2[6] (Row<64>::reduce16_scatter)
     unsigned cand[kWaves][5][64];  // every lane's four smallest keys + the smallest it dropped, pooled lane by lane
     unsigned dropped[kWaves];
     int elig[kWaves];
     double single_sum;   // a patch of one chunk: wave 0's result
     unsigned single_T;
     unsigned cnt_g, cnt_ng;
-    long long mom2[kWaves][10];  // dual seed pass: the band between the two seed thresholds
-    long long mom_hi[kWaves][6], mom2_hi[kWaves][6];  // patches beyond 65535 points: upper halves of the second moments
+    long long mom2[kWaves][16];  // dual seed pass: the band between the two seed thresholds
     PlaneFit plane[2];           // R-VPF fit | R-GPF seed fit, solved side by side by different waves
     FitShared fs;  // for block_lpr, the exact fall-back of the lowest-point selection
 };
@@ -1633,16 +1284,16 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsi
     const int wv = wave_id(), ln = lane_id();
     unsigned k0 = INF, k1 = INF, k2 = INF, k3 = INF, dropped = INF;
     int elig = 0;
-    ChunkPts cp;
-    load_chunk<64>(cp, pts, n, (unsigned)wv);
+    ChunkZ cp;
+    load_chunk_z<64>(cp, pts, n, (unsigned)wv);
     for (unsigned c = (unsigned)wv; c < nchunk; c += kWaves) {
-        ChunkPts nx;  // the next chunk is in flight while this one is ranked (this is the first, cold touch of the patch)
-        load_chunk<64>(nx, pts, n, c + kWaves);
+        ChunkZ nx;  // the next chunk is in flight while this one is ranked (this is the first, cold touch of the patch)
+        load_chunk_z<64>(nx, pts, n, c + kWaves);
         const unsigned act = chunk_act(cp);
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
-            const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.lp.z[k] < cutoff);
-            unsigned x = e ? z_key(cp.lp.z[k]) : INF;
+            const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.z[k] < cutoff);
+            unsigned x = e ? z_key(cp.z[k]) : INF;
             ce(k0, x);
             ce(k1, x);
             ce(k2, x);
@@ -1727,36 +1378,29 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsi
 __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &Bt, int b_lo, int b_hi, unsigned by /* block index among the patch blocks */) {
     const int f = blockIdx.x;
     const PwppDevParams &P = Bt.P;
-    const int NB = P.num_bins + 2;
     const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
     const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
     if (cbeg + by >= cend) return;                    // workgroup-uniform
     const unsigned slot = cend - 1u - by;             // largest patches first
     const int wv = wave_id(), ln = lane_id();
-    const int bin = (int)Bt.cls_list[(size_t)f * P.num_bins + slot];
-    const unsigned n = Bt.bin_count[(size_t)f * NB + bin];
-    // (only when this kernel is the plan's last class does it see more than 65535 points: the second
-    // moments of such a patch outgrow int64 once they are added up across lanes, so their 32-bit halves
-    // are reduced separately -- exact, like everything else here)
-    const bool wide = n > 65535u;
+    const PatchCtx pc = patch_ctx(Bt, f, slot, true);
+    const int bin = pc.bin, zone = pc.zone;
+    const unsigned n = pc.n;  // (at most 2^19 - 1 points: 2047 per lane, see Moments; pwpp_launch_fit sends larger patches to k_fit_stream)
     const PwppFrameDesc fd = Bt.frames[f];
-    const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + off);
-    int *plist = Bt.plist + fd.sbase + off;
-    const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
+    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + pc.off);
+    int *plist = Bt.plist + fd.sbase + pc.off;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;
     const bool use_cutoff = zone == 0;
-    const float qscale = (float)(1 << P.fxp_shift);
+    const double scale = (double)(1 << P.fxp_shift);
     const unsigned nchunk = (n + 511u) / 512u;
 
     PlaneFit pl;
-    pl.nx = pl.ny = pl.nz = 0.0f;
-    pl.mean[0] = pl.mean[1] = pl.mean[2] = 0.0f;
-    pl.sv[0] = pl.sv[1] = pl.sv[2] = 0.0f;
-    pl.d = 0.0;
+    plane_clear(pl);
     double lpr = 0.0;
-    bool lpr_valid = false;
+    bool lpr_valid = false, z0_set = false;
+    float z0 = 0.0f;
+    FxpOrg org = fxp_org(pc.ox, pc.oy, 0.0f, scale, P.fxp_zr);
     int kind = (P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED;  // everything below is workgroup-uniform
     int it = 0;
     // Dual seed pass as in k_fit_w64 (an R-VPF round and the R-GPF seed stage pick their seeds from the
@@ -1793,6 +1437,11 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         if ((kind == ST_VPF || kind == ST_SEED) && !lpr_valid) {
             lpr = brow_lpr(sh, pts, n, nchunk, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
             lpr_valid = true;
+            if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative
+                z0 = fxp_z_origin(lpr);
+                z0_set = true;
+                org = fxp_org(pc.ox, pc.oy, z0, scale, P.fxp_zr);
+            }
             probe(2);
         }
         const bool dual_now = kind == ST_VPF;
@@ -1802,9 +1451,6 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         Moments m, m2;
         m.clear();
         m2.clear();
-        ChunkMoments cm;
-        cm.clear();
-        unsigned done = 0;
         ChunkPts cp;
         load_chunk<64>(cp, pts, n, (unsigned)wv);
         int w[kPPT];
@@ -1814,16 +1460,13 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
             load_chunk<64>(nx, pts, n, c + kWaves);
             int wnx[kPPT];
             if (last) load_chunk_idx<64>(wnx, pts, n, c + kWaves);
-            const unsigned gmask = lane_stage_accum(cp.lp, chunk_act(cp), kind, thr_seed, P.th_dist, pl, qscale, cm);
-            if (++done % kFlushChunks == 0u) {
-                cm.flush_into(m);
-                cm.clear();
-            }
+            const unsigned act = chunk_act(cp);
+            const unsigned gmask = lane_stage_accum(cp, act, kind, thr_seed, P.th_dist, pl, scale, org, m);
             if (dual_now) {  // the band [thr_seed, thr_band)
-                const unsigned rest = chunk_act(cp) & ~gmask;
+                const unsigned rest = act & ~gmask;
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k)
-                    if ((rest >> k & 1u) && (double)cp.lp.z[k] < thr_band) m2.add(cp.lp.x[k], cp.lp.y[k], cp.lp.z[k], qscale);
+                    if ((rest >> k & 1u) && (double)cp.z[k] < thr_band) m2.add(cp.x[k], cp.y[k], cp.z[k], scale, org);
             }
             if (last) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                 const unsigned ngm = cp.valid & ~gmask;
@@ -1842,7 +1485,7 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
                     if (gmask >> k & 1u)
                         plist[bg++] = w[k];
                     else if (ngm >> k & 1u)
-                        plist[n - 1u - (bn++)] = nonground_entry(w[k], cp.lp.x[k]);
+                        plist[n - 1u - (bn++)] = nonground_entry(w[k], cp.z[k]);
                 }
             }
             cp = nx;
@@ -1851,49 +1494,27 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
                 for (int k = 0; k < kPPT; ++k) w[k] = wnx[k];
             }
         }
-        cm.flush_into(m);
         probe(3);
-        {   // the wave's sums -> LDS -> totals of the patch (every thread)
-            auto wave_sums = [&](const Moments &mm, long long (*dst)[10], long long (*dst_hi)[6]) {
-                if (!wide) {  // reduce-scatter: each total is stored by the lane it ends up with
-                    const long long t[10] = {mm.n, mm.s1[0], mm.s1[1], mm.s1[2], mm.s2[0], mm.s2[1], mm.s2[2], mm.s2[3], mm.s2[4], mm.s2[5]};
-                    int slot;
-                    const long long mine = Row<64>::reduce10_scatter(t, slot);
-                    if (slot >= 0 && ln < 16) dst[wv][slot] = mine;
-                    return;
-                }
-                long long v[10];
-                v[0] = Row<64>::sum_i64(mm.n);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) v[1 + k] = Row<64>::sum_i64(mm.s1[k]);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) v[4 + k] = Row<64>::sum_i64(mm.s2[k] & 0xffffffffLL);  // lower halves here, upper halves below
-                if (ln < 10) {
-                    long long mine = v[0];
-#pragma unroll
-                    for (int k = 1; k < 10; ++k) mine = ln == k ? v[k] : mine;
-                    dst[wv][ln] = mine;
-                }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) v[k] = Row<64>::sum_i64(mm.s2[k] >> 32);
-                if (ln < 6) {
-                    long long mine = v[0];
-#pragma unroll
-                    for (int k = 1; k < 6; ++k) mine = ln == k ? v[k] : mine;
-                    dst_hi[wv][ln] = mine;
-                }
+        {   // the wave's sums -> LDS (reduce-scatter: each of the sixteen values is stored by the lane it ends up with)
+            auto wave_sums = [&](const Moments &mm, long long (*dst)[16]) {
+                long long v[16];
+                moments_to_16(mm, v);
+                int slot16;
+                const long long mine = Row<64>::reduce16_scatter(v, slot16);
+                if (ln < 16) dst[wv][slot16] = mine;
             };
-            wave_sums(m, sh.mom, sh.mom_hi);
-            if (dual_now) wave_sums(m2, sh.mom2, sh.mom2_hi);
+            wave_sums(m, sh.mom);
+            if (dual_now) wave_sums(m2, sh.mom2);
         }
         __syncthreads();
         const bool spec = dual_now && wv >= kWaves / 2;  // this wave solves the R-GPF seed fit
         long long tot[4];
         __int128 s2[6];
         long long cnt = 0;
-        if (!wide) {  // the usual case: everything fits int64 (<= 65535 points), the solve is entered a few hundred instructions earlier
+        {
+            long long t16[16];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) {
+            for (int k = 0; k < 16; ++k) {
                 long long a = 0, b = 0;  // a: below the smaller threshold, a + b: below the larger one
 #pragma unroll
                 for (int w2 = 0; w2 < kWaves; ++w2) {
@@ -1902,44 +1523,23 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
                 }
                 const long long t_vpf = dual_now ? (v_is_hi ? a + b : a) : a;
                 const long long t_seed = v_is_hi ? a : a + b;
-                const long long t = spec ? t_seed : t_vpf;
-                if (k < 4) tot[k] = t;
-                else s2[k - 4] = (__int128)t;
+                t16[k] = spec ? t_seed : t_vpf;
                 if (k == 0) {
                     cnt = t_vpf;
                     if (dual_now) stash_cnt = t_seed;
                 }
             }
-        } else {
 #pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                __int128 a = 0, b = 0;
+            for (int k = 0; k < 4; ++k) tot[k] = t16[k];
 #pragma unroll
-                for (int w2 = 0; w2 < kWaves; ++w2) {
-                    a += (__int128)sh.mom[w2][k];
-                    if (dual_now) b += (__int128)sh.mom2[w2][k];
-                    if (k >= 4) {
-                        a += (__int128)sh.mom_hi[w2][k >= 4 ? k - 4 : 0] << 32;
-                        if (dual_now) b += (__int128)sh.mom2_hi[w2][k >= 4 ? k - 4 : 0] << 32;
-                    }
-                }
-                const __int128 t_vpf = dual_now ? (v_is_hi ? a + b : a) : a;
-                const __int128 t_seed = v_is_hi ? a : a + b;
-                const __int128 t = spec ? t_seed : t_vpf;
-                if (k < 4) tot[k] = (long long)t;  // count and first moments: int64 at any size
-                else s2[k - 4] = t;
-                if (k == 0) {
-                    cnt = (long long)t_vpf;
-                    if (dual_now) stash_cnt = (long long)t_seed;
-                }
-            }
+            for (int k = 0; k < 6; ++k) s2[k] = join_halves(t16[4 + k], t16[10 + k]);
         }
         __syncthreads();
         probe(4);
         PlaneFit fitted = pl;
         if (tot[0] > 0) {  // empty: ref :49
             const long long s1[3] = {tot[1], tot[2], tot[3]};
-            plane_from_totals(tot[0], s1, s2, P.fxp_shift, Bt.debug, fitted);
+            plane_from_totals(tot[0], s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug, fitted);
         }
         if (dual_now) {
             if (ln == 0 && (wv == 0 || wv == kWaves / 2)) sh.plane[wv ? 1 : 0] = fitted;
@@ -1958,7 +1558,7 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
                 for (unsigned c = (unsigned)wv; c < nchunk; c += kWaves) {
                     ChunkPts cs2;
                     load_chunk<64>(cs2, pts, n, c);
-                    const unsigned hit = lane_strip(cs2.lp, chunk_act(cs2), true, pl, P.th_dist_v);
+                    const unsigned hit = lane_strip(cs2, chunk_act(cs2), true, pl, P.th_dist_v);
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k)
                         if (hit >> k & 1u) strip_point(pts, c * 512u + (unsigned)k * 64u + (unsigned)ln, it);
@@ -2002,30 +1602,28 @@ __global__ __launch_bounds__(kBlock, 2) void k_fit_brows(PwppBatch Bt, int b_lo,
 // ~300 patches, the chip 256 CUs).  Here only the patches above `b_mid` get four waves (k_fit_brows'
 // body); the small ones, which fit one chunk of one wave anyway, go four to a workgroup, one wave each
 // (k_fit_srows<64>'s body) -- ~110 workgroups per frame, every one alone on its CU, in ONE launch.
-__global__ __launch_bounds__(kBlock, 1) void k_fit_hybrid(PwppBatch Bt, int b_mid, unsigned nb_big) {
+__global__ __launch_bounds__(kBlock, 1) void k_fit_hybrid(PwppBatch Bt, int b_mid, int b_hi, unsigned nb_big) {
     __shared__ BRowShared sh;
     if (blockIdx.y < nb_big)
-        fit_brows_body(sh, Bt, b_mid, PWPP_NUM_BUCKETS, blockIdx.y);
+        fit_brows_body(sh, Bt, b_mid, b_hi, blockIdx.y);
     else
         fit_srows_body<64>(Bt, 0, b_mid, blockIdx.y - nb_big);
 }
 
-// the whole fit chain of one patch of any size by one workgroup (k_fit_stream; k_fit_brows for what exceeds its rows)
-__device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch &Bt, int f, int bin) {
+// the whole fit chain of one patch of any size by one workgroup (k_fit_stream: what exceeds the plan's classes)
+__device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch &Bt, int f, unsigned slot) {
     const PwppDevParams &P = Bt.P;
-    const int NB = P.num_bins + 2;
-    const unsigned n = Bt.bin_count[(size_t)f * NB + bin];
+    const PatchCtx pc = patch_ctx(Bt, f, slot, true);
+    const int bin = pc.bin, zone = pc.zone;
+    const unsigned n = pc.n;
     PwppPatchRec *rec = Bt.recs + (size_t)f * P.num_bins + bin;
     const PwppFrameDesc fd = Bt.frames[f];
-    const unsigned off = Bt.bin_off[(size_t)f * NB + bin];
-    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + off);
-    int *plist = Bt.plist + fd.sbase + off;
-    const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
+    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + pc.off);
+    int *plist = Bt.plist + fd.sbase + pc.off;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;  // ref :90
     const bool use_cutoff = zone == 0;
-    const float qscale = (float)(1 << P.fxp_shift);
-    const bool wide = n > 65536u;
+    const double scale = (double)(1 << P.fxp_shift);
 
     if (threadIdx.x == 0) {
         sh.normal[0] = sh.normal[1] = sh.normal[2] = 0.0f;
@@ -2038,31 +1636,43 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
     __syncthreads();
 
     double lpr = 0.0;
-    bool lpr_valid = false;
-    Moments m;
+    bool lpr_valid = false, z0_set = false;
+    float z0 = 0.0f;
+    FxpOrg org = fxp_org(pc.ox, pc.oy, 0.0f, scale, P.fxp_zr);
+    auto new_lpr = [&]() {
+        lpr = block_lpr(sh, pts, n, use_cutoff, cutoff, P.num_lpr);
+        lpr_valid = true;
+        if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative
+            z0 = fxp_z_origin(lpr);
+            z0_set = true;
+            org = fxp_org(pc.ox, pc.oy, z0, scale, P.fxp_zr);
+        }
+    };
+    MomentsWide m;
 
     // ---- R-VPF, ref :482-508
     if (P.enable_RVPF) {
         for (int it = 0; it < P.num_iter; ++it) {
-            if (!lpr_valid) {
-                lpr = (Bt.debug & 2) ? -1.8 : block_lpr(sh, pts, n, use_cutoff, cutoff, P.num_lpr);
-                lpr_valid = true;
-            }
+            if (!lpr_valid) new_lpr();
             const double thr = lpr + P.th_seeds_v;  // ref :108
             m.clear();
             for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-                const float4 p = load_pt4(pts, i);
-                if (!pt_stripped(p) && (double)p.z < thr) m.add(p.x, p.y, p.z, qscale);
+                const float z = pts.z[i];
+                if (!z_stripped(z) && (double)z < thr) {
+                    const float2 xy = pts.xy[i];
+                    m.add(xy.x, xy.y, z, scale, org);
+                }
             }
-            reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);
+            reduce_and_fit(sh, m, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug);
             const float nx = sh.normal[0], ny = sh.normal[1], nz = sh.normal[2];
             const double d = sh.d;
             if (zone == 0 && (double)nz < P.uprightness_thr) {  // ref :489
                 int any = 0;
                 for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-                    float4 p = load_pt4(pts, i);
-                    if (pt_stripped(p)) continue;
-                    const double dist = point_to_plane(nx, ny, nz, d, p);
+                    const float z = pts.z[i];
+                    if (z_stripped(z)) continue;
+                    const float2 xy = pts.xy[i];
+                    const double dist = plane_dist(nx, ny, nz, d, xy.x, xy.y, z);
                     if (fabs(dist) < P.th_dist_v) {  // ref :499 -> non_ground_dst
                         strip_point(pts, i, it);
                         any = 1;
@@ -2076,15 +1686,18 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
     }
 
     // ---- R-GPF, ref :513-543
-    if (!lpr_valid) lpr = (Bt.debug & 2) ? -1.8 : block_lpr(sh, pts, n, use_cutoff, cutoff, P.num_lpr);
+    if (!lpr_valid) new_lpr();
     {
         const double thr = lpr + P.th_seeds;  // ref :145
         m.clear();
         for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-            const float4 p = load_pt4(pts, i);
-            if (!pt_stripped(p) && (double)p.z < thr) m.add(p.x, p.y, p.z, qscale);
+            const float z = pts.z[i];
+            if (!z_stripped(z) && (double)z < thr) {
+                const float2 xy = pts.xy[i];
+                m.add(xy.x, xy.y, z, scale, org);
+            }
         }
-        reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);
+        reduce_and_fit(sh, m, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug);
     }
     const int ln = lane_id();
     for (int it = 0; it < P.num_iter; ++it) {
@@ -2095,20 +1708,23 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
         for (unsigned i0 = 0; i0 < n; i0 += kBlock) {
             const unsigned i = i0 + threadIdx.x;
             const bool in = i < n;
-            float4 p = make_float4(0, 0, 0, 0);
-            if (in) p = load_pt4(pts, i);
-            const bool stripped = in && pt_stripped(p);
-            const bool active = in && !stripped;
+            float z = 0.0f;
+            float2 xy = make_float2(0.0f, 0.0f);
+            if (in) {
+                z = pts.z[i];
+                xy = pts.xy[i];
+            }
+            const bool active = in && !z_stripped(z);
             bool g = false;
             if (active) {
-                const double dist = point_to_plane(nx, ny, nz, d, p);
+                const double dist = plane_dist(nx, ny, nz, d, xy.x, xy.y, z);
                 g = dist < P.th_dist;  // ref :525,529 (one-sided)
             }
-            if (g) m.add(p.x, p.y, p.z, qscale);
+            if (g) m.add(xy.x, xy.y, z, scale, org);
             if (last) {
                 // regionwise_ground_ from the front, regionwise_nonground_ (R-VPF strips included,
                 // ref :500,532) from the back of this patch's slot range
-                const int idx = (int)(__float_as_uint(p.w) & 0x7fffffffu);
+                const int idx = in ? pts.idx[i] : 0;
                 const unsigned long long mg = __ballot(g);
                 const unsigned long long mn = __ballot(in && !g);
                 const unsigned long long lt = (1ull << ln) - 1ull;
@@ -2122,10 +1738,10 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
                 if (g)
                     plist[bg + (unsigned)__popcll(mg & lt)] = idx;
                 else if (in)
-                    plist[n - 1u - (bn + (unsigned)__popcll(mn & lt))] = nonground_entry(idx, p.x);
+                    plist[n - 1u - (bn + (unsigned)__popcll(mn & lt))] = nonground_entry(idx, z);
             }
         }
-        reduce_and_fit(sh, m, wide, P.fxp_shift, Bt.debug);  // ref :537-542
+        reduce_and_fit(sh, m, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug);  // ref :537-542
     }
 
     if (threadIdx.x == 0) {
@@ -2149,11 +1765,11 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
 
 __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
     __shared__ FitShared sh;
-    const int f = blockIdx.x;  // frame = fast grid dimension, see k_fit_rows
+    const int f = blockIdx.x;  // frame = fast grid dimension, see fit_srows_body
     const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
     const unsigned slot = cs[b_lo] + blockIdx.y;
     if (slot >= cs[PWPP_NUM_BUCKETS]) return;
-    fit_stream_patch(sh, Bt, f, (int)Bt.cls_list[(size_t)f * Bt.P.num_bins + slot]);
+    fit_stream_patch(sh, Bt, f, slot);
 }
 
 }  // namespace
@@ -2161,7 +1777,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
 // launches of K4; ev (optional) = 7 events recorded around up to six launches
 #define PWPP_DEFAULT_FIT_PLAN "W16:1023,W64.2:65535"
 #define PWPP_LATENCY_FIT_PLAN "H64:1023"
-// `aux` (optional): a second stream + two events, for PWPP_FIT_CONCURRENT (classes of a plan side by side).
+// `aux` (optional): a second stream + two events, for the fit_concurrent option (classes of a plan side by side).
 extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
                                hipEvent_t aux_fork, hipEvent_t aux_join) {
     const PwppBatch &B = *batch;
@@ -2174,11 +1790,11 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
         return c < 1 ? 1u : c;
     };
     // The plan: which kernel handles which size range (ranges = runs of the quarter-octave size
-    // buckets k_czm_scan sorts the patches into).  "L16:127" = LDS-parked rows of 16 lanes for
-    // patches up to 127 points, "S16:1023" = streaming rows of 16 lanes up to 1023 points, ...;
-    // whatever is larger than the last entry goes to the workgroup-per-patch kernel.
-    // PWPP_FIT_PLAN overrides the default for tuning experiments.
-    const char *plan = getenv("PWPP_FIT_PLAN");
+    // buckets k_czm_scan sorts the patches into).  "S16:1023" = streaming rows of 16 lanes up to
+    // 1023 points, "W64.2:65535" = two big bins per wave, ...; whatever is larger than the last entry
+    // goes to the workgroup-per-patch kernel.  pwpp_set_option(h, "fit_plan", ...) overrides the default
+    // for tuning experiments (the environment variable PWPP_FIT_PLAN sets that option at pwpp_create).
+    const char *plan = B.fit_plan;
     // The right granularity depends on how much work there is to spread over 1024 SIMDs (measured with
     // tools/plan_by_frames.sh on KITTI frames; "frames" below = points of the batch / 125 000):
     //   <= 9    k_fit_hybrid: four waves per patch above 1023 points, one wave per smaller patch, one launch,
@@ -2193,7 +1809,7 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     //   more    64 small patches per wave; big bins two per wave          (fewest solve instances)
     // e.g. 1 frame: 0.128 ms instead of 0.174 with the second plan; 32 frames: 93 k frames/s instead of
     // 44 k with the last plan; 256 frames: 237 k instead of 208 k.
-    if (!plan) {
+    if (!plan || !*plan) {
         const double eff = (double)F * (double)B.max_n / 125000.0;
         plan = eff <= 9.0 ? PWPP_LATENCY_FIT_PLAN
              : eff <= 48.0 ? "S64:65535"
@@ -2204,71 +1820,62 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     }
     int k_lo = 0, slot = 0;
     unsigned n_lo = 1;
-    // The classes of a plan are independent of each other: PWPP_FIT_CONCURRENT=1 runs the later ones on
+    // The classes of a plan are independent of each other: the fit_concurrent option runs the later ones on
     // the aux stream beside the first (fork after K3, join before K5; +3.5 % on the 1024-frame batch;
     // off by default: the per-kernel times bench.py reports would lose their meaning).
-    const bool concurrent = aux != nullptr && !ev && getenv("PWPP_FIT_CONCURRENT") != nullptr;
+    const bool concurrent = aux != nullptr && !ev && B.fit_concurrent != 0;
     const bool fork = concurrent;
     if (fork) {  // every class only depends on K3
         (void)hipEventRecord(aux_fork, stream);
         (void)hipStreamWaitEvent(aux, aux_fork, 0);
     }
     const char *p = plan;
-    bool rest_done = false;
     while (*p && slot < 5) {
         char mode = p[0];
         int g = 0, pw = 0;
         unsigned upper = 0;
         if (sscanf(p + 1, "%d.%d:%u", &g, &pw, &upper) != 3) {
             pw = 0;
-            if (sscanf(p + 1, "%d:%u", &g, &upper) != 2) break;
+            if (sscanf(p + 1, "%d:%u", &g, &upper) != 2) return (int)hipErrorInvalidValue;
         }
-        if (mode == 'L' && upper > 8u * (unsigned)g - 1u) upper = 8u * (unsigned)g - 1u;  // 8 points per lane in LDS
-        if (upper > 65535u) upper = 65535u;  // int64 second moments hold up to 2^17 points; keep a margin
+        if (g != 8 && g != 16 && g != 32 && g != 64) return (int)hipErrorInvalidValue;
+        // A lane adds up at most 2047 points (Moments): G lanes per patch hold 2047 G points, four waves 2^19 - 1;
+        // rows of 16 lanes in k_fit_w64 keep their ten totals in int64, which also ends at 2047 points.
+        const unsigned lane_cap = mode == 'B' || mode == 'H' ? 524287u : (mode == 'W' && g == 16 ? 2047u : 2047u * (unsigned)g);
+        if (upper > lane_cap) upper = lane_cap;
+        if (upper > 65535u && mode != 'B' && mode != 'H') upper = 65535u;  // one wave per patch: keep the classes short
         const int k_hi = pwpp_size_bucket(upper + 1u);
         if (k_hi > k_lo) {
             if (ev) (void)hipEventRecord(ev[slot], stream);
             const hipStream_t ls = (concurrent && slot >= 1) ? aux : stream;  // later classes beside the first one
             const unsigned patches = cap(n_lo);
             const dim3 grid(F, (patches * (unsigned)g + kBlock - 1) / kBlock);
-            if (mode == 'L' && g == 16) hipLaunchKernelGGL(k_fit_rows<16>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-            else if (mode == 'L' && g == 32) hipLaunchKernelGGL(k_fit_rows<32>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-            else if (mode == 'L' && g == 64) hipLaunchKernelGGL(k_fit_rows<64>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-            else if (mode == 'S' && g == 8) hipLaunchKernelGGL(k_fit_srows<8>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            if (mode == 'S' && g == 8) hipLaunchKernelGGL(k_fit_srows<8>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'S' && g == 16) hipLaunchKernelGGL(k_fit_srows<16>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'S' && g == 32) hipLaunchKernelGGL(k_fit_srows<32>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'S' && g == 64) hipLaunchKernelGGL(k_fit_srows<64>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-            else if (mode == 'H') {  // "H64:<n>": up to n points a wave per patch, four waves above, everything in one launch
+            else if (mode == 'H') {  // "H64:<n>": up to n points a wave per patch, four waves above (up to 2^19 - 1 points), everything in one launch
+                const int k_top = pwpp_size_bucket(524288u);
                 const unsigned nb_big = cap(pwpp_bucket_floor(k_hi));
-                hipLaunchKernelGGL(k_fit_hybrid, dim3(F, nb_big + (patches + kWaves - 1) / kWaves), dim3(kBlock), 0, ls, B, k_hi, nb_big);
-                rest_done = true;
+                hipLaunchKernelGGL(k_fit_hybrid, dim3(F, nb_big + (patches + kWaves - 1) / kWaves), dim3(kBlock), 0, ls, B, k_hi, k_top, nb_big);
+                k_lo = k_top;
+                n_lo = 524288u;
+                ++slot;
+                while (*p && *p != ',') ++p;
+                if (*p == ',') ++p;
+                continue;
             }
-            else if (mode == 'B') {
-                // a B class that ends the ladder also takes the patches beyond it: one launch less on the latency path
-                const bool takes_rest = upper == 65535u;
-                hipLaunchKernelGGL(k_fit_brows, dim3(F, patches), dim3(kBlock), 0, ls, B, k_lo, takes_rest ? PWPP_NUM_BUCKETS : k_hi);
-                rest_done = takes_rest;
-            }
+            else if (mode == 'B') hipLaunchKernelGGL(k_fit_brows, dim3(F, patches), dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'W') {  // "W<lanes per patch>.<patches per wave>"
                 if (pw == 0) pw = 64;
                 const dim3 wgrid(F, (patches + (unsigned)pw * kWaves - 1) / ((unsigned)pw * kWaves));
                 if (g == 16 && pw == 64) hipLaunchKernelGGL((k_fit_w64<16, 64>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
                 else if (g == 16 && pw == 32) hipLaunchKernelGGL((k_fit_w64<16, 32>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
                 else if (g == 16 && pw == 16) hipLaunchKernelGGL((k_fit_w64<16, 16>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-                else if (g == 64 && pw == 32) hipLaunchKernelGGL((k_fit_w64<64, 32>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-                else if (g == 64 && pw == 16) hipLaunchKernelGGL((k_fit_w64<64, 16>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
                 else if (g == 64 && pw == 8) hipLaunchKernelGGL((k_fit_w64<64, 8>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
                 else if (g == 64 && pw == 4) hipLaunchKernelGGL((k_fit_w64<64, 4>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
                 else if (g == 64 && pw == 2) hipLaunchKernelGGL((k_fit_w64<64, 2>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
                 else return (int)hipErrorInvalidValue;
-            }
-            else if (mode == 'P') {
-                const int rounds = 2 * B.P.num_iter + 2;
-                for (int r = 0; r < rounds; ++r) {
-                    if (g == 64) hipLaunchKernelGGL(k_ph_rows<64>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-                    else hipLaunchKernelGGL(k_ph_rows<16>, dim3(F, (patches * 16u + kBlock - 1) / kBlock), dim3(kBlock), 0, ls, B, k_lo, k_hi);
-                    hipLaunchKernelGGL(k_ph_solve, dim3(F, (patches + kBlock - 1) / kBlock), dim3(kBlock), 0, ls, B, k_lo, k_hi);
-                }
             }
             else return (int)hipErrorInvalidValue;
             ++slot;
@@ -2281,14 +1888,19 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     for (; slot < 5; ++slot)
         if (ev) (void)hipEventRecord(ev[slot], stream);
     if (ev) (void)hipEventRecord(ev[5], stream);
-    if (rest_done) {
+    // whatever is larger than the plan's last class: a workgroup per patch (none can exist when the largest
+    // frame of the batch is smaller than that class's upper bound -- one launch less on the latency path)
+    const bool rest_possible = (unsigned)B.max_n >= n_lo;
+    if (!rest_possible) {
         // nothing left
     } else if (fork) {
         hipLaunchKernelGGL(k_fit_stream, dim3(F, cap(n_lo)), dim3(kBlock), 0, aux, B, k_lo);
-        (void)hipEventRecord(aux_join, aux);
-        (void)hipStreamWaitEvent(stream, aux_join, 0);
     } else {
         hipLaunchKernelGGL(k_fit_stream, dim3(F, cap(n_lo)), dim3(kBlock), 0, stream, B, k_lo);
+    }
+    if (fork) {
+        (void)hipEventRecord(aux_join, aux);
+        (void)hipStreamWaitEvent(stream, aux_join, 0);
     }
     if (ev) (void)hipEventRecord(ev[6], stream);
     return (int)hipGetLastError();

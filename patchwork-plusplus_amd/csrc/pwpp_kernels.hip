@@ -202,9 +202,13 @@ __device__ __forceinline__ void fill_zone_table(const PwppDevParams &P, float4 *
     }
 }
 
+// z as the bin-ordered plane holds it: a NaN of the cloud becomes THE quiet NaN 0x7fc00000, because the fit
+// kernels mark the points an R-VPF round removes with 0x7fc00000 | round (pwpp_fit.hip, strip_point).  A NaN z
+// never enters a seed or ground set either way (every test it takes part in is false).
+__device__ __forceinline__ float binned_z(float z) { return z != z ? __uint_as_float(0x7fc00000u) : z; }
+
 __device__ __forceinline__ unsigned czm_code(const PwppDevParams &P, const float4 *zt, float x, float y, float z, float inten,
-                                             bool has_intensity, double sensor_height, float rnr_z_guard, bool exact_only,
-                                             bool never_exact = false) {
+                                             bool has_intensity, double sensor_height, float rnr_z_guard, bool exact_only) {
     const unsigned B = (unsigned)P.num_bins;
     // Reflected Noise Removal, ref :385-396.  r is FLOAT there (:387), the rest double.
     // rnr_z_guard = float(-sensor_height - 0.8) + 1e-3: a float pre-test that can only say "no"
@@ -221,7 +225,6 @@ __device__ __forceinline__ unsigned czm_code(const PwppDevParams &P, const float
     if (z == FLT_MIN) return PWPP_CODE_DROP;  // ref :591 (tombstone value in the input itself)
     unsigned code = 0;
     if (!exact_only && bin_code_fast(P, zt, x, y, code)) return code;
-    if (never_exact) return code;  // timing ablation only (PWPP_DEBUG_FLAGS & 128)
     return bin_code_exact(P, x, y);
 }
 
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
         if (i < fd.n) {
             float x, y, z, w;
             load_point(fd, i, x, y, z, w);
-            const unsigned code = czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0, (Bt.debug & 128) != 0);
+            const unsigned code = czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0);
             codes[i] = (uint16_t)code;
             if (code == PWPP_CODE_DROP) ++dropped;
             pcode[j] = code;
@@ -304,22 +307,21 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt, int ti
     const float rnr_z_guard = (float)(-sensor_height - 0.8) + 1e-3f;
     constexpr int kPer = kOnePassPts / kBlock;
     unsigned pc[kPer];  // code | rank inside the workgroup << 16
-    PwppXyz pt[kPer];
+    float px[kPer], py[kPer], pz[kPer];
     unsigned dropped = 0;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const int i = first + j * kBlock + threadIdx.x;
         unsigned code = PWPP_CODE_DROP;
-        pt[j].x = pt[j].y = pt[j].z = 0.0f;
+        px[j] = py[j] = pz[j] = 0.0f;
         if (i < fd.n) {
             float x, y, z, w;
             load_point(fd, i, x, y, z, w);
-            code = (Bt.debug & 8192) ? (unsigned)((i >> 5) % 500)  // timing ablation only: no code computation
-                                     : czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0, (Bt.debug & 128) != 0);
+            code = czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0);
             if (code == PWPP_CODE_DROP) ++dropped;
-            pt[j].x = x;
-            pt[j].y = y;
-            pt[j].z = z;
+            px[j] = x;
+            py[j] = y;
+            pz[j] = binned_z(z);
         }
         unsigned pos;
         const unsigned old = wave_run_add(s_cnt, code, code != PWPP_CODE_DROP, pos);
@@ -334,7 +336,8 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt, int ti
     dropped = wave_sum_u32(dropped);
     if (lane_id() == 0 && dropped) atomicAdd((unsigned *)&Bt.results[f].n_dropped, dropped);
     __syncthreads();
-    PwppXyz *sorted_xyz = Bt.sorted_xyz + fd.sbase;
+    float *sorted_z = Bt.sorted_z + fd.sbase;
+    float2 *sorted_xy = Bt.sorted_xy + fd.sbase;
     int *sorted_idx = Bt.sorted_idx + fd.sbase;
     bool over = false;
 #pragma unroll
@@ -344,10 +347,9 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt, int ti
             const unsigned seg = s_seg[code], cap = s_seg[code + 1] - seg;
             const unsigned r = s_cnt[code] + (pc[j] >> 16);
             if (r < cap) {
-                if (!(Bt.debug & 4096)) {  // (timing ablation only: no stores)
-                    sorted_xyz[seg + r] = pt[j];
-                    sorted_idx[seg + r] = first + j * kBlock + (int)threadIdx.x;
-                }
+                sorted_z[seg + r] = pz[j];
+                sorted_xy[seg + r] = make_float2(px[j], py[j]);
+                sorted_idx[seg + r] = first + j * kBlock + (int)threadIdx.x;
             } else {
                 over = true;
             }
@@ -425,18 +427,6 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
             continue;
         }
         atomicAdd(&s_cnt[pwpp_size_bucket(n)], 1u);
-        {   // start of the fit chain (phase kernels): R-VPF for zone 0, else the R-GPF seeds
-            PwppFitState *st = Bt.fit + (size_t)f * B + b;
-            st->kind = (Bt.P.enable_RVPF != 0 && b < Bt.P.bin_base[1]) ? 0 /*ST_VPF*/ : 1 /*ST_SEED*/;
-            st->it = 0;
-            st->lpr_valid = 0;
-            st->need_strip = 0;
-            st->lpr = 0.0;
-            st->d = 0.0;
-            st->nx = st->ny = st->nz = 0.0f;
-            st->mean[0] = st->mean[1] = st->mean[2] = 0.0f;
-            st->sv[0] = st->sv[1] = st->sv[2] = 0.0f;
-        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -473,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_scatter(PwppBatch Bt) {
     const uint16_t *codes = Bt.codes + fd.base;
     constexpr int kPer = kPtsPerBlock / kBlock;
     unsigned code[kPer], rank[kPer];
-    PwppXyz pt[kPer];
+    float px[kPer], py[kPer], pz[kPer];
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const int i = first + j * kBlock + threadIdx.x;
@@ -482,9 +472,9 @@ __global__ __launch_bounds__(kBlock) void k_czm_scatter(PwppBatch Bt) {
             code[j] = codes[i];
             float x, y, z, w;
             load_point(fd, i, x, y, z, w);
-            pt[j].x = x;
-            pt[j].y = y;
-            pt[j].z = z;
+            px[j] = x;
+            py[j] = y;
+            pz[j] = binned_z(z);
             if (code[j] != PWPP_CODE_DROP) rank[j] = atomicAdd(&s_cnt[code[j]], 1u);
         }
     }
@@ -496,13 +486,15 @@ __global__ __launch_bounds__(kBlock) void k_czm_scatter(PwppBatch Bt) {
     }
     __syncthreads();
     const unsigned *off = Bt.bin_off + (size_t)f * NB;
-    PwppXyz *sorted_xyz = Bt.sorted_xyz + fd.sbase;
+    float *sorted_z = Bt.sorted_z + fd.sbase;
+    float2 *sorted_xy = Bt.sorted_xy + fd.sbase;
     int *sorted_idx = Bt.sorted_idx + fd.sbase;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         if (code[j] != PWPP_CODE_DROP) {
             const unsigned slot = off[code[j]] + s_base[code[j]] + rank[j];
-            sorted_xyz[slot] = pt[j];
+            sorted_z[slot] = pz[j];
+            sorted_xy[slot] = make_float2(px[j], py[j]);
             sorted_idx[slot] = first + j * kBlock + (int)threadIdx.x;
         }
     }

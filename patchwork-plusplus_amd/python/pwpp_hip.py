@@ -98,6 +98,9 @@ def load():
         L.pwpp_get_kernel_profile.argtypes = [vp, vp, vp]
         L.pwpp_reset_kernel_profile.argtypes = [vp]
         L.pwpp_get_fxp_shift.argtypes = [vp]
+        L.pwpp_get_fxp_origins.argtypes = [vp, vp, ci]
+        L.pwpp_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
+        L.pwpp_trim_workspace.argtypes = [vp]
         L.pwpp_get_one_pass_stats.argtypes = [vp, vp, vp]
         L.pwpp_set_output_order.argtypes = [vp, ci]
         L.pwpp_set_overlap.argtypes = [vp, ci]
@@ -326,6 +329,22 @@ class Handle:
 
     def fxp_shift(self):
         return self._L.pwpp_get_fxp_shift(self._h)
+
+    def fxp_origins(self):
+        """(B, 2) float32: the origin of every bin's fixed-point plane-fit sums."""
+        out = np.zeros((4096, 2), np.float32)
+        b = self._L.pwpp_get_fxp_origins(self._h, _vp(out), out.shape[0])
+        self._check(b)
+        return out[:b].copy()
+
+    def set_option(self, name, value):
+        """Tuning / test switches (pwpp_set_option): fit_plan, fit_concurrent, one_pass, one_pass_min_frames,
+        one_pass_scale, debug_flags.  None of them changes a result."""
+        self._check(self._L.pwpp_set_option(self._h, name.encode(), str(value).encode()))
+
+    def trim_workspace(self):
+        """Free the per-batch workspaces (results of the last call are gone afterwards)."""
+        self._check(self._L.pwpp_trim_workspace(self._h))
 
     def set_output_order(self, reference):
         """True: the points of a patch come out in the reference's order (z-sorted bins); False: scatter order."""

@@ -7,8 +7,9 @@ Outputs: tests/golden/kitti_00000k.bin.xz        -- the frames, byte-identical a
          tests/golden/kitti_golden.npz           -- what the REFERENCE's own patchworkpp.cpp
              (compiled unmodified against oracle/eigen_shim -> oracle/_ref/libpwpp_ref*.so)
              produces for them: ground masks, counts, centres, normals, adaptive state,
-             sha256 of the index lists in the reference's own output order; for both shim
-             flavours (eigen-f32 / fxp), fresh-state per frame and as one 6-frame sequence.
+             sha256 of the index lists in the reference's own output order; for the three shim
+             flavours (eigen-f32 / exact-f64 arbiter / f32 4-lane order), fresh-state per frame
+             and as one 6-frame sequence.
 
 The reference has no golden vectors of its own; these are outputs of the
 reference itself run here, which is what pins oracle/pwpp_oracle.cpp.
@@ -54,7 +55,7 @@ def main():
         frames.append(np.frombuffer(raw, np.float32).reshape(-1, 4))
     out = {"md5": np.array([hashlib.md5(f.tobytes()).hexdigest() for f in frames]),
            "n_points": np.array([f.shape[0] for f in frames], np.int64)}
-    for arith, name in ((ol.ARITH_EIGEN_F32, "f32"), (ol.ARITH_FXP, "fxp")):
+    for arith, name in ((ol.ARITH_EIGEN_F32, "f32"), (ol.ARITH_EXACT_F64, "exact"), (ol.ARITH_F32_PACKET4, "pk4")):
         lib = ol.reference(arith)
         assert lib is not None, "build oracle/_ref first (make -C oracle ref)"
         for k, f in enumerate(frames):

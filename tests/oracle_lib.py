@@ -17,8 +17,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
-ARITH_EIGEN_F32 = 0
-ARITH_FXP = 1
+ARITH_EIGEN_F32 = 0   # float sums in storage order (plainest reading of Eigen)
+ARITH_FXP = 1         # the product's fixed-point contract (restatement only)
+ARITH_EXACT_F64 = 2   # reference-neutral arbiter: double sums of the unquantised floats
+ARITH_F32_PACKET4 = 3  # float sums, four partial sums (a SIMD reduction order)
+REF_LIBS = {ARITH_EIGEN_F32: "libpwpp_ref.so", ARITH_EXACT_F64: "libpwpp_ref_exact.so",
+            ARITH_F32_PACKET4: "libpwpp_ref_pk4.so"}
 
 DEC_NAMES = {1: "not_upright", 2: "far_ground", 3: "heading", 4: "ground", 5: "tgr_reject", 6: "tgr_revert"}
 
@@ -91,8 +95,13 @@ class _Lib:
             L.pwo_ext_get_records.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
             L.pwo_ext_set_state.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
             L.pwo_ext_jacobi.argtypes = [ctypes.c_void_p] * 3
-            L.pwo_ext_fxp_shift.argtypes = [ctypes.c_double]
-            L.pwo_ext_quantise.argtypes = [ctypes.c_float, ctypes.c_int]
+            L.pwo_ext_fxp_geometry.argtypes = [ctypes.c_void_p] * 5
+            L.pwo_ext_quantise.restype = ctypes.c_longlong
+            L.pwo_ext_quantise.argtypes = [ctypes.c_float, ctypes.c_double, ctypes.c_int]
+            L.pwo_ext_quantise_z.restype = ctypes.c_longlong
+            L.pwo_ext_quantise_z.argtypes = [ctypes.c_float, ctypes.c_double, ctypes.c_int]
+            L.pwo_ext_z_origin.restype = ctypes.c_double
+            L.pwo_ext_z_origin.argtypes = [ctypes.c_double]
 
     def default_params(self):
         p = Params()
@@ -117,12 +126,13 @@ def restatement():
 
 
 def reference(arith=ARITH_EIGEN_F32):
-    """oracle/_ref/libpwpp_ref[_fxp].so or None when it has not been built."""
+    """oracle/_ref/libpwpp_ref*.so of that flavour, or None when it does not exist (not built, or the
+    flavour is the fixed-point contract, which only the restatement implements)."""
     key = ("r", arith)
     if key not in _cache:
-        name = "libpwpp_ref_fxp.so" if arith == ARITH_FXP else "libpwpp_ref.so"
-        path = os.path.join(ORACLE_DIR, "_ref", name)
-        _cache[key] = _Lib(path, False) if os.path.exists(path) else None
+        name = REF_LIBS.get(arith)
+        path = os.path.join(ORACLE_DIR, "_ref", name) if name else None
+        _cache[key] = _Lib(path, False) if path and os.path.exists(path) else None
     return _cache[key]
 
 
@@ -159,6 +169,14 @@ class Estimator:
             self.close()
         except Exception:
             pass
+
+    def fxp_geometry(self):
+        """(shift, z half-range in metres, per-bin origin x, per-bin origin y) of the fixed-point contract."""
+        nb = sum(self.params.num_rings_each_zone[k] * self.params.num_sectors_each_zone[k] for k in range(4))
+        sh, zr = ctypes.c_int(), ctypes.c_double()
+        ox, oy = np.zeros(nb, np.float32), np.zeros(nb, np.float32)
+        self._l.lib.pwo_ext_fxp_geometry(self._h, ctypes.byref(sh), ctypes.byref(zr), _vp(ox), _vp(oy))
+        return sh.value, zr.value, ox, oy
 
     def set_state(self, sensor_height, elevation_thr, flatness_thr):
         e = np.ascontiguousarray(elevation_thr, np.float64)

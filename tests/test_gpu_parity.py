@@ -174,9 +174,7 @@ PARAM_VARIANTS = [
 ]
 
 
-@pytest.mark.parametrize("variant", PARAM_VARIANTS, ids=lambda v: ",".join("%s=%s" % kv for kv in v.items()))
-def test_parameter_variants(kitti, oracle, variant, monkeypatch):
-    p = pwpp_hip.default_params()
+def apply_variant(p, variant):
     for k, v in variant.items():
         if k == "sectors":
             for i in range(4):
@@ -192,6 +190,12 @@ def test_parameter_variants(kitti, oracle, variant, monkeypatch):
                 p.flatness_thr[i] = v[i]
         else:
             setattr(p, k, v)
+    return p
+
+
+@pytest.mark.parametrize("variant", PARAM_VARIANTS, ids=lambda v: ",".join("%s=%s" % kv for kv in v.items()))
+def test_parameter_variants(kitti, oracle, variant):
+    p = apply_variant(pwpp_hip.default_params(), variant)
     h = pwpp_hip.Handle(p)
     est = ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP)
     syn = pwpp_synth.add_edge_cases(pwpp_synth.make_cloud(5, beams=48, azimuth_steps=1500), 5)
@@ -203,11 +207,8 @@ def test_parameter_variants(kitti, oracle, variant, monkeypatch):
     frames = [kitti[1], syn, kitti[3], kitti[0], kitti[5], syn]
     refs = [ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(pts) for pts in frames]
     hb = pwpp_hip.Handle(p)
-    for plan in (None, "W16:1023,W64.2:65535", "W16.16:1023,S64:65535"):
-        if plan is None:
-            monkeypatch.delenv("PWPP_FIT_PLAN", raising=False)
-        else:
-            monkeypatch.setenv("PWPP_FIT_PLAN", plan)
+    for plan in ("", "W16:1023,W64.2:65535", "W16.16:1023,S64:65535"):
+        hb.set_option("fit_plan", plan)
         hb.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
         for i, pts in enumerate(frames):
             assert_frame_equal(hb, i, refs[i], pts.shape[0])
@@ -366,15 +367,15 @@ def test_points_on_bin_boundaries(oracle):
     assert_frame_equal(h, 0, ref, cloud.shape[0], state_index=0)
 
 
-@pytest.mark.parametrize("plan", ["L16:127,L32:255,L64:511,S64:65535", "S8:63,S16:255,S32:1023,S64:4095", "S8:65535", "S64:65535",
-                                  "W16:65535", "W16:255,P16:2047,P64:65535", "P16:65535", "S16:100",
-                                  "W16.16:1023,W64.2:65535", "W16.32:511,W64.4:65535", "S64:255,B64:65535", "B64:65535", "H64:511", "H64:63"])
-def test_every_fit_kernel_variant(kitti, oracle, plan, monkeypatch):
-    """All fit kernels (LDS-parked rows, streaming rows of every width, 64-patch waves, the phase
-    kernels with one-lane-per-patch solves, the workgroup kernel for whatever exceeds the plan) produce the same bit-exact result: the integer plane-fit sums do
-    not depend on how many lanes share a patch."""
-    monkeypatch.setenv("PWPP_FIT_PLAN", plan)
+@pytest.mark.parametrize("plan", ["S8:63,S16:255,S32:1023,S64:4095", "S8:65535", "S64:65535", "W16:65535", "S16:100",
+                                  "W16.16:1023,W64.2:65535", "W16.32:511,W64.4:65535", "W16:255,W64.8:65535", "S64:255,B64:65535",
+                                  "B64:65535", "H64:511", "H64:63"])
+def test_every_fit_kernel_variant(kitti, oracle, plan):
+    """All fit kernels (streaming rows of every width, 16 / 32 / 64 small patches per wave, 2 / 4 / 8 big bins per
+    wave, four waves per patch, the workgroup kernel for whatever exceeds the plan) produce the same bit-exact
+    result: the integer plane-fit sums do not depend on how many lanes share a patch."""
     h = pwpp_hip.Handle()
+    h.set_option("fit_plan", plan)
     syn = pwpp_synth.add_edge_cases(pwpp_synth.make_cloud(8), 8)
     h.estimate_ground_batch([kitti[0], syn, kitti[5]], mode=pwpp_hip.MODE_FRESH)
     for k, pts in enumerate((kitti[0], syn, kitti[5])):
@@ -481,7 +482,7 @@ def test_c_abi_demo_program(kitti, golden, tmp_path):
     assert abs(float(m.group(5)) - golden["f32/seq/0/state"][0]) < 1e-4
 
 
-def test_one_pass_binning_and_its_overflow_fallback(kitti, oracle, monkeypatch):
+def test_one_pass_binning_and_its_overflow_fallback(kitti, oracle):
     """Batches of independent frames bin in one pass into fixed bin segments (k_czm_bin_scatter).
     (1) the default capacities hold KITTI frames: the one-pass path is taken and nothing is redone;
     (2) with absurdly small segments every frame overflows: the batch is redone on the exact
@@ -513,8 +514,8 @@ def test_one_pass_binning_and_its_overflow_fallback(kitti, oracle, monkeypatch):
         assert_frame_equal(h, i, refs[i % 6], pts.shape[0])
     assert h.one_pass_stats() == (2, 1)
     # (2)
-    monkeypatch.setenv("PWPP_ONE_PASS_SCALE", "0.05")
     h2 = pwpp_hip.Handle()
+    h2.set_option("one_pass_scale", 0.05)
     h2.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
     for i, pts in enumerate(frames):
         assert_frame_equal(h2, i, refs[i % 6], pts.shape[0])
@@ -617,25 +618,25 @@ def test_reference_output_order(kitti, oracle):
 
 
 @pytest.mark.parametrize("flags", ["16384", "32768"])
-def test_lowest_point_selection_fallbacks(kitti, oracle, flags, monkeypatch):
+def test_lowest_point_selection_fallbacks(kitti, oracle, flags):
     """The one-pass selection of the num_lpr lowest points falls back to a gather pass (a lane held
     more than four of them) and, if that overflows, to an exact extraction by distinct values (streamed
     rows) or a radix select (four-waves-per-patch kernel).  The fall-backs are rare on real clouds, so
-    PWPP_DEBUG_FLAGS 16384 / 32768 force them for every patch: the results must not change."""
-    monkeypatch.setenv("PWPP_DEBUG_FLAGS", flags)
+    the debug_flags option (16384 / 32768) forces them for every patch: the results must not change."""
     frames = [kitti[0], kitti[4], kitti[2], kitti[1], kitti[5], kitti[3]]
     refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(p) for p in frames]
     h = pwpp_hip.Handle()
+    h.set_option("debug_flags", flags)
     for plan in ("W16:1023,W64.2:65535", "S16:255,S64:65535", "B64:65535", "H64:511"):
-        monkeypatch.setenv("PWPP_FIT_PLAN", plan)
+        h.set_option("fit_plan", plan)
         h.estimate_ground_batch(frames[:5] if plan[0] in "BH" else frames, mode=pwpp_hip.MODE_FRESH)
         for i in range(5):
             assert_frame_equal(h, i, refs[i], frames[i].shape[0])
 
 
-def test_size_extremes(oracle, monkeypatch):
+def test_size_extremes(oracle):
     """The largest frame the C-ABI accepts (4 194 304 points: bins far beyond 65 535 points go to the
-    workgroup kernel) and a batch of 60 tiny frames around one of 2 M points (the one-pass capacities
+    workgroup kernel with its 128-bit lane sums) and a batch of 60 tiny frames around one of 2 M points (the one-pass capacities
     follow the largest frame); bit-exact against the oracle."""
     rng = np.random.default_rng(3)
     base = pwpp_synth.make_cloud(5, beams=64, azimuth_steps=2000)
@@ -645,11 +646,10 @@ def test_size_extremes(oracle, monkeypatch):
     h.estimate_ground_batch([big], mode=pwpp_hip.MODE_FRESH)
     big_ref = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(big)
     assert_frame_equal(h, 0, big_ref, big.shape[0])
-    for plan in ("H64:1023", "B64:65535"):  # the four-waves-per-patch body on bins of ~10^5 points: split second moments
-        monkeypatch.setenv("PWPP_FIT_PLAN", plan)
+    for plan in ("H64:1023", "B64:65535"):  # the four-waves-per-patch body on bins of ~10^5 points
+        h.set_option("fit_plan", plan)
         h.estimate_ground_batch([big], mode=pwpp_hip.MODE_FRESH)
         assert_frame_equal(h, 0, big_ref, big.shape[0])
-    monkeypatch.delenv("PWPP_FIT_PLAN")
     tiny = [base[rng.choice(base.shape[0], 800, replace=False)] for _ in range(60)]
     mix = tiny[:30] + [big[:2000000]] + tiny[30:]
     h2 = pwpp_hip.Handle()

@@ -11,7 +11,8 @@ import pytest
 import oracle_lib as ol
 from conftest import ground_mask
 
-FLAVOURS = [(ol.ARITH_EIGEN_F32, "f32"), (ol.ARITH_FXP, "fxp")]
+# flavours the reference build exists in (oracle/Makefile); the fixed-point contract is the restatement's alone
+FLAVOURS = [(ol.ARITH_EIGEN_F32, "f32"), (ol.ARITH_EXACT_F64, "exact"), (ol.ARITH_F32_PACKET4, "pk4")]
 
 
 def sha(a):
@@ -56,20 +57,38 @@ def test_survey_anchor_counts(golden):
                (69315, 54654, 254), (68068, 55856, 250)]
     for k, a in enumerate(anchors):
         assert tuple(golden["f32/fresh/%d/counts" % k]) == a
-        assert tuple(golden["fxp/fresh/%d/counts" % k]) == a
+        assert tuple(golden["exact/fresh/%d/counts" % k]) == a
     seq = [72665, 71848, 71263, 70535, 69095, 67614]
     assert [int(golden["f32/seq/%d/counts" % k][0]) for k in range(6)] == seq
 
 
-def test_fxp_flavour_same_index_sets_as_eigen_f32_flavour(golden):
-    """The fixed-point plane-fit arithmetic changes no decision on the reference's own data,
-    and moves plane normals by far less than the 1e-4 tolerance of BASELINE.json."""
+def test_float_flavours_agree_with_the_exact_arbiter_on_kitti(golden):
+    """On the reference's own data the summation arithmetic changes no decision: the two float flavours of
+    the reference build and its exact-f64 flavour give the same ground masks, normals within 1e-4."""
     for mode in ("fresh", "seq"):
         for k in range(6):
-            a, b = "f32/%s/%d/" % (mode, k), "fxp/%s/%d/" % (mode, k)
-            assert np.array_equal(golden[a + "ground_mask"], golden[b + "ground_mask"])
-            assert np.abs(golden[a + "normals"] - golden[b + "normals"]).max() < 1e-4
-            assert np.abs(golden[a + "centers"] - golden[b + "centers"]).max() < 1e-4
+            for name in ("f32", "pk4"):
+                a, b = "%s/%s/%d/" % (name, mode, k), "exact/%s/%d/" % (mode, k)
+                assert np.array_equal(golden[a + "ground_mask"], golden[b + "ground_mask"])
+                assert np.abs(golden[a + "normals"] - golden[b + "normals"]).max() < 1e-4
+                assert np.abs(golden[a + "centers"] - golden[b + "centers"]).max() < 1e-4
+
+
+def test_fixed_point_contract_vs_the_exact_arbiter_on_kitti(oracle_built, kitti, golden):
+    """The product's arithmetic contract (restatement, fxp flavour) against the reference build in exact
+    arithmetic (golden): identical ground masks, centres within 1e-6, normals within 3e-5 -- closer to exact
+    arithmetic than the reference's own float sums (test above / tests/test_arith_flavours.py)."""
+    lib = oracle_built.restatement()
+    for mode in ("fresh", "seq"):
+        est = ol.Estimator(lib, arith=ol.ARITH_FXP)
+        for k, pts in enumerate(kitti):
+            res = est.run(pts) if mode == "seq" else ol.Estimator(lib, arith=ol.ARITH_FXP).run(pts)
+            key = "exact/%s/%d/" % (mode, k)
+            assert np.array_equal(np.packbits(ground_mask(res.ground_idx, pts.shape[0])), golden[key + "ground_mask"])
+            assert np.abs(res.centers - golden[key + "centers"]).max() < 1e-6
+            assert np.abs(res.normals - golden[key + "normals"]).max() < 3e-5
+            state = np.concatenate([[res.sensor_height], res.elevation_thr, res.flatness_thr])
+            assert np.abs(state - golden[key + "state"]).max() < 1e-6
 
 
 @pytest.mark.parametrize("arith,name", FLAVOURS)
@@ -143,11 +162,26 @@ def test_jacobi_is_an_eigen_decomposition(oracle_built):
     assert np.array_equal(u, np.eye(3, dtype=np.float32)) and not sv.any()
 
 
-def test_fxp_quantiser(oracle_built):
-    L = oracle_built.restatement().lib
-    assert L.pwo_ext_fxp_shift(80.0) == 16 and L.pwo_ext_fxp_shift(120.0) == 16
-    assert L.pwo_ext_fxp_shift(200.0) == 15 and L.pwo_ext_fxp_shift(5.0) == 20
-    q = lambda v: L.pwo_ext_quantise(ctypes.c_float(v), 16)
-    assert q(1.0) == 65536 and q(-1.0) == -65536 and q(0.0) == 0
-    assert q(1.5 / 65536) == 2 and q(2.5 / 65536) == 2 and q(0.5 / 65536) == 0  # ties to even
-    assert q(1e30) == 8388607 and q(-1e30) == -8388607 and q(float("nan")) == 0
+def test_fxp_contract_primitives(oracle_built):
+    """Shift, origins and quantisers of the fixed-point contract."""
+    lib = oracle_built.restatement()
+    L = lib.lib
+    sh, zr, ox, oy = ol.Estimator(lib, arith=ol.ARITH_FXP).fxp_geometry()
+    assert sh == 21 and zr == 32.0 and len(ox) == 504  # default CZM: every bin within 32 m of its origin
+    assert (np.abs(ox * 8 - np.rint(ox * 8)) == 0).all() and (np.abs(oy * 8 - np.rint(oy * 8)) == 0).all()
+    p = lib.default_params()
+    p.max_range = 500.0
+    assert ol.Estimator(lib, p, arith=ol.ARITH_FXP).fxp_geometry()[0] == 20  # bigger bins, coarser grid
+    for k in range(4):
+        p.num_sectors_each_zone[k] = 1
+    sh1, zr1, ox1, oy1 = ol.Estimator(lib, p, arith=ol.ARITH_FXP).fxp_geometry()
+    assert sh1 == 17 and not ox1.any() and not oy1.any()  # one sector per ring: the sensor is the origin
+    q = lambda v, o: L.pwo_ext_quantise(ctypes.c_float(v), o, 21)
+    assert q(1.0, 0.0) == 1 << 21 and q(-1.0, 0.0) == -(1 << 21) and q(10.125, 10.125) == 0
+    assert q(1.5 / (1 << 21), 0.0) == 2 and q(2.5 / (1 << 21), 0.0) == 2 and q(0.5 / (1 << 21), 0.0) == 0  # ties to even
+    assert q(30.0, 12.5) == int(17.5 * (1 << 21))
+    qz = lambda v, z0: L.pwo_ext_quantise_z(ctypes.c_float(v), z0, 21)
+    assert qz(-1.75, -1.75) == 0 and qz(1e30, -1.75) == 1 << 26 and qz(-1e30, -1.75) == -(1 << 26)
+    assert qz(float("inf"), 0.0) == 1 << 26 and qz(float("-inf"), 0.0) == -(1 << 26)
+    assert L.pwo_ext_z_origin(-1.73) == -1.75 and L.pwo_ext_z_origin(float("nan")) == 0.0
+    assert L.pwo_ext_z_origin(float("inf")) == 0.0 and L.pwo_ext_z_origin(1e9) == 4096.0

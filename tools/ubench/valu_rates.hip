@@ -79,6 +79,27 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, int iters, flo
             asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
                          "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (OP == 15) {  // v_rndne_f64
+            asm volatile("v_rndne_f64 %0, %0\n v_rndne_f64 %1, %1\n v_rndne_f64 %2, %2\n v_rndne_f64 %3, %3\n"
+                         "v_rndne_f64 %4, %4\n v_rndne_f64 %5, %5\n v_rndne_f64 %6, %6\n v_rndne_f64 %7, %7\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
+        } else if (OP == 16) {  // v_cvt_i32_f64
+            asm volatile("v_cvt_i32_f64 %0, %8\n v_cvt_i32_f64 %1, %9\n v_cvt_i32_f64 %2, %10\n v_cvt_i32_f64 %3, %11\n"
+                         "v_cvt_i32_f64 %4, %12\n v_cvt_i32_f64 %5, %13\n v_cvt_i32_f64 %6, %14\n v_cvt_i32_f64 %7, %15\n"
+                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7)
+                         : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(d4), "v"(d5), "v"(d6), "v"(d7));
+        } else if (OP == 17) {  // v_max_f64
+            asm volatile("v_max_f64 %0, %0, %1\n v_max_f64 %1, %1, %2\n v_max_f64 %2, %2, %3\n v_max_f64 %3, %3, %4\n"
+                         "v_max_f64 %4, %4, %5\n v_max_f64 %5, %5, %6\n v_max_f64 %6, %6, %7\n v_max_f64 %7, %7, %0\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
+        } else if (OP == 18) {  // v_lshl_add_u64 (64-bit integer add)
+            asm volatile("v_lshl_add_u64 %0, %0, 0, %1\n v_lshl_add_u64 %1, %1, 0, %2\n v_lshl_add_u64 %2, %2, 0, %3\n v_lshl_add_u64 %3, %3, 0, %0\n"
+                         "v_lshl_add_u64 %0, %0, 0, %2\n v_lshl_add_u64 %1, %1, 0, %3\n v_lshl_add_u64 %2, %2, 0, %0\n v_lshl_add_u64 %3, %3, 0, %1\n"
+                         : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
+        } else if (OP == 19) {  // v_mul_lo_u32
+            asm volatile("v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %1, %1, %2\n v_mul_lo_u32 %2, %2, %3\n v_mul_lo_u32 %3, %3, %4\n"
+                         "v_mul_lo_u32 %4, %4, %5\n v_mul_lo_u32 %5, %5, %6\n v_mul_lo_u32 %6, %6, %7\n v_mul_lo_u32 %7, %7, %0\n"
+                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -124,6 +145,11 @@ int main() {
     run<10>("v_mov_b32 dpp", 8, d_out);
     run<12>("v_pk_mul_f32", 8, d_out);
     run<14>("v_rcp_f32", 8, d_out);
+    run<15>("v_rndne_f64", 8, d_out);
+    run<16>("v_cvt_i32_f64", 8, d_out);
+    run<17>("v_max_f64", 8, d_out);
+    run<18>("v_lshl_add_u64", 8, d_out);
+    run<19>("v_mul_lo_u32", 8, d_out);
     run<13>("cmp+saveexec+add+or (x2)", 2, d_out);
     return 0;
 }
