@@ -352,7 +352,7 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     for (int f = 0; f < frames; ++f) {
         PwppFrameDesc &d = h->descs[(size_t)f];
         d.sbase = one_pass ? (int64_t)f * h->slots_per_frame : base;
-        base += d.n;
+        base += ((int64_t)d.n + 3 * (int64_t)NB + 3) & ~(int64_t)3;  // compact layout: every bin starts at a multiple of four slots (k_czm_scan)
     }
     // the descriptors on the device are reused when nothing changed (a caller cycling through the same
     // device buffers, a replayed batch): one host-to-device copy less in front of the first kernel
@@ -722,7 +722,8 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     // bin-ordered buffers hold frames x slots_per_frame records instead of one per point.  Used when
     // the memory is there; any overflow is caught when the batch lands and the batch is redone exactly.
     bool one_pass = false;
-    size_t bin_slots = tp;
+    const size_t compact_slots = tp + (size_t)frames * (size_t)(3 * NB + 4);  // bins padded to multiples of four slots
+    size_t bin_slots = compact_slots;
     {
         const bool env_off = h->no_one_pass;
         const int min_frames = h->one_pass_min_frames;
@@ -738,7 +739,7 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
             size_t free_b = 0, total_b = 0;
             const size_t per_slot = 3 * sizeof(float) + 2 * sizeof(int32_t);  // z, {x, y}, cloud index, plist
             const size_t held = (h->d_sorted_z.cap + h->d_sorted_idx.cap + h->d_plist.cap) * sizeof(int32_t) + h->d_sorted_xy.cap * sizeof(float2);
-            const bool have = h->d_sorted_z.cap >= want + 16 && h->d_sorted_xy.cap >= want + 16 && h->d_sorted_idx.cap >= want && h->d_plist.cap >= want;  // already allocated
+            const bool have = h->d_sorted_z.cap >= want + 1024 && h->d_sorted_xy.cap >= want + 1024 && h->d_sorted_idx.cap >= want && h->d_plist.cap >= want;  // already allocated
             if (have || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (want + want / 8 + 64) * per_slot * 21 / 20 <= free_b + held &&
                          want < ((size_t)1 << 40))) {
                 one_pass = true;
@@ -751,14 +752,14 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     if ((rc = h->h_frames.ensure((size_t)frames))) return rc;
     if ((rc = h->h_base.ensure((size_t)frames + 1))) return rc;
     if ((rc = h->d_codes.ensure(tp))) return rc;
-    // (slack: load_chunk reads record 0 of a patch beyond its end)
-    if (one_pass && (h->d_sorted_z.ensure(bin_slots + 16) || h->d_sorted_xy.ensure(bin_slots + 16) || h->d_sorted_idx.ensure(bin_slots) || h->d_plist.ensure(bin_slots))) {
+    // (slack: the fit kernels fetch whole chunks, up to 512 points beyond a patch's end)
+    if (one_pass && (h->d_sorted_z.ensure(bin_slots + 1024) || h->d_sorted_xy.ensure(bin_slots + 1024) || h->d_sorted_idx.ensure(bin_slots) || h->d_plist.ensure(bin_slots))) {
         one_pass = false;  // the big allocation failed after all (fragmentation): compact layout, two-pass binning
-        bin_slots = tp;
+        bin_slots = compact_slots;
         (void)hipGetLastError();
     }
-    if ((rc = h->d_sorted_z.ensure(bin_slots + 16))) return rc;
-    if ((rc = h->d_sorted_xy.ensure(bin_slots + 16))) return rc;
+    if ((rc = h->d_sorted_z.ensure(bin_slots + 1024))) return rc;
+    if ((rc = h->d_sorted_xy.ensure(bin_slots + 1024))) return rc;
     if ((rc = h->d_sorted_idx.ensure(bin_slots))) return rc;
     if ((rc = h->d_plist.ensure(bin_slots))) return rc;
     if ((rc = h->d_out.ensure(tp))) return rc;

@@ -274,9 +274,17 @@ __device__ __forceinline__ int nonground_entry(int idx, float z) {
     return z_stripped(z) ? (idx | (int)((__float_as_uint(z) & 0xffu) << 24)) : idx;
 }
 
-// One chunk = 8 points per lane of a row.  The loads are unconditional (record 0 of the patch stands in
-// beyond the end; the buffers carry a few records of slack): the compiler can then keep a whole chunk in
-// flight behind the arithmetic of the previous one and wait with a counted s_waitcnt.
+// One chunk = 8 points per lane of a row of G lanes.  Which lane sees which point is free (the sums are exact
+// integers, the lists are written in scatter order anyway), so the mapping follows the loads:
+//   G = 64 (big bins: every lane busy)  slot k of lane j = point c * 512 + (k / 4) * 256 + 4 j + (k % 4): a lane
+//          fetches FOUR CONSECUTIVE POINTS per load (a patch starts at a multiple of four slots, k_czm_scan /
+//          cap_off) -- two 16-byte loads for z, four for {x, y}, two for the cloud indices instead of 8 + 8 + 8;
+//   G < 64 (small patches)              slot k of lane j = point c * 8G + k * G + j: a patch of n points fills
+//          ceil(n / G) slots of every lane, and the slots above are skipped wave-wide (with four consecutive
+//          points per lane a 20-point patch would keep 5 lanes busy for 4 slots: k_fit_w64<16,64> 0.84 -> 1.19 ms).
+// The loads are unconditional (the first points of the patch stand in beyond its end -- NOT whatever follows in
+// memory: a one-pass segment is mostly unwritten space, and fetching it cost k_fit_w64<16,64> 9 %): the compiler can
+// keep a whole chunk in flight behind the arithmetic of the previous one and wait with a counted s_waitcnt.
 struct ChunkZ {  // what the lowest-point pass needs
     float z[kPPT];
     unsigned valid;
@@ -286,29 +294,72 @@ struct ChunkPts {
     unsigned valid;
 };
 template <int G>
-__device__ __forceinline__ void load_chunk_z(ChunkZ &cp, const PatchRef &pr, unsigned n, unsigned c) {
-    cp.valid = 0;
-    const unsigned j = (unsigned)lane_id() & (G - 1);
+__device__ __forceinline__ unsigned chunk_point(unsigned c, int k, unsigned j) {
+    if constexpr (G == 64) return c * 512u + (unsigned)(k >> 2) * 256u + 4u * j + (unsigned)(k & 3);
+    return c * (8u * G) + (unsigned)k * G + j;
+}
+template <int G>
+__device__ __forceinline__ unsigned chunk_valid(unsigned n, unsigned c, unsigned j) {
+    unsigned valid = 0;
 #pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-        const unsigned i = c * (8u * G) + (unsigned)k * G + j;
-        cp.z[k] = pr.z[i < n ? i : 0u];
-        if (i < n) cp.valid |= 1u << k;
+    for (int k = 0; k < kPPT; ++k)
+        if (chunk_point<G>(c, k, j) < n) valid |= 1u << k;
+    return valid;
+}
+template <int G>
+__device__ __forceinline__ void load_chunk_z(ChunkZ &cp, const PatchRef &pr, unsigned n, unsigned c) {
+    const unsigned j = (unsigned)lane_id() & (G - 1);
+    cp.valid = chunk_valid<G>(n, c, j);
+    if constexpr (G == 64) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned p0 = chunk_point<G>(c, 4 * q, j);
+            const float4 v = *reinterpret_cast<const float4 *>(pr.z + (p0 < n ? p0 : 0u));
+            cp.z[4 * q] = v.x;
+            cp.z[4 * q + 1] = v.y;
+            cp.z[4 * q + 2] = v.z;
+            cp.z[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            const unsigned i = chunk_point<G>(c, k, j);
+            cp.z[k] = pr.z[i < n ? i : 0u];
+        }
     }
 }
 template <int G>
 __device__ __forceinline__ void load_chunk(ChunkPts &cp, const PatchRef &pr, unsigned n, unsigned c) {
-    cp.valid = 0;
     const unsigned j = (unsigned)lane_id() & (G - 1);
+    cp.valid = chunk_valid<G>(n, c, j);
+    if constexpr (G == 64) {
 #pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-        const unsigned i = c * (8u * G) + (unsigned)k * G + j;
-        const unsigned ii = i < n ? i : 0u;
-        const float2 v = pr.xy[ii];
-        cp.z[k] = pr.z[ii];
-        cp.x[k] = v.x;
-        cp.y[k] = v.y;
-        if (i < n) cp.valid |= 1u << k;
+        for (int q = 0; q < 2; ++q) {
+            const unsigned p1 = chunk_point<G>(c, 4 * q, j), p0 = p1 < n ? p1 : 0u;
+            const float4 v = *reinterpret_cast<const float4 *>(pr.z + p0);
+            const float4 a = *reinterpret_cast<const float4 *>(pr.xy + p0), b = *reinterpret_cast<const float4 *>(pr.xy + p0 + 2);
+            cp.z[4 * q] = v.x;
+            cp.z[4 * q + 1] = v.y;
+            cp.z[4 * q + 2] = v.z;
+            cp.z[4 * q + 3] = v.w;
+            cp.x[4 * q] = a.x;
+            cp.y[4 * q] = a.y;
+            cp.x[4 * q + 1] = a.z;
+            cp.y[4 * q + 1] = a.w;
+            cp.x[4 * q + 2] = b.x;
+            cp.y[4 * q + 2] = b.y;
+            cp.x[4 * q + 3] = b.z;
+            cp.y[4 * q + 3] = b.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            const unsigned i1 = chunk_point<G>(c, k, j), i = i1 < n ? i1 : 0u;
+            const float2 v = pr.xy[i];
+            cp.z[k] = pr.z[i];
+            cp.x[k] = v.x;
+            cp.y[k] = v.y;
+        }
     }
 }
 // the points of a chunk that are still in the patch's working set (not removed by R-VPF); evaluated
@@ -325,10 +376,23 @@ __device__ __forceinline__ unsigned chunk_act(const C &cp) {
 template <int G>
 __device__ __forceinline__ void load_chunk_idx(int w[kPPT], const PatchRef &pr, unsigned n, unsigned c) {
     const unsigned j = (unsigned)lane_id() & (G - 1);
+    if constexpr (G == 64) {
 #pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-        const unsigned i = c * (8u * G) + (unsigned)k * G + j;
-        w[k] = i < n ? pr.idx[i] : 0;
+        for (int q = 0; q < 2; ++q) {
+            const unsigned p0 = chunk_point<G>(c, 4 * q, j);
+            int4 v = make_int4(0, 0, 0, 0);
+            if (p0 < n) v = *reinterpret_cast<const int4 *>(pr.idx + p0);  // (a patch's slots are padded to a multiple of four)
+            w[4 * q] = v.x;
+            w[4 * q + 1] = v.y;
+            w[4 * q + 2] = v.z;
+            w[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            const unsigned i = chunk_point<G>(c, k, j);
+            w[k] = i < n ? pr.idx[i] : 0;
+        }
     }
 }
 
@@ -685,8 +749,7 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k) {
                         if (hit >> k & 1u) {
-                            const unsigned i = c * (8u * G) + (unsigned)k * G + (unsigned)j;
-                            strip_point(pts, i, it);
+                            strip_point(pts, chunk_point<G>(c, k, (unsigned)j), it);
                         }
                     }
                     any = any || hit != 0;
@@ -731,6 +794,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo,
 // wave gets a similar mix and the rows of a points phase have similar trip counts.
 // Waves are independent: no workgroup barrier anywhere.
 // ------------------------------------------------------------------------------------------
+template <bool DUAL>
 struct W64Patch {
     unsigned off, n;
     int kind;        // stage of the coming points phase; ST_DONE = nothing to do
@@ -739,13 +803,13 @@ struct W64Patch {
     int vpf_round;   // the R-VPF round of the strip in progress (reference-order output)
     double d;
     double thr_seed;
-    double thr_band;  // dual seed pass: upper end of the band [thr_seed, thr_band)
     float ox, oy, z0; // origin of the patch's fixed-point sums
     float pad_;
+    double thr_band[DUAL ? 1 : 0];  // dual seed pass: upper end of the band [thr_seed, thr_band)
 };
 template <int PW, bool DUAL, int MW>
 struct W64Shared {
-    W64Patch p[PW];
+    W64Patch<DUAL> p[PW];
     long long mom[PW][MW];
     long long mom2[DUAL ? PW : 1][MW];  // dual seed pass: moments of the band; then the stashed seed totals of the R-GPF stage
     double lpr[PW];
@@ -763,10 +827,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 // Moments per patch in LDS: rows of 16 lanes only see patches below 2048 points, whose ten totals fit
 // int64; 64-lane rows leave sixteen values (second moments as 32-bit halves, Row<64>::reduce16_scatter).
 template <int G, int PW>
-__global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, int b_lo, int b_hi) {
+__global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, int b_lo, int b_hi) {
+    // ONE WAVE PER WORKGROUP: the waves never talk to each other, and a workgroup of four only starts when a CU has
+    // room for all four at once -- with waves of very different lifetimes the slots of the early finishers stood empty
+    // (27 % of the wave slots of k_fit_w64<64,2>, profiles/).
     constexpr int MW = G == 64 ? 16 : 10;
-    __shared__ W64Shared<PW, G == 64, MW> sh_all[kWaves];
-    W64Shared<PW, G == 64, MW> &sh = sh_all[wave_id()];
+    __shared__ W64Shared<PW, G == 64, MW> sh;
     constexpr int R = 64 / G;      // patches per points-phase sub-batch
     constexpr int NSB = PW / R;    // sub-batches
     static_assert(PW % R == 0 && PW <= 64, "patches per wave");
@@ -776,7 +842,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
     const unsigned cbeg = cs[b_lo], cend = cs[b_hi];
     const unsigned npatch = cend - cbeg;
     const unsigned nwaves = (npatch + PW - 1u) / PW;
-    const unsigned w = blockIdx.y * kWaves + (unsigned)wave_id();
+    const unsigned w = blockIdx.y;
     if (w >= nwaves) return;  // wave-uniform
     const int ln = lane_id();
     const int j = ln & (G - 1), row = ln / G;
@@ -863,7 +929,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
             sh.p[ln].z0 = z0;
             const double th = (kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds;
             sh.p[ln].thr_seed = lpr + (dual_now ? (v_is_hi ? P.th_seeds : P.th_seeds_v) : th);
-            sh.p[ln].thr_band = lpr + (v_is_hi ? P.th_seeds_v : P.th_seeds);
+            if constexpr (DUAL) sh.p[ln].thr_band[0] = lpr + (v_is_hi ? P.th_seeds_v : P.th_seeds);
         }
         wave_lds_sync();
 
@@ -872,7 +938,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
         for (int sb = 0; sb < NSB; ++sb) {
             if (((act_mask >> (R * sb)) & ((1ull << R) - 1ull)) == 0ull) continue;
             const int q = R * sb + row;
-            const W64Patch pp = sh.p[q];
+            const W64Patch<DUAL> pp = sh.p[q];
             const bool on = pp.kind != ST_DONE;
             const bool last = on && (pp.flags & 1);
             PlaneFit qpl;
@@ -897,11 +963,13 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
                 if (__any(last)) load_chunk_idx<G>(w, pts, last ? qn : 0u, c);
                 const unsigned act = chunk_act(cp);
                 const unsigned gmask = lane_stage_accum(cp, act, pp.kind, pp.thr_seed, P.th_dist, qpl, scale, org, m);
-                if (DUAL && __any(dual)) {  // the band [thr_seed, thr_band) of a dual seed pass
-                    const unsigned rest = dual ? (act & ~gmask) : 0u;
+                if constexpr (DUAL) {
+                    if (__any(dual)) {  // the band [thr_seed, thr_band) of a dual seed pass
+                        const unsigned rest = dual ? (act & ~gmask) : 0u;
 #pragma unroll
-                    for (int k = 0; k < kPPT; ++k)
-                        if ((rest >> k & 1u) && (double)cp.z[k] < pp.thr_band) m2.add(cp.x[k], cp.y[k], cp.z[k], scale, org);
+                        for (int k = 0; k < kPPT; ++k)
+                            if ((rest >> k & 1u) && (double)cp.z[k] < pp.thr_band[0]) m2.add(cp.x[k], cp.y[k], cp.z[k], scale, org);
+                    }
                 }
                 if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                     const unsigned gm = last ? gmask : 0u;
@@ -992,7 +1060,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
                 if (((v_mask >> (R * sb)) & ((1ull << R) - 1ull)) == 0ull) continue;
                 const int q = R * sb + row;
                 const bool vrow = (v_mask >> q) & 1ull;
-                const W64Patch pp = sh.p[q];
+                const W64Patch<DUAL> pp = sh.p[q];
                 PlaneFit qpl;
                 qpl.nx = pp.nx;
                 qpl.ny = pp.ny;
@@ -1009,8 +1077,7 @@ __global__ __launch_bounds__(kBlock, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch B
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k) {
                         if (hit >> k & 1u) {
-                            const unsigned i = c * (8u * G) + (unsigned)k * G + (unsigned)j;
-                            strip_point(pts, i, pp.vpf_round);
+                            strip_point(pts, chunk_point<G>(c, k, (unsigned)j), pp.vpf_round);
                         }
                     }
                     any = any || hit != 0;
@@ -1561,7 +1628,7 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
                     const unsigned hit = lane_strip(cs2, chunk_act(cs2), true, pl, P.th_dist_v);
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k)
-                        if (hit >> k & 1u) strip_point(pts, c * 512u + (unsigned)k * 64u + (unsigned)ln, it);
+                        if (hit >> k & 1u) strip_point(pts, chunk_point<64>(c, k, (unsigned)ln), it);
                     any |= hit != 0u;
                 }
                 if (__syncthreads_or(any)) {  // the working set changed (and the marks are visible)
@@ -1868,13 +1935,13 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
             else if (mode == 'B') hipLaunchKernelGGL(k_fit_brows, dim3(F, patches), dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'W') {  // "W<lanes per patch>.<patches per wave>"
                 if (pw == 0) pw = 64;
-                const dim3 wgrid(F, (patches + (unsigned)pw * kWaves - 1) / ((unsigned)pw * kWaves));
-                if (g == 16 && pw == 64) hipLaunchKernelGGL((k_fit_w64<16, 64>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-                else if (g == 16 && pw == 32) hipLaunchKernelGGL((k_fit_w64<16, 32>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-                else if (g == 16 && pw == 16) hipLaunchKernelGGL((k_fit_w64<16, 16>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-                else if (g == 64 && pw == 8) hipLaunchKernelGGL((k_fit_w64<64, 8>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-                else if (g == 64 && pw == 4) hipLaunchKernelGGL((k_fit_w64<64, 4>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-                else if (g == 64 && pw == 2) hipLaunchKernelGGL((k_fit_w64<64, 2>), wgrid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+                const dim3 wgrid(F, (patches + (unsigned)pw - 1) / (unsigned)pw), wblock(64);  // one wave per workgroup
+                if (g == 16 && pw == 64) hipLaunchKernelGGL((k_fit_w64<16, 64>), wgrid, wblock, 0, ls, B, k_lo, k_hi);
+                else if (g == 16 && pw == 32) hipLaunchKernelGGL((k_fit_w64<16, 32>), wgrid, wblock, 0, ls, B, k_lo, k_hi);
+                else if (g == 16 && pw == 16) hipLaunchKernelGGL((k_fit_w64<16, 16>), wgrid, wblock, 0, ls, B, k_lo, k_hi);
+                else if (g == 64 && pw == 8) hipLaunchKernelGGL((k_fit_w64<64, 8>), wgrid, wblock, 0, ls, B, k_lo, k_hi);
+                else if (g == 64 && pw == 4) hipLaunchKernelGGL((k_fit_w64<64, 4>), wgrid, wblock, 0, ls, B, k_lo, k_hi);
+                else if (g == 64 && pw == 2) hipLaunchKernelGGL((k_fit_w64<64, 2>), wgrid, wblock, 0, ls, B, k_lo, k_hi);
                 else return (int)hipErrorInvalidValue;
             }
             else return (int)hipErrorInvalidValue;

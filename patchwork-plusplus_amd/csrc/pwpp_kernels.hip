@@ -385,8 +385,8 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
             const int b = b0 + j;
-            local[j] = b < NB ? cnt[b] : 0u;
-            sum += local[j];
+            local[j] = b < NB ? ((cnt[b] + 3u) & ~3u) : 0u;  // every bin starts at a multiple of four slots: the fit kernels
+            sum += local[j];                                 // fetch four points (16 / 32 bytes) per lane and load
         }
         // inclusive scan inside the wave (DPP), then the four wave totals through LDS: one barrier
         // instead of the sixteen of a Hillis-Steele scan over 256 partials (a single frame waits for this)
