@@ -79,14 +79,17 @@ def cpu_baseline(src, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1024, help="frames per batch per GPU")
     ap.add_argument("--workload", default="kitti", choices=["kitti", "dense"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-events", action="store_true")
-    ap.add_argument("--overlap", action="store_true",
-                    help="opt-in: pwpp_set_overlap (two frame ranges on two streams); the per-kernel events then come from a separate single-stream pass")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="single-stream schedule (pwpp_set_overlap(0)); default is the library's default: batches of 128+ frames "
+                         "as two frame ranges on two streams")
+    ap.add_argument("--overlap", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="steps of the separate single-stream pass that measures per-kernel times")
     ap.add_argument("--skip-latency", action="store_true")
     args = ap.parse_args()
 
@@ -142,13 +145,12 @@ def main():
         by_src.setdefault(which[i], set()).add(tuple(int(v) for v in counts[i, :3]))
     assert os.environ.get("PWPP_BENCH_NO_SELFCHECK") or all(len(v) == 1 for v in by_src.values()), "replayed frames disagree: %r" % by_src
 
-    if args.overlap:
-        h.set_overlap(True)
-        for _ in range(2):
-            step()
-    elif not args.no_profile_events:
-        h.set_profiling(True)
-        h.reset_kernel_profile()
+    # The timed region runs the library's default schedule (overlap mode for batches of 128+ frames) with no
+    # profiling events in it; the per-kernel times and the roofline line come from a SEPARATE single-stream pass
+    # after the timed region (HIP events around every launch would serialise the two frame ranges).
+    h.set_overlap(not args.no_overlap)
+    for _ in range(2):
+        step()
     pwpp_dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -158,10 +160,10 @@ def main():
     pwpp_dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed, total_frames = pwpp_dist.aggregate(elapsed, F * args.steps, dev)  # MAX time, SUM frames over ranks
-    if args.overlap and not args.no_profile_events:  # kernel times of the single-stream schedule, outside the timed region
+    if not args.no_profile_events:  # kernel times of the single-stream schedule, outside the timed region
         h.set_profiling(True)
         h.reset_kernel_profile()
-        for _ in range(3):
+        for _ in range(max(args.profile_steps, 1)):
             step()
     prof = h.kernel_profile() if not args.no_profile_events else {}
     h.set_profiling(False)
@@ -192,7 +194,8 @@ def main():
                                    % (F, F, offs[-1] * 16 / 1e9) if args.workload == "kitti" else
                                    "configs[4]: %d dense synthetic 128-beam ~500k-pt frames per GPU, 36-sector CZM" % F,
                        "frames_per_gpu": F, "points_per_frame": int(np.mean(ns)), "parallelism": "frames sharded, dp%d" % world,
-                       "schedule": "overlap: two frame ranges on two streams (kernel_ms / roofline from a separate single-stream pass)" if args.overlap else "one stream"},
+                       "schedule": ("one stream" if args.no_overlap or F < 128 else "library default: two frame ranges on two streams")
+                                   + "; kernel_ms / roofline.kernel_ms: separate single-stream pass of %d steps outside the timed region" % args.profile_steps},
             "latency": {"workload": "configs[1]: single frame, device-resident, fresh state", "ms_per_frame_wall": 1000.0 * lat,
                         "gpu_us": lat_gpu_us},
         }

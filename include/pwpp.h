@@ -106,7 +106,8 @@ typedef enum pwpp_decision {
 } pwpp_decision;
 
 enum { PWPP_LAYOUT_ROW_MAJOR = 0, /* (n, cols) C-order: np.fromfile(..).reshape(-1,4), python/examples/demo_visualize.py:10-14 */
-       PWPP_LAYOUT_COL_MAJOR = 1  /* Eigen::MatrixXf default storage: cols planes of n floats (patchworkpp.h:152) */ };
+       PWPP_LAYOUT_COL_MAJOR = 1, /* Eigen::MatrixXf default storage: cols planes of n floats (patchworkpp.h:152) */
+       PWPP_LAYOUT_FIELDS = 2     /* (internal to pwpp_estimate_ground_fields*: float32 fields at byte offsets of a record) */ };
 enum { PWPP_MEM_HOST = 0,         /* pageable or pinned host memory; the call returns when the results are ready */
        PWPP_MEM_DEVICE = 1,       /* device memory; asynchronous */
        PWPP_MEM_HOST_PINNED = 2   /* page-locked host memory (pwpp_host_alloc / hipHostMalloc) that stays valid and
@@ -143,6 +144,15 @@ int pwpp_estimate_ground(pwpp_handle *h, const float *points, int n, int cols, i
  * PWPP_MEM_DEVICE or PWPP_MEM_HOST_PINNED: call pwpp_synchronize() before reading results. */
 int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const int32_t *n, int frames,
                                int cols, int layout, int mem, int mode);
+/* The ROS 2 wrapper's input (reference ros/src/GroundSegmentationServer.cpp:72-75, ros/src/Utils.hpp:158-172
+ * PointCloud2ToEigenMat: x, y, z read through one float32 iterator per field): `data` = msg->data, n = height * width,
+ * point_step and the byte offsets of the fields as the message declares them (4-byte aligned; off_intensity < 0 when
+ * there is none -- RNR is then skipped as for an N x 3 matrix, patchworkpp.cpp:379-382).  The fields are read where
+ * they lie: no repacked copy on the host.  pwpp_estimate_ground_fields = one frame on stream 0 from host memory, like
+ * pwpp_estimate_ground; the _batch form takes `mem` and `mode` like pwpp_estimate_ground_batch. */
+int pwpp_estimate_ground_fields(pwpp_handle *h, const void *data, int n, int point_step, int off_x, int off_y, int off_z, int off_intensity);
+int pwpp_estimate_ground_fields_batch(pwpp_handle *h, const void *const *data, const int32_t *n, int frames, int point_step,
+                                      int off_x, int off_y, int off_z, int off_intensity, int mem, int mode);
 int pwpp_synchronize(pwpp_handle *h);
 int pwpp_set_num_streams(pwpp_handle *h, int streams); /* (re)creates `streams` fresh stream states */
 
@@ -179,8 +189,11 @@ double pwpp_get_time_us(pwpp_handle *h);
 /* state after the last call; PWPP_MODE_FRESH: `index` is the frame, PWPP_MODE_STREAMS: the stream */
 int pwpp_get_state(pwpp_handle *h, int index, pwpp_state *out);
 int pwpp_get_history(pwpp_handle *h, int index, int which /*0 elevation, 1 flatness*/, int ring, double *out, int capacity);
-/* overwrite the scalars of a stream state (histories are cleared) */
+/* overwrite the scalars of a stream state; its histories are cleared (elevation_len / flatness_len of `in` are ignored) */
 int pwpp_set_state(pwpp_handle *h, int stream, const pwpp_state *in);
+/* ... and put a history back: after pwpp_set_state + eight pwpp_set_history calls with what pwpp_get_state /
+ * pwpp_get_history returned, a stream continues exactly where the checkpointed one stood. */
+int pwpp_set_history(pwpp_handle *h, int stream, int which /*0 elevation, 1 flatness*/, int ring, const double *values, int count);
 
 /* ---- ingest ----------------------------------------------------------------- */
 /* Page-locked host memory: frames handed over in such buffers are DMA'd straight to the device
@@ -198,7 +211,8 @@ int pwpp_get_all_indices(pwpp_handle *h, int32_t *out, int64_t *frame_base, int3
 typedef struct pwpp_device_view {
     const int32_t *indices;      /* all frames: [frame_base[f] .. +n_ground) ground, then nonground */
     const int64_t *frame_base;   /* frames+1 prefix sums of n (host pointer, pinned)                */
-    const int32_t *counts;       /* frames x 8 int32 (host pointer, pinned): n_ground, n_nonground, n_patches, n_rnr, n_out_of_range, n_dropped, 0, 0 */
+    const int32_t *counts;       /* frames x 8 int32 (host pointer, pinned): n_ground, n_nonground, n_patches, n_rnr, n_out_of_range, n_dropped,
+                                    history fill (library bookkeeping), 0 */
     int32_t frames;
     int32_t pad_;
 } pwpp_device_view;
@@ -225,10 +239,11 @@ int pwpp_get_fxp_origins(pwpp_handle *h, float *out_xy, int capacity_bins);
 enum { PWPP_ORDER_SCATTER = 0, PWPP_ORDER_REFERENCE = 1 };
 int pwpp_set_output_order(pwpp_handle *h, int order);
 
-/* Overlap mode (off by default): batches of 128 frames or more are processed as two frame ranges with
- * their own launches on the handle's two streams, so that the memory-bound stages of one range (binning,
- * index lists) run under the VALU-bound plane fits of the other.  Same results; per-kernel profiling
- * (pwpp_set_profiling) and PWPP_ORDER_REFERENCE fall back to the single-stream schedule. */
+/* Overlap mode (ON by default): batches of 128 frames or more are processed as two frame ranges with
+ * their own launches on the handle's two streams, so that the stages of one range fill the wave slots the
+ * other leaves empty (binning and index lists are bound by memory, the plane fits by their dependent chains).
+ * Same results; per-kernel profiling (pwpp_set_profiling) and PWPP_ORDER_REFERENCE use the single-stream
+ * schedule.  pwpp_set_overlap(h, 0) / PWPP_OVERLAP=0 select that schedule for everything. */
 int pwpp_set_overlap(pwpp_handle *h, int on);
 /* one-pass binning (fixed bin segments; DESIGN.md 3, K1'): batches launched that way and how many of
  * them had to be redone on the exact two-pass path because a bin outgrew its segment.  Finishes the
@@ -245,6 +260,7 @@ int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone);
  *   "one_pass"            "0": always the two-pass binning
  *   "one_pass_min_frames" smallest batch that takes the one-pass binning (default 5)
  *   "one_pass_scale"      segment size of a bin in multiples of its even share of a frame (default 4)
+ *   "overlap_ranges"      frame ranges of the overlap mode (default 2; more were slower: 3.49 ms vs 2.98 ms with 4)
  *   "debug_flags"         4: timing probes of the fit chain; 16: exact binning arithmetic only;
  *                         16384 / 32768: force the fall-back paths of the lowest-point selection
  * Returns PWPP_E_ARG for an unknown name or a value out of range. */

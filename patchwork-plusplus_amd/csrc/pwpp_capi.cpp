@@ -7,6 +7,7 @@
 // point fails with PWPP_E_NODEVICE / PWPP_E_HIP.
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -104,7 +105,8 @@ struct pwpp_handle {
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;  // second stream for the latency plan (few frames)
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
-    bool overlap = false;  // pwpp_set_overlap: big batches as two frame ranges on the two streams
+    bool overlap = true;   // pwpp_set_overlap: big batches as frame ranges on the two streams (default on)
+    int overlap_ranges = 2;
     // tuning / test options (pwpp_set_option; the PWPP_* environment variables are read ONCE, in pwpp_create)
     int debug_flags = 0;
     std::string fit_plan;
@@ -166,6 +168,7 @@ struct pwpp_handle {
     // adaptive state: streams (long history slabs) and per-frame fresh outputs (short slabs)
     int num_streams = 0;
     int stream_hist_cap = 0, fresh_hist_cap = 0;
+    int max_pushes_per_frame = 0;  // bins of the widest ring of interest: what one frame can add to a history
     DevBuf<PwppStateScalar> d_st_stream, d_st_fresh;
     DevBuf<double> d_hist_stream, d_hist_fresh;
     // one-pass batches of stateful streams: the state of the streams before the batch, so that a redo after an
@@ -306,6 +309,20 @@ void fill_default_state(const pwpp_handle *h, PwppStateScalar &s) {
 
 int finish_pending(pwpp_handle *h);
 
+// the stream history slabs [stream][2][4][cap] re-laid out for a larger cap (contents kept)
+int grow_stream_histories(pwpp_handle *h, int new_cap) {
+    const size_t rows = (size_t)h->num_streams * 8;
+    DevBuf<double> bigger;
+    int rc = bigger.ensure(rows * (size_t)new_cap);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy2D(bigger.p, (size_t)new_cap * sizeof(double), h->d_hist_stream.p, (size_t)h->stream_hist_cap * sizeof(double),
+                       (size_t)h->stream_hist_cap * sizeof(double), rows, hipMemcpyDeviceToDevice));
+    h->d_hist_stream.release();
+    h->d_hist_stream = bigger;
+    h->stream_hist_cap = new_cap;
+    return PWPP_OK;
+}
+
 // Segment sizes of the one-pass path for batches whose largest frame has max_n points: a bin of zone
 // k gets `scale` times its even share of such a frame (KITTI: the fullest bin holds 2.0x the even
 // share of its zone; default scale 4), the two pseudo-bins (RNR hits, out-of-range points) a whole
@@ -420,7 +437,7 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     // other (tools/two_handles.py: +7.5 % on 1024 KITTI frames).  Every per-frame array is indexed by the
     // frame, so the halves are two views of the same workspaces with shifted base pointers.
     if (h->overlap && !h->profiling && !ordered && frames >= 128 && bt.debug == 0) {
-        auto half = [&](int f0, int nf) {
+        auto range = [&](int f0, int nf) {
             PwppBatch v = bt;
             const int B = h->dp.num_bins;
             v.frames += f0;
@@ -440,13 +457,27 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
             v.results_host += f0;
             return v;
         };
-        const int fa = ((frames / 2) + 7) / 8 * 8;  // whole groups of eight frames (K1' deals frames to the 8 XCDs)
-        const PwppBatch a = half(0, fa), b = half(fa, frames - fa);
+        // R frame ranges of whole groups of eight frames (K1' deals frames to the 8 XCDs), alternating between the
+        // two streams: while one range is in its plane fits the other one is binning or writing its lists.  Every
+        // range is launched with the fit plan of the WHOLE batch (the machine is shared, not split).
+        int R = h->overlap_ranges < 2 ? 2 : h->overlap_ranges;
+        while (R > 2 && frames / R < 64) --R;
+        static const char *kBigPlan = "W16:1023,W64.2:65535";
+        const double eff = (double)frames * (double)h->max_n / 125000.0;
+        if (!bt.fit_plan && eff > 640.0) bt.fit_plan = kBigPlan;
         lrc = pwpp_launch_clear(&bt, h->stream);
         HIPCHK(hipEventRecord(h->aux_fork, h->stream));
         HIPCHK(hipStreamWaitEvent(h->aux_stream, h->aux_fork, 0));
-        if (lrc == 0) lrc = pwpp_launch_pipeline(&a, h->stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-        if (lrc == 0) lrc = pwpp_launch_pipeline(&b, h->aux_stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        int f0 = 0;
+        for (int r = 0; r < R && lrc == 0; ++r) {
+            int f1 = r == R - 1 ? frames : (int)(((int64_t)frames * (r + 1) / R + 7) / 8 * 8);
+            if (f1 > frames) f1 = frames;
+            if (f1 > f0) {
+                const PwppBatch v = range(f0, f1 - f0);
+                lrc = pwpp_launch_pipeline(&v, (r & 1) ? h->aux_stream : h->stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            }
+            f0 = f1;
+        }
         HIPCHK(hipEventRecord(h->aux_join, h->aux_stream));
         HIPCHK(hipStreamWaitEvent(h->stream, h->aux_join, 0));
     } else {
@@ -496,6 +527,22 @@ int finish_pending(pwpp_handle *h) {
         }
     }
     h->have_results = true;
+    if (h->mode == PWPP_MODE_STREAMS) {
+        // The reference's history vectors are unbounded (update_flatness_thr stops trimming the higher rings while a
+        // lower one holds <= 1 entries, patchworkpp.cpp:363-364).  The slabs grow before a call could fill them.
+        int fill = 0;
+        bool dropped = false;
+        for (int f = 0; f < h->frames; ++f) {
+            const int hs = h->h_results.p[f].hist_state;
+            fill = (hs >> 1) > fill ? (hs >> 1) : fill;
+            dropped = dropped || (hs & 1);
+        }
+        if (dropped) return fail(PWPP_E_STATE, "an A-GLE history outgrew its slab (%d entries): the adaptive thresholds of this stream are no longer the reference's", h->stream_hist_cap);
+        if (fill + h->max_pushes_per_frame + 8 > h->stream_hist_cap) {
+            const int rc = grow_stream_histories(h, 2 * h->stream_hist_cap);
+            if (rc) return rc;
+        }
+    }
     return PWPP_OK;
 }
 
@@ -603,20 +650,23 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
     h->fit_concurrent = std::getenv("PWPP_FIT_CONCURRENT") != nullptr;
     h->no_one_pass = std::getenv("PWPP_NO_ONE_PASS") != nullptr;
     if (const char *e = std::getenv("PWPP_ONE_PASS_MIN_FRAMES")) h->one_pass_min_frames = std::atoi(e);
+    if (const char *e = std::getenv("PWPP_OVERLAP_RANGES")) h->overlap_ranges = std::atoi(e) < 2 ? 2 : std::atoi(e);
     if (const char *e = std::getenv("PWPP_ONE_PASS_SCALE")) {
         const double v = std::atof(e);
         if (v > 0.0 && v <= 1024.0) h->one_pass_scale = v;
         else std::fprintf(stderr, "pwpp: ignoring PWPP_ONE_PASS_SCALE=%s (a positive number up to 1024 expected)\n", e);
     }
     if (h->debug_flags || !h->fit_plan.empty() || h->fit_concurrent || h->no_one_pass || std::getenv("PWPP_ONE_PASS_MIN_FRAMES") ||
-        std::getenv("PWPP_ONE_PASS_SCALE") || std::getenv("PWPP_OVERLAP"))
+        std::getenv("PWPP_ONE_PASS_SCALE") || std::getenv("PWPP_OVERLAP") || std::getenv("PWPP_OVERLAP_RANGES"))
         std::fprintf(stderr, "pwpp: tuning options taken from the environment (PWPP_*): debug_flags=%d fit_plan='%s' fit_concurrent=%d "
                              "no_one_pass=%d one_pass_min_frames=%d one_pass_scale=%g overlap=%d\n", h->debug_flags, h->fit_plan.c_str(),
-                     (int)h->fit_concurrent, (int)h->no_one_pass, h->one_pass_min_frames, h->one_pass_scale, std::getenv("PWPP_OVERLAP") != nullptr);
+                     (int)h->fit_concurrent, (int)h->no_one_pass, h->one_pass_min_frames, h->one_pass_scale,
+                     std::getenv("PWPP_OVERLAP") ? std::atoi(std::getenv("PWPP_OVERLAP")) : 1);
     const int storage = p->max_elevation_storage > p->max_flatness_storage ? p->max_elevation_storage : p->max_flatness_storage;
     h->stream_hist_cap = storage + max_near_sectors + 1024;
+    h->max_pushes_per_frame = max_near_sectors;
     h->fresh_hist_cap = max_near_sectors + 2;
-    h->overlap = std::getenv("PWPP_OVERLAP") != nullptr;  // (pwpp_set_overlap; the variable is for running existing programs and the test suite in that mode)
+    if (const char *e = std::getenv("PWPP_OVERLAP")) h->overlap = std::atoi(e) != 0;  // (pwpp_set_overlap; PWPP_OVERLAP=0 runs existing programs on one stream)
     hipError_t se = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipEventCreateWithFlags(&h->aux_fork, hipEventDisableTiming);
@@ -687,13 +737,55 @@ int pwpp_destroy(pwpp_handle *h) {
     return PWPP_OK;
 }
 
+}  // extern "C"
+
+namespace {
+struct FieldSpec {  // PWPP_LAYOUT_FIELDS: where the float32 fields of a point lie
+    int step, off[4];
+};
+int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n, int frames, int cols, int layout, int mem, int mode,
+                   const FieldSpec *fs);
+}  // namespace
+
+extern "C" {
+
 int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const int32_t *n, int frames, int cols,
                                int layout, int mem, int mode) {
+    if (layout != PWPP_LAYOUT_ROW_MAJOR && layout != PWPP_LAYOUT_COL_MAJOR) return fail(PWPP_E_ARG, "bad layout %d", layout);
+    return estimate_batch(h, points, n, frames, cols, layout, mem, mode, nullptr);
+}
+
+int pwpp_estimate_ground_fields_batch(pwpp_handle *h, const void *const *data, const int32_t *n, int frames, int point_step,
+                                      int off_x, int off_y, int off_z, int off_intensity, int mem, int mode) {
+    if (point_step < 12 || (point_step & 3)) return fail(PWPP_E_ARG, "point_step=%d: a multiple of 4, at least 12, expected", point_step);
+    const int off[4] = {off_x, off_y, off_z, off_intensity};
+    for (int k = 0; k < 4; ++k) {
+        if (k == 3 && off[k] < 0) continue;  // no intensity field: RNR is skipped, as for an N x 3 matrix (patchworkpp.cpp:379-382)
+        if (off[k] < 0 || (off[k] & 3) || off[k] + 4 > point_step)
+            return fail(PWPP_E_ARG, "field offset %d does not name a 4-byte aligned float32 inside a point of %d bytes", off[k], point_step);
+    }
+    FieldSpec fs;
+    fs.step = point_step;
+    for (int k = 0; k < 4; ++k) fs.off[k] = off[k] < 0 ? -1 : off[k];
+    return estimate_batch(h, reinterpret_cast<const float *const *>(data), n, frames, off_intensity >= 0 ? 4 : 3, PWPP_LAYOUT_FIELDS, mem, mode, &fs);
+}
+
+int pwpp_estimate_ground_fields(pwpp_handle *h, const void *data, int n, int point_step, int off_x, int off_y, int off_z, int off_intensity) {
+    const void *ptrs[1] = {data};
+    const int32_t ns[1] = {n};
+    return pwpp_estimate_ground_fields_batch(h, ptrs, ns, 1, point_step, off_x, off_y, off_z, off_intensity, PWPP_MEM_HOST, PWPP_MODE_STREAMS);
+}
+
+}  // extern "C"
+
+namespace {
+int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n, int frames, int cols, int layout, int mem, int mode,
+                   const FieldSpec *fs) {
     if (!h || !points || !n) return fail(PWPP_E_ARG, "null argument");
     if (frames < 1) return fail(PWPP_E_ARG, "frames must be >= 1");
     if (frames > 65535) return fail(PWPP_E_ARG, "%d frames: at most 65535 per call (the frame is a grid dimension of the kernels)", frames);
     if (cols != 3 && cols != 4) return fail(PWPP_E_ARG, "cols=%d: 3 or 4 expected", cols);
-    if (layout != PWPP_LAYOUT_ROW_MAJOR && layout != PWPP_LAYOUT_COL_MAJOR) return fail(PWPP_E_ARG, "bad layout %d", layout);
+    const int64_t floats_per_point = fs ? fs->step / 4 : cols;  // what a frame occupies in the staging buffer
     if (mem != PWPP_MEM_HOST && mem != PWPP_MEM_DEVICE && mem != PWPP_MEM_HOST_PINNED) return fail(PWPP_E_ARG, "bad mem %d", mem);
     const bool from_host = mem != PWPP_MEM_DEVICE;
     if (mode != PWPP_MODE_FRESH && mode != PWPP_MODE_STREAMS) return fail(PWPP_E_ARG, "bad mode %d", mode);
@@ -712,7 +804,7 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
         if (mem == PWPP_MEM_DEVICE && layout == PWPP_LAYOUT_ROW_MAJOR && cols == 4 && ((uintptr_t)points[f] & 15u))
             return fail(PWPP_E_ARG, "frame %d: device buffer must be 16-byte aligned", f);
         total += n[f];
-        total_in += ((int64_t)n[f] * cols + 3) & ~(int64_t)3;
+        total_in += ((int64_t)n[f] * floats_per_point + 3) & ~(int64_t)3;
         if (n[f] > max_n) max_n = n[f];
     }
     if (total >= ((int64_t)1 << 31)) return fail(PWPP_E_ARG, "batch of %lld points exceeds 2^31", (long long)total);
@@ -794,6 +886,10 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
         d.n = n[f];
         d.cols = cols;
         d.layout = layout;
+        if (fs) {
+            d.step = fs->step;
+            for (int k = 0; k < 4; ++k) d.off[k] = fs->off[k];
+        }
         d.base = base;
         if (mode == PWPP_MODE_FRESH) {
             d.state_in = -1;
@@ -806,7 +902,7 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
             d.pts = h->d_in.p + in_off;
             // Frames that lie back to back in host memory (one slab per chunk) go over in copies of up to
             // 32 MB: 2 MB copies reach 34 GB/s on this PCIe Gen5 x16 link, 8-32 MB ones 49-52 GB/s.
-            const int64_t fl = (int64_t)n[f] * cols;
+            const int64_t fl = (int64_t)n[f] * floats_per_point;
             if (fl > 0) {
                 if (run_len > 0 && points[f] == run_src + run_len && h->d_in.p + in_off == run_dst + run_len &&
                     (run_len + fl) * (int64_t)sizeof(float) <= ((int64_t)32 << 20)) {
@@ -848,6 +944,9 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
     if (mem == PWPP_MEM_HOST) return finish_pending(h);  // the caller's buffers may go away
     return PWPP_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int pwpp_estimate_ground(pwpp_handle *h, const float *points, int n, int cols, int layout) {
     const float *ptrs[1] = {points};
@@ -1010,6 +1109,25 @@ int pwpp_set_state(pwpp_handle *h, int stream, const pwpp_state *in) {
     return PWPP_OK;
 }
 
+int pwpp_set_history(pwpp_handle *h, int stream, int which, int ring, const double *values, int count) {
+    if (!h || (count > 0 && !values)) return fail(PWPP_E_ARG, "null argument");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    if (stream < 0 || stream >= h->num_streams) return fail(PWPP_E_ARG, "stream %d out of range", stream);
+    if (which < 0 || which > 1 || ring < 0 || ring > 3) return fail(PWPP_E_ARG, "bad history selector");
+    if (count < 0 || count > (1 << 24)) return fail(PWPP_E_ARG, "count %d out of range", count);
+    while (count + h->max_pushes_per_frame + 8 > h->stream_hist_cap)
+        if ((rc = grow_stream_histories(h, 2 * h->stream_hist_cap))) return rc;
+    double *dst = h->d_hist_stream.p + ((size_t)stream * 8 + (size_t)which * 4 + ring) * h->stream_hist_cap;
+    if (count > 0) HIPCHK(hipMemcpy(dst, values, (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+    const size_t field = which == 0 ? offsetof(PwppStateScalar, elev_len) : offsetof(PwppStateScalar, flat_len);
+    char *dlen = reinterpret_cast<char *>(h->d_st_stream.p + stream) + field + (size_t)ring * sizeof(int32_t);
+    const int32_t c32 = count;
+    HIPCHK(hipMemcpy(dlen, &c32, sizeof(int32_t), hipMemcpyHostToDevice));
+    return PWPP_OK;
+}
+
 int pwpp_get_device_view(pwpp_handle *h, pwpp_device_view *out) {
     if (!h || !out) return fail(PWPP_E_ARG, "null argument");
     int rc = use_device(h);
@@ -1112,6 +1230,10 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
         if (!(v > 0.0 && v <= 1024.0)) return fail(PWPP_E_ARG, "one_pass_scale=%s: a positive number up to 1024 expected", value);
         h->one_pass_scale = v;
         h->cap_max_n = -1;  // rebuild the capacity table
+    } else if (k == "overlap_ranges") {
+        const int v = std::atoi(value);
+        if (v < 2 || v > 64) return fail(PWPP_E_ARG, "overlap_ranges=%s: 2..64 expected", value);
+        h->overlap_ranges = v;
     } else if (k == "debug_flags") {
         h->debug_flags = std::atoi(value);
     } else {

@@ -10,10 +10,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include "../../include/pwpp.h"
 #include "pwpp_dev.h"
 
-#define PWPP_LAYOUT_ROW_MAJOR 0
-#define PWPP_LAYOUT_COL_MAJOR 1
+// (PWPP_LAYOUT_ROW_MAJOR / _COL_MAJOR / _FIELDS: include/pwpp.h)
 
 namespace {
 
@@ -49,6 +49,14 @@ __device__ __forceinline__ void load_point(const PwppFrameDesc &fd, int i, float
             z = p[2];
             w = 0.0f;
         }
+    } else if (fd.layout == PWPP_LAYOUT_FIELDS) {
+        // sensor_msgs/PointCloud2 as the reference's ROS wrapper reads it (ros/src/Utils.hpp:158-172: one float
+        // iterator per field): the fields are fetched where they lie, no repack on the host
+        const char *rec = reinterpret_cast<const char *>(fd.pts) + (size_t)i * (size_t)fd.step;
+        x = *reinterpret_cast<const float *>(rec + fd.off[0]);
+        y = *reinterpret_cast<const float *>(rec + fd.off[1]);
+        z = *reinterpret_cast<const float *>(rec + fd.off[2]);
+        w = fd.off[3] >= 0 ? *reinterpret_cast<const float *>(rec + fd.off[3]) : 0.0f;
     } else {  // column-major planes (Eigen::MatrixXf storage)
         const size_t n = (size_t)fd.n;
         x = fd.pts[i];

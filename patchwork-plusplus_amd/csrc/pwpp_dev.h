@@ -50,6 +50,9 @@ struct PwppFrameDesc {
     int64_t base;      // first slot of this frame in the compact per-point workspaces (codes, out_idx)
     int32_t state_out; // index the updated state is written to
     int32_t pad_;
+    int32_t step;      // PWPP_LAYOUT_FIELDS: bytes from one point to the next (sensor_msgs/PointCloud2 point_step) ...
+    int32_t off[4];    // ... and the byte offsets of x, y, z, intensity inside a point (intensity < 0: none)
+    int32_t pad2_[3];
     int64_t sbase;     // first slot of this frame in the bin-ordered workspaces (sorted_*, plist); == base
                        // on the two-pass path, frame * slots_per_frame on the one-pass path (see cap_off)
 };
@@ -76,7 +79,7 @@ struct PwppPatchRec {  // one per (frame, bin); written by k_patch_fit, finished
 
 struct PwppFrameResult {
     int32_t n_ground, n_nonground, n_patches, n_rnr, n_oor, n_dropped;
-    int32_t pad0;      // history slab full (flag)
+    int32_t hist_state;  // (entries of the fullest A-GLE history after this frame << 1) | a push found its slab full
     int32_t overflow;  // one-pass binning: some bin of this frame outgrew its segment (the batch is redone on the two-pass path)
 };
 

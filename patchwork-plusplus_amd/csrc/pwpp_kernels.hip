@@ -597,6 +597,7 @@ __global__ __launch_bounds__(64) void k_gle_tgr_seq(PwppBatch Bt) {
         }
     }
 
+    int dropped_push = 0;  // a history slab was full (never, unless the host failed to grow it: hist_state)
     // ---- pass 1: decisions in traversal order (ref :184-311)
     int concentric_idx = 0;
     int n_ring_flat = 0;  // ringwise_flatness: only cleared when a ring had candidates (ref :292-304)
@@ -651,14 +652,17 @@ __global__ __launch_bounds__(64) void k_gle_tgr_seq(PwppBatch Bt) {
                     is_flat = flatness < st.flatness_thr[concentric_idx];
                 }
                 if (is_upright && not_elevated && is_near) {  // ref :253-259
-                    // (the reference's vectors are unbounded; the slabs are sized so that this guard
-                    // only trips in the pathological un-trimmed case of ref :363-364, then flagged)
-                    if (st.elev_len[concentric_idx] < P.hist_cap && st.flat_len[concentric_idx] < P.hist_cap) {
+                    // (the reference's vectors are unbounded -- update_flatness_thr stops trimming the higher rings
+                    // while a lower one holds <= 1 entries, ref :363-364; the host grows the slabs in time
+                    // (hist_state), so these guards never trip; each history has its own)
+                    if (st.elev_len[concentric_idx] < P.hist_cap)
                         hist_out[(0 * 4 + concentric_idx) * P.hist_cap + st.elev_len[concentric_idx]++] = elevation;
+                    else
+                        dropped_push = 1;
+                    if (st.flat_len[concentric_idx] < P.hist_cap)
                         hist_out[(1 * 4 + concentric_idx) * P.hist_cap + st.flat_len[concentric_idx]++] = flatness;
-                    } else {
-                        Bt.results[f].pad0 = 1;
-                    }
+                    else
+                        dropped_push = 1;
                     s_ring_flat[n_ring_flat++] = flatness;
                 }
                 int dec;
@@ -810,6 +814,14 @@ __global__ __launch_bounds__(64) void k_gle_tgr_seq(PwppBatch Bt) {
         }
     }
     Bt.st_scalar[fd.state_out] = st;
+    {   // how full the fullest history is: the host grows the slabs before they run out (pwpp_capi.cpp)
+        int mx = 0;
+        for (int k = 0; k < 4; ++k) {
+            mx = st.elev_len[k] > mx ? st.elev_len[k] : mx;
+            mx = st.flat_len[k] > mx ? st.flat_len[k] : mx;
+        }
+        res->hist_state = (mx << 1) | dropped_push;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -857,6 +869,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
                                                                                 // later the staging tile of the histories
     __shared__ unsigned s_epush[PWPP_MAX_NEAR_BINS + 1];
     __shared__ double s_pseq[PWPP_MAX_NEAR_BINS];     // flatness of the pushed patches, in push order
+    __shared__ int s_dropped;                         // a history slab was full (never, unless the host failed to grow it)
     __shared__ unsigned s_wave[kBlock / 64][4];
     __shared__ PwppStateScalar s_st;
     __shared__ int s_ring_first[PWPP_MAX_ROI + 1];    // first bin of near ring ci; [roi] = end
@@ -878,6 +891,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     const int roi = P.num_rings_of_interest;
 
     if (threadIdx.x == 0) {
+        s_dropped = 0;
         PwppStateScalar st;
         if (fd.state_in >= 0) {
             st = Bt.st_scalar[fd.state_in];
@@ -1022,12 +1036,9 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         const int pos = (int)(s_epush[bin] - s_epush[s_ring_first[ci]]);
         const int e = s_len0[0][ci] + pos, fl = s_len0[1][ci] + pos;
         const PwppPatchRec &r = rr[j];
-        if (e < P.hist_cap && fl < P.hist_cap) {
-            hist_out[(0 * 4 + ci) * P.hist_cap + e] = (double)r.mean[2];
-            hist_out[(1 * 4 + ci) * P.hist_cap + fl] = s_pseq[s_epush[bin]];
-        } else {
-            Bt.results[f].pad0 = 1;  // slab full (only the un-trimmed case of ref :363-364), flagged
-        }
+        // (each history has its own guard; the host grows the slabs before one can fill: hist_state)
+        if (e < P.hist_cap) hist_out[(0 * 4 + ci) * P.hist_cap + e] = (double)r.mean[2];
+        if (fl < P.hist_cap) hist_out[(1 * 4 + ci) * P.hist_cap + fl] = s_pseq[s_epush[bin]];
     }
     // ring-wise flatness statistics for TGR: the list is only cleared by a ring that had
     // candidates (ref :292-304), so it may span several rings
@@ -1037,8 +1048,8 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
             const unsigned end = s_epush[s_ring_first[ci + 1]];
             const int pushed = (int)(end - s_epush[s_ring_first[ci]]);
             int ne = s_len0[0][ci] + pushed, nf = s_len0[1][ci] + pushed;
-            if (ne > P.hist_cap) ne = P.hist_cap;
-            if (nf > P.hist_cap) nf = P.hist_cap;
+            if (ne > P.hist_cap) { ne = P.hist_cap; s_dropped = 1; }  // (the pushes beyond the slab were not written)
+            if (nf > P.hist_cap) { nf = P.hist_cap; s_dropped = 1; }
             s_st.elev_len[ci] = ne;
             s_st.flat_len[ci] = nf;
             s_seg_begin[ci] = begin;
@@ -1286,6 +1297,12 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
             }
         }
         Bt.st_scalar[fd.state_out] = s_st;
+        int mx = 0;
+        for (int k = 0; k < 4; ++k) {
+            mx = s_st.elev_len[k] > mx ? s_st.elev_len[k] : mx;
+            mx = s_st.flat_len[k] > mx ? s_st.flat_len[k] : mx;
+        }
+        Bt.results[f].hist_state = (mx << 1) | s_dropped;  // the host grows the slabs before they run out (pwpp_capi.cpp)
     }
     __syncthreads();
     {  // erase(begin, begin + exceed), ref :354-355,372-373: every history at once, loads before stores
@@ -1510,7 +1527,7 @@ __global__ __launch_bounds__(kBlock) void k_clear(uint4 *slabs, size_t n16, Pwpp
     if (i < n16) slabs[i] = make_uint4(0u, 0u, 0u, 0u);
     if (i < (size_t)frames) {
         PwppFrameResult z;
-        z.n_ground = z.n_nonground = z.n_patches = z.n_rnr = z.n_oor = z.n_dropped = z.pad0 = z.overflow = 0;
+        z.n_ground = z.n_nonground = z.n_patches = z.n_rnr = z.n_oor = z.n_dropped = z.hist_state = z.overflow = 0;
         results[i] = z;
     }
 }

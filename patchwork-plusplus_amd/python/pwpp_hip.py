@@ -78,6 +78,7 @@ def load():
         L.pwpp_destroy.argtypes = [vp]
         L.pwpp_estimate_ground.argtypes = [vp, vp, ci, ci, ci]
         L.pwpp_estimate_ground_batch.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci]
+        L.pwpp_estimate_ground_fields.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci]
         L.pwpp_synchronize.argtypes = [vp]
         L.pwpp_set_num_streams.argtypes = [vp, ci]
         L.pwpp_get_counts.argtypes = [vp, ci, vp, vp, vp]
@@ -90,6 +91,7 @@ def load():
         L.pwpp_get_state.argtypes = [vp, ci, ctypes.POINTER(State)]
         L.pwpp_get_history.argtypes = [vp, ci, ci, ci, vp, ci]
         L.pwpp_set_state.argtypes = [vp, ci, ctypes.POINTER(State)]
+        L.pwpp_set_history.argtypes = [vp, ci, ci, ci, vp, ci]
         L.pwpp_get_device_view.argtypes = [vp, ctypes.POINTER(DeviceView)]
         L.pwpp_set_profiling.argtypes = [vp, ci]
         L.pwpp_host_alloc.argtypes = [ctypes.POINTER(vp), ctypes.c_uint64]
@@ -282,6 +284,28 @@ class Handle:
             s.elevation_thr[k] = elevation_thr[k]
             s.flatness_thr[k] = flatness_thr[k]
         self._check(self._L.pwpp_set_state(self._h, stream, ctypes.byref(s)))
+
+    def estimate_ground_fields(self, data, n, point_step, off_x, off_y, off_z, off_intensity=-1):
+        """One frame handed over as a sensor_msgs/PointCloud2 data blob (bytes-like / uint8 array)."""
+        buf = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data
+        self._keep = buf
+        self._check(self._L.pwpp_estimate_ground_fields(self._h, _vp(buf), n, point_step, off_x, off_y, off_z, off_intensity))
+
+    def set_history(self, stream, which, ring, values):
+        v = np.ascontiguousarray(values, np.float64)
+        self._check(self._L.pwpp_set_history(self._h, stream, which, ring, _vp(v) if v.size else None, int(v.size)))
+
+    def checkpoint(self, stream=0):
+        """Everything a stream carries from frame to frame (pwpp_get_state + the eight histories)."""
+        st = self.state(stream)
+        return dict(sensor_height=st.sensor_height, elevation_thr=list(st.elevation_thr), flatness_thr=list(st.flatness_thr),
+                    hist=[[self.history(stream, w, r) for r in range(4)] for w in range(2)])
+
+    def restore(self, ck, stream=0):
+        self.set_state(stream, ck["sensor_height"], ck["elevation_thr"], ck["flatness_thr"])
+        for w in range(2):
+            for r in range(4):
+                self.set_history(stream, w, r, ck["hist"][w][r])
 
     def history(self, index, which, ring):
         n = self._check(self._L.pwpp_get_history(self._h, index, which, ring, None, 0))

@@ -863,3 +863,138 @@ def test_cpp_class_with_eigen_types(kitti, golden, tmp_path):
     npatch = int(re.search(r"patches: (\d+)", out).group(1))
     assert [ng, nn, npatch] == list(golden["f32/fresh/0/counts"])
     assert "aligned: 1" in out
+
+
+def test_histories_that_the_reference_never_trims(oracle):
+    """A sensor that sees no ground in ring 0: update_flatness_thr stops at ring 0 ("break", ref :363-364), so the
+    flatness histories of rings 1-3 are never trimmed and grow by up to 32 + 54 + 54 entries a frame -- unbounded
+    vectors in the reference.  The history slabs (max storage + 1024 at first) must grow with them: 150 frames on one
+    stream, compared with the oracle frame by frame, histories included."""
+    base = pwpp_synth.make_cloud(21, beams=48, azimuth_steps=1200)
+    r = np.hypot(base[:, 0], base[:, 1])
+    far = base[r > 7.7]  # nothing in ring 0 (2.7 .. 7.53 m)
+    rng = np.random.default_rng(5)
+    h = pwpp_hip.Handle()
+    est = ol.Estimator(oracle, arith=ol.ARITH_FXP)
+    for t in range(150):
+        pts = far.copy()
+        pts[:, 2] += rng.normal(0, 0.004, len(pts)).astype(np.float32)
+        h.estimate_ground(pts)
+        ref = est.run(pts)
+        if t % 10 == 9 or t > 120:
+            assert_frame_equal(h, 0, ref, pts.shape[0], state_index=0)
+    assert len(ref.hist_flat[0]) <= 1 and max(len(ref.hist_flat[k]) for k in (1, 2, 3)) > 2100  # beyond the first slab
+    assert len(ref.hist_elev[1]) == 1000  # ... while the elevation histories are trimmed every frame
+
+
+def test_checkpoint_and_restore_a_stream(kitti, oracle):
+    """pwpp_get_state / pwpp_get_history -> pwpp_set_state / pwpp_set_history: a stream restored on another handle
+    continues bit for bit (set_state used to drop the histories)."""
+    a = pwpp_hip.Handle()
+    est = ol.Estimator(oracle, arith=ol.ARITH_FXP)
+    for k in (0, 1, 2, 3):
+        a.estimate_ground(kitti[k])
+        est.run(kitti[k])
+    ck = a.checkpoint(0)
+    b = pwpp_hip.Handle()
+    b.restore(ck, 0)
+    for k in (4, 5, 0):
+        b.estimate_ground(kitti[k])
+        assert_frame_equal(b, 0, est.run(kitti[k]), kitti[k].shape[0], state_index=0)
+
+
+def test_trim_workspace_and_options(kitti, oracle):
+    """pwpp_trim_workspace gives the per-batch buffers back and the next call allocates again; pwpp_set_option rejects
+    what it does not know; more than 65535 frames per call are refused up front."""
+    h = pwpp_hip.Handle()
+    frames = [kitti[k % 6] for k in range(8)]
+    h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+    ref = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(kitti[1])
+    assert_frame_equal(h, 1, ref, kitti[1].shape[0])
+    h.trim_workspace()
+    with pytest.raises(pwpp_hip.PwppError):
+        h.ground_indices(0)  # the lists lived in the workspace
+    h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+    assert_frame_equal(h, 1, ref, kitti[1].shape[0])
+    with pytest.raises(pwpp_hip.PwppError):
+        h.set_option("no_such_option", 1)
+    with pytest.raises(pwpp_hip.PwppError):
+        h.set_option("fit_plan", "rm -rf")
+    with pytest.raises(pwpp_hip.PwppError):
+        h.estimate_ground_batch([kitti[0][:16]] * 65536, mode=pwpp_hip.MODE_FRESH)
+
+
+# the parameter set of the reference's ROS 2 launch file (ros/launch/patchworkpp.launch.py:50-64) as the node
+# applies it (ros/src/GroundSegmentationServer.cpp:27-46: RNR off, N x 3 input)
+ROS_LAUNCH = dict(sensor_height=1.88, num_iter=3, num_lpr=20, num_min_pts=0, th_seeds=0.3, th_dist=0.125, th_seeds_v=0.25,
+                  th_dist_v=0.9, max_range=80.0, min_range=1.0, uprightness_thr=0.101, enable_RNR=0)
+
+
+def pointcloud2_blob(pts, point_step, off, extra_seed=0):
+    """A sensor_msgs/PointCloud2 data blob: float32 x, y, z (and intensity) at byte offsets `off` of records of
+    point_step bytes, the rest of a record filled with other fields' bytes (ring, time, padding)."""
+    rng = np.random.default_rng(extra_seed)
+    blob = rng.integers(0, 256, (pts.shape[0], point_step), dtype=np.uint8)
+    for k, o in enumerate(off):
+        if o >= 0:
+            blob[:, o:o + 4] = pts[:, k].astype(np.float32).view(np.uint8).reshape(-1, 4)
+    return np.ascontiguousarray(blob)
+
+
+def test_ros_wrapper_parameters_and_pointcloud2_input(kitti, oracle):
+    """SURVEY 8f-f4, the part that can be tested without ROS: (i) the launch file's parameter set as ONE variant,
+    on a stateful three-frame sequence of N x 3 clouds (num_min_pts = 0 lets empty bins through: the sequential
+    GLE kernel); (ii) the same frames handed over as PointCloud2 blobs (x, y, z at odd offsets of 32-byte and
+    18 * 4-byte records, with and without an intensity field), read in place by the binning kernels."""
+    p = apply_variant(pwpp_hip.default_params(), ROS_LAUNCH)
+    op = to_oracle_params(p)
+    syn = pwpp_synth.add_edge_cases(pwpp_synth.make_cloud(31, beams=32, azimuth_steps=1200), 31)
+    seq = [kitti[2], syn, kitti[3]]
+    est = ol.Estimator(oracle, op, arith=ol.ARITH_FXP)
+    refs = [est.run(np.ascontiguousarray(c[:, :3])) for c in seq]
+    # (i) N x 3 matrices, as PointCloud2ToEigenMat produces them
+    h = pwpp_hip.Handle(p)
+    for c, ref in zip(seq, refs):
+        h.estimate_ground(np.ascontiguousarray(c[:, :3]))
+        assert_frame_equal(h, 0, ref, c.shape[0], state_index=0)
+    # (ii) the message's data blob, fields in place
+    for step, off in ((32, (0, 4, 8, -1)), (32, (4, 12, 20, -1)), (72, (60, 8, 32, -1)), (16, (0, 4, 8, 12))):
+        h2 = pwpp_hip.Handle(p)
+        for c, ref in zip(seq, refs):
+            h2.estimate_ground_fields(pointcloud2_blob(c, step, off, step), c.shape[0], step, *off)
+            assert_frame_equal(h2, 0, ref, c.shape[0], state_index=0)
+            g = h2.ground_indices(0)
+            assert np.array_equal(h2.ground(0), c[g, :3])  # the xyz getters read the same fields
+    # with RNR enabled an intensity field is used exactly like the fourth matrix column
+    p4 = pwpp_hip.default_params()
+    ref4 = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(kitti[1])
+    h4 = pwpp_hip.Handle(p4)
+    h4.estimate_ground_fields(pointcloud2_blob(kitti[1], 24, (8, 0, 16, 4), 1), kitti[1].shape[0], 24, 8, 0, 16, 4)
+    assert_frame_equal(h4, 0, ref4, kitti[1].shape[0], state_index=0)
+    for bad in ((10, 0, 4, 8, -1), (16, 0, 4, 14, -1), (16, 0, 4, 8, 13), (8, 0, 4, 8, -1)):
+        with pytest.raises(pwpp_hip.PwppError):
+            h4.estimate_ground_fields(np.zeros(64, np.uint8), 1, *bad)
+
+
+def test_dense_batch_one_pass_36_sectors(oracle):
+    """BASELINE.json configs[4] as a BATCH (bench.py --workload dense): 32 dense 128-beam ~480 k-point frames,
+    36-sector CZM, one-pass binning, overlap off and on; every frame against the oracle (only a
+    single frame was compared)."""
+    p = pwpp_hip.default_params()
+    for k in range(4):
+        p.num_sectors_each_zone[k] = 36
+    src = [pwpp_synth.make_dense_cloud(1000 + k) for k in range(4)]
+    refs = [ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(c) for c in src]
+    frames = [src[i % 4] for i in range(32)]
+    h = pwpp_hip.Handle(p)
+    h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+    assert h.one_pass_stats() == (1, 0)
+    for i in range(32):
+        assert_frame_equal(h, i, refs[i % 4], frames[i].shape[0])
+    big = [src[i % 4] for i in range(128)]  # 128 frames: two frame ranges on two streams (default schedule)
+    h.estimate_ground_batch(big, mode=pwpp_hip.MODE_FRESH)
+    for i in (0, 1, 63, 64, 65, 126, 127):
+        assert_frame_equal(h, i, refs[i % 4], big[i].shape[0])
+    counts = h.all_counts()
+    for i in range(128):
+        assert tuple(counts[i, :3]) == tuple(counts[i % 4, :3])
