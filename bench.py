@@ -107,8 +107,6 @@ def main():
     import pwpp_hip
 
     src, data_name = load_source_frames(args.workload)
-    if args.workload == "dense" and args.frames == 1024:
-        args.frames = 128
     F = args.frames
     # F distinct device buffers carved from one allocation; each frame starts 16-byte aligned
     which = pwpp_dist.shard_sources(len(src), F, rank)
@@ -196,6 +194,8 @@ def main():
                        "frames_per_gpu": F, "points_per_frame": int(np.mean(ns)), "parallelism": "frames sharded, dp%d" % world,
                        "schedule": ("one stream" if args.no_overlap or F < 128 else "library default: two frame ranges on two streams")
                                    + "; kernel_ms / roofline.kernel_ms: separate single-stream pass of %d steps outside the timed region" % args.profile_steps},
+            "binning": {"one_pass_batches": h.one_pass_stats()[0], "redone_two_pass": h.one_pass_stats()[1],
+                        "workspace_gb": h.workspace_bytes() / 1e9, "input_gb": float(offs[-1]) * 16 / 1e9},
             "latency": {"workload": "configs[1]: single frame, device-resident, fresh state", "ms_per_frame_wall": 1000.0 * lat,
                         "gpu_us": lat_gpu_us},
         }

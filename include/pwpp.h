@@ -269,6 +269,8 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value);
  * after 1024 KITTI frames with one-pass binning); streams' state and results of the last call are kept
  * only as far as they live outside those buffers: fetch results first.  The next call allocates again. */
 int pwpp_trim_workspace(pwpp_handle *h);
+/* device memory the handle holds for its workspaces right now, in bytes (inputs handed over as device buffers are the caller's) */
+int64_t pwpp_get_workspace_bytes(pwpp_handle *h);
 
 #ifdef __cplusplus
 }

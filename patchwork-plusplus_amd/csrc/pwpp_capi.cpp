@@ -23,6 +23,7 @@
 extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
                                     hipEvent_t aux_fork, hipEvent_t aux_join, unsigned long long *order_a, unsigned long long *order_b);
 extern "C" int pwpp_launch_clear(const PwppBatch *batch, hipStream_t stream);
+extern "C" int pwpp_launch_histogram(const PwppBatch *batch, hipStream_t stream);
 extern "C" int pwpp_launch_gather_xyz(const PwppFrameDesc *fd, const int *idx, int count, float *out, hipStream_t stream);
 
 static_assert(sizeof(pwpp_state) == sizeof(PwppStateScalar), "pwpp_state must mirror PwppStateScalar");
@@ -157,6 +158,11 @@ struct pwpp_handle {
     DevBuf<uint32_t> d_bins;  // 5 slabs of frames*(B+2): count, off, cursor, dst_a, dst_b
     DevBuf<uint32_t> d_cls_start;  // frames * 8
     DevBuf<uint32_t> d_cap_off;    // B + 3 segment starts of the one-pass path
+    DevBuf<uint32_t> d_bin_max;    // B + 2: largest count of every bin so far (k_czm_scan)
+    std::vector<uint32_t> observed, cap_table;  // host copies: d_bin_max as last read; capacities of the table on the device
+    bool have_observation = false, table_stale = true;
+    DevBuf<PwppFrameDesc> d_frames_probe;
+    PinnedBuf<uint32_t> h_bin_max;
     DevBuf<uint16_t> d_cls_list;   // frames * B
     DevBuf<PwppPatchRec> d_recs;
     DevBuf<float> d_centers, d_normals;
@@ -323,31 +329,27 @@ int grow_stream_histories(pwpp_handle *h, int new_cap) {
     return PWPP_OK;
 }
 
-// Segment sizes of the one-pass path for batches whose largest frame has max_n points: a bin of zone
-// k gets `scale` times its even share of such a frame (KITTI: the fullest bin holds 2.0x the even
-// share of its zone; default scale 4), the two pseudo-bins (RNR hits, out-of-range points) a whole
-// frame each.  PWPP_ONE_PASS_SCALE overrides the scale (tests use a tiny one to force the
-// overflow path).
+// Segment sizes of the one-pass path.  A bin's segment holds 1.5 x the largest count that bin has had in any frame
+// this handle has seen (d_bin_max, kept by k_czm_scan; before the first batch a histogram of a few sample frames
+// fills it: probe_histogram) plus 256 slots -- ~2.7 slots per point of a KITTI frame, 54 B per point.  (Round 1
+// gave every bin 4 x its even share of its zone and the two pseudo-bins a whole frame each: 20 slots, 410 B per
+// point, 52 GB for the 1024-frame batch.)  one_pass_scale scales the 1.5 (tests use a tiny one to force overflows).
+// A bin that outgrows its segment raises the frame's overflow flag; the batch is then redone on the exact two-pass
+// path, whose counts enter d_bin_max, and the table is rebuilt.
 int build_capacity_table(pwpp_handle *h, int max_n) {
     const PwppDevParams &P = h->dp;
     const int B = P.num_bins, NB = B + 2;
-    const double scale = h->one_pass_scale;
+    const double scale = 1.5 * h->one_pass_scale / 4.0;
     std::vector<uint32_t> off((size_t)NB + 1);
+    h->cap_table.assign((size_t)NB, 0u);
     uint64_t run = 0;
     for (int b = 0; b < NB; ++b) {
         off[(size_t)b] = (uint32_t)run;
-        double cap;
-        if (b < B) {
-            int k = 0;
-            while (k < 3 && b >= P.bin_base[k + 1]) ++k;
-            const int bins_k = P.bin_base[k + 1] - P.bin_base[k];
-            cap = scale * (double)max_n / (double)(bins_k > 0 ? bins_k : 1) + 64.0;
-        } else {
-            cap = (double)max_n;  // RNR hits / out-of-range points: a sensor that sees further than max_range leaves
-                                  // a third of its points here, so these two can hold a whole frame each
-        }
-        if (cap > (double)max_n) cap = (double)max_n;
-        run += ((uint64_t)cap + 15u) & ~(uint64_t)15u;
+        double cap = scale * (double)h->observed[(size_t)b] + (h->one_pass_scale >= 1.0 ? 256.0 : 16.0);
+        if (cap > (double)max_n + 16.0) cap = (double)max_n + 16.0;
+        const uint64_t c = ((uint64_t)cap + 15u) & ~(uint64_t)15u;
+        h->cap_table[(size_t)b] = (uint32_t)c;
+        run += c;
         if (run >= ((uint64_t)1 << 32)) return fail(PWPP_E_NOMEM, "one-pass capacity table overflows 32-bit offsets");
     }
     off[(size_t)NB] = (uint32_t)run;
@@ -356,33 +358,52 @@ int build_capacity_table(pwpp_handle *h, int max_n) {
     HIPCHK(hipMemcpy(h->d_cap_off.p, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     h->slots_per_frame = (int64_t)run;
     h->cap_max_n = max_n;
+    h->table_stale = false;
     return PWPP_OK;
 }
 
-// Launches the pipeline over the batch described by h->descs (buffers sized, inputs on the device).
-// one_pass: fixed bin segments (k_czm_bin_scatter); otherwise the exact two-pass binning.
-int launch_prepared(pwpp_handle *h, bool one_pass) {
-    const int B = h->dp.num_bins, NB = B + 2;
-    const int frames = h->frames;
-    // where a frame's bins live in the bin-ordered buffers
-    int64_t base = 0;
-    for (int f = 0; f < frames; ++f) {
-        PwppFrameDesc &d = h->descs[(size_t)f];
-        d.sbase = one_pass ? (int64_t)f * h->slots_per_frame : base;
-        base += ((int64_t)d.n + 3 * (int64_t)NB + 3) & ~(int64_t)3;  // compact layout: every bin starts at a multiple of four slots (k_czm_scan)
-    }
-    // the descriptors on the device are reused when nothing changed (a caller cycling through the same
-    // device buffers, a replayed batch): one host-to-device copy less in front of the first kernel
-    const size_t desc_bytes = (size_t)frames * sizeof(PwppFrameDesc);
-    if (h->descs_on_device.size() != (size_t)frames || h->descs_dev_ptr != h->d_frames.p ||
-        std::memcmp(h->descs_on_device.data(), h->descs.data(), desc_bytes) != 0) {
-        std::memcpy(h->h_frames.p, h->descs.data(), desc_bytes);
-        HIPCHK(hipMemcpyAsync(h->d_frames.p, h->h_frames.p, desc_bytes, hipMemcpyHostToDevice, h->stream));
-        h->descs_on_device = h->descs;
-        h->descs_dev_ptr = h->d_frames.p;
-    }
+void fill_batch(pwpp_handle *h, PwppBatch &bt);
 
+int read_observed(pwpp_handle *h) {
+    const size_t NB = (size_t)h->dp.num_bins + 2;
+    h->observed.resize(NB);
+    HIPCHK(hipMemcpy(h->observed.data(), h->d_bin_max.p, NB * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return PWPP_OK;
+}
+
+// Histogram of up to 16 frames spread over the batch described by h->descs (inputs already on their way to the device):
+// K0 + K1 + K2 on a private descriptor array, which leaves the bins' largest counts in d_bin_max.
+int probe_histogram(pwpp_handle *h) {
+    const int S = h->frames < 32 ? h->frames : 32;
+    std::vector<PwppFrameDesc> sample((size_t)S);
+    int max_n = 0;
+    for (int i = 0; i < S; ++i) {
+        // (scattered over the batch, not evenly spaced: replayed or periodic inputs would alias with a fixed stride)
+        const size_t pick = S == h->frames ? (size_t)i : (size_t)(((uint64_t)(i + 1) * 2654435761ull) % (uint64_t)h->frames);
+        sample[(size_t)i] = h->descs[pick];
+        if (h->mode != PWPP_MODE_FRESH) sample[(size_t)i].state_in = sample[(size_t)i].state_out;  // (RNR reads the stream's sensor height)
+        sample[(size_t)i].state_out = i;  // never written: the probe stops after K2
+        if (sample[(size_t)i].n > max_n) max_n = sample[(size_t)i].n;
+    }
+    int rc = h->d_frames_probe.ensure((size_t)S);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_frames_probe.p, sample.data(), (size_t)S * sizeof(PwppFrameDesc), hipMemcpyHostToDevice, h->stream));
     PwppBatch bt;
+    fill_batch(h, bt);
+    bt.frames = h->d_frames_probe.p;
+    bt.num_frames = S;
+    bt.max_n = max_n;
+    bt.cap_off = nullptr;
+    const int lrc = pwpp_launch_histogram(&bt, h->stream);
+    if (lrc != 0) return fail(PWPP_E_HIP, "histogram probe failed: %s", hipGetErrorString((hipError_t)lrc));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_observation = true;
+    return read_observed(h);
+}
+
+// everything a launch needs except the frame range, the capacity table and the events
+void fill_batch(pwpp_handle *h, PwppBatch &bt) {
+    const int B = h->dp.num_bins, NB = B + 2;
     std::memset(&bt, 0, sizeof(bt));
     bt.P = h->dp;
     bt.frames = h->d_frames.p;
@@ -421,6 +442,35 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     bt.results = h->d_results.p;
     bt.results_host = h->h_results.p;  // hipHostMalloc'ed: the same address on the device
     bt.dbg = h->d_dbg.p;
+
+    bt.bin_max = h->d_bin_max.p;
+}
+
+// Launches the pipeline over the batch described by h->descs (buffers sized, inputs on the device).
+// one_pass: fixed bin segments (k_czm_bin_scatter); otherwise the exact two-pass binning.
+int launch_prepared(pwpp_handle *h, bool one_pass) {
+    const int B = h->dp.num_bins, NB = B + 2;
+    const int frames = h->frames;
+    // where a frame's bins live in the bin-ordered buffers
+    int64_t base = 0;
+    for (int f = 0; f < frames; ++f) {
+        PwppFrameDesc &d = h->descs[(size_t)f];
+        d.sbase = one_pass ? (int64_t)f * h->slots_per_frame : base;
+        base += ((int64_t)d.n + 3 * (int64_t)NB + 3) & ~(int64_t)3;  // compact layout: every bin starts at a multiple of four slots (k_czm_scan)
+    }
+    // the descriptors on the device are reused when nothing changed (a caller cycling through the same
+    // device buffers, a replayed batch): one host-to-device copy less in front of the first kernel
+    const size_t desc_bytes = (size_t)frames * sizeof(PwppFrameDesc);
+    if (h->descs_on_device.size() != (size_t)frames || h->descs_dev_ptr != h->d_frames.p ||
+        std::memcmp(h->descs_on_device.data(), h->descs.data(), desc_bytes) != 0) {
+        std::memcpy(h->h_frames.p, h->descs.data(), desc_bytes);
+        HIPCHK(hipMemcpyAsync(h->d_frames.p, h->h_frames.p, desc_bytes, hipMemcpyHostToDevice, h->stream));
+        h->descs_on_device = h->descs;
+        h->descs_dev_ptr = h->d_frames.p;
+    }
+
+    PwppBatch bt;
+    fill_batch(h, bt);
 
     bt.cap_off = one_pass ? h->d_cap_off.p : nullptr;
     HIPCHK(hipEventRecord(h->ev_begin, h->stream));
@@ -486,6 +536,8 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     }
     if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
+    if (one_pass)  // the bins' largest counts, for the segment sizes of the next batches (finish_pending)
+        HIPCHK(hipMemcpyAsync(h->h_bin_max.p, h->d_bin_max.p, (size_t)NB * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     h->profile_pending = h->profiling;
     h->one_pass = one_pass;
     g_slot0_one_pass = one_pass;
@@ -508,25 +560,34 @@ int finish_pending(pwpp_handle *h) {
         }
         h->profile_pending = false;
     }
+    const bool was_one_pass = h->one_pass;
     if (h->one_pass) {  // did every bin fit its segment?  if not, redo the batch on the exact two-pass path
         bool over = false;
         for (int f = 0; f < h->frames; ++f) over = over || h->h_results.p[f].overflow != 0;
         h->one_pass = false;
         if (over) {
             ++h->one_pass_redone;
-            h->one_pass_holdoff = 8;
+            h->one_pass_holdoff = 0;  // (the redo's exact counts enter d_bin_max and the table is rebuilt: no need to stay away)
+            h->table_stale = true;
             if (h->mode == PWPP_MODE_STREAMS) {  // back to the streams' state before the first attempt
                 const size_t slab = (size_t)8 * (size_t)h->stream_hist_cap;
                 HIPCHK(hipMemcpyAsync(h->d_st_stream.p, h->d_st_snap.p, (size_t)h->frames * sizeof(PwppStateScalar), hipMemcpyDeviceToDevice, h->stream));
                 HIPCHK(hipMemcpyAsync(h->d_hist_stream.p, h->d_hist_snap.p, (size_t)h->frames * slab * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
             }
-            const int rc = launch_prepared(h, false);
+            int rc = launch_prepared(h, false);
             if (rc) return rc;
             h->pending = true;
-            return finish_pending(h);
+            if ((rc = finish_pending(h))) return rc;
+            return read_observed(h);  // the exact counts of the redo size the next table
         }
     }
     h->have_results = true;
+    if (was_one_pass) {
+        // a bin that came within 10 % of its segment's capacity: grow the table before the next batch
+        h->observed.assign(h->h_bin_max.p, h->h_bin_max.p + h->cap_table.size());
+        for (size_t b = 0; b < h->cap_table.size() && !h->table_stale; ++b)
+            if ((uint64_t)h->observed[b] * 10u > (uint64_t)h->cap_table[b] * 9u) h->table_stale = true;
+    }
     if (h->mode == PWPP_MODE_STREAMS) {
         // The reference's history vectors are unbounded (update_flatness_thr stops trimming the higher rings while a
         // lower one holds <= 1 entries, patchworkpp.cpp:363-364).  The slabs grow before a call could fill them.
@@ -679,6 +740,9 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
         return fail(PWPP_E_HIP, "stream/event creation failed: %s", hipGetErrorString(se));
     }
     int rc = pwpp_set_num_streams(h, 1);
+    if (!rc) rc = h->h_bin_max.ensure((size_t)dp.num_bins + 2);
+    if (!rc) rc = h->d_bin_max.ensure((size_t)dp.num_bins + 2);
+    if (!rc && hipMemset(h->d_bin_max.p, 0, ((size_t)dp.num_bins + 2) * sizeof(uint32_t)) != hipSuccess) rc = fail(PWPP_E_HIP, "hipMemset failed");
     if (!rc) rc = h->d_bin_origin.ensure(origin.size());
     if (!rc && hipMemcpy(h->d_bin_origin.p, origin.data(), origin.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(PWPP_E_HIP, "uploading the bin origins failed");
@@ -704,6 +768,9 @@ int pwpp_destroy(pwpp_handle *h) {
     h->d_sorted_xy.release();
     h->d_sorted_idx.release();
     h->d_bin_origin.release();
+    h->d_bin_max.release();
+    h->h_bin_max.release();
+    h->d_frames_probe.release();
     h->d_plist.release();
     h->d_out.release();
     h->d_ord_a.release();
@@ -810,50 +877,11 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     if (total >= ((int64_t)1 << 31)) return fail(PWPP_E_ARG, "batch of %lld points exceeds 2^31", (long long)total);
     const size_t tp = (size_t)(total > 0 ? total : 1);
 
-    // One-pass binning (fixed bin segments, k_czm_bin_scatter) for batches of independent frames: the
-    // bin-ordered buffers hold frames x slots_per_frame records instead of one per point.  Used when
-    // the memory is there; any overflow is caught when the batch lands and the batch is redone exactly.
-    bool one_pass = false;
-    const size_t compact_slots = tp + (size_t)frames * (size_t)(3 * NB + 4);  // bins padded to multiples of four slots
-    size_t bin_slots = compact_slots;
-    {
-        const bool env_off = h->no_one_pass;
-        const int min_frames = h->one_pass_min_frames;
-        if (h->one_pass_holdoff > 0) {
-            --h->one_pass_holdoff;
-        } else if (!env_off && frames >= min_frames && max_n > 0) {
-            if (max_n > h->cap_max_n || 2 * (int64_t)max_n < h->cap_max_n) {
-                if ((rc = finish_pending(h))) return rc;
-                // (an eighth of headroom: frames of a sensor differ by a few hundred points, the table should not follow them)
-                if ((rc = build_capacity_table(h, max_n + max_n / 8))) return rc;
-            }
-            const size_t want = (size_t)frames * (size_t)h->slots_per_frame;
-            size_t free_b = 0, total_b = 0;
-            const size_t per_slot = 3 * sizeof(float) + 2 * sizeof(int32_t);  // z, {x, y}, cloud index, plist
-            const size_t held = (h->d_sorted_z.cap + h->d_sorted_idx.cap + h->d_plist.cap) * sizeof(int32_t) + h->d_sorted_xy.cap * sizeof(float2);
-            const bool have = h->d_sorted_z.cap >= want + 1024 && h->d_sorted_xy.cap >= want + 1024 && h->d_sorted_idx.cap >= want && h->d_plist.cap >= want;  // already allocated
-            if (have || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (want + want / 8 + 64) * per_slot * 21 / 20 <= free_b + held &&
-                         want < ((size_t)1 << 40))) {
-                one_pass = true;
-                bin_slots = want;
-            }
-        }
-    }
-
+    // ---- 1. everything but the bin-ordered buffers
     if ((rc = h->d_frames.ensure((size_t)frames))) return rc;
     if ((rc = h->h_frames.ensure((size_t)frames))) return rc;
     if ((rc = h->h_base.ensure((size_t)frames + 1))) return rc;
     if ((rc = h->d_codes.ensure(tp))) return rc;
-    // (slack: the fit kernels fetch whole chunks, up to 512 points beyond a patch's end)
-    if (one_pass && (h->d_sorted_z.ensure(bin_slots + 1024) || h->d_sorted_xy.ensure(bin_slots + 1024) || h->d_sorted_idx.ensure(bin_slots) || h->d_plist.ensure(bin_slots))) {
-        one_pass = false;  // the big allocation failed after all (fragmentation): compact layout, two-pass binning
-        bin_slots = compact_slots;
-        (void)hipGetLastError();
-    }
-    if ((rc = h->d_sorted_z.ensure(bin_slots + 1024))) return rc;
-    if ((rc = h->d_sorted_xy.ensure(bin_slots + 1024))) return rc;
-    if ((rc = h->d_sorted_idx.ensure(bin_slots))) return rc;
-    if ((rc = h->d_plist.ensure(bin_slots))) return rc;
     if ((rc = h->d_out.ensure(tp))) return rc;
     if (h->output_order == PWPP_ORDER_REFERENCE) {
         if ((rc = h->d_ord_a.ensure(tp))) return rc;
@@ -874,7 +902,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     }
     if (from_host && (rc = h->d_in.ensure((size_t)(total_in > 0 ? total_in : 4)))) return rc;
 
-    // frame descriptors
+    // ---- 2. frame descriptors; host inputs start their way to the device
     h->descs.resize((size_t)frames);
     int64_t base = 0, in_off = 0;
     const float *run_src = nullptr;  // pending host-to-device copy (merged run of adjacent frames)
@@ -923,6 +951,50 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     }
     h->h_base.p[frames] = base;
     if (run_len > 0) HIPCHK(hipMemcpyAsync(run_dst, run_src, (size_t)run_len * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    h->frames = frames;
+    h->mode = mode;
+
+    // ---- 3. One-pass binning (fixed bin segments, k_czm_bin_scatter) for batches of independent frames: the
+    // bin-ordered buffers hold frames x slots_per_frame records instead of one per point.  Used when the memory
+    // is there; any overflow is caught when the batch lands and the batch is redone exactly.
+    bool one_pass = false;
+    const size_t compact_slots = tp + (size_t)frames * (size_t)(3 * NB + 4);  // bins padded to multiples of four slots
+    size_t bin_slots = compact_slots;
+    if (h->one_pass_holdoff > 0) {
+        --h->one_pass_holdoff;
+    } else if (!h->no_one_pass && frames >= h->one_pass_min_frames && max_n > 0) {
+        if (2 * (int64_t)max_n < h->cap_max_n) {  // a much smaller sensor than the table was built for: start over
+            HIPCHK(hipMemsetAsync(h->d_bin_max.p, 0, (size_t)NB * sizeof(uint32_t), h->stream));
+            h->have_observation = false;
+        }
+        if (!h->have_observation) {
+            if ((rc = probe_histogram(h))) return rc;
+            h->table_stale = true;
+        }
+        if (h->table_stale || max_n > h->cap_max_n || 2 * (int64_t)max_n < h->cap_max_n)
+            if ((rc = build_capacity_table(h, max_n + max_n / 8))) return rc;
+        const size_t want = (size_t)frames * (size_t)h->slots_per_frame;
+        size_t free_b = 0, total_b = 0;
+        const size_t per_slot = 3 * sizeof(float) + 2 * sizeof(int32_t);  // z, {x, y}, cloud index, plist
+        const size_t held = (h->d_sorted_z.cap + h->d_sorted_idx.cap + h->d_plist.cap) * sizeof(int32_t) + h->d_sorted_xy.cap * sizeof(float2);
+        const bool have = h->d_sorted_z.cap >= want + 1024 && h->d_sorted_xy.cap >= want + 1024 && h->d_sorted_idx.cap >= want && h->d_plist.cap >= want;  // already allocated
+        if (have || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (want + want / 8 + 64) * per_slot * 21 / 20 <= free_b + held &&
+                     want < ((size_t)1 << 40))) {
+            one_pass = true;
+            bin_slots = want > compact_slots ? want : compact_slots;  // (a redo after an overflow uses the compact layout)
+        }
+    }
+
+    // ---- 4. the bin-ordered buffers (slack: the fit kernels fetch whole chunks, up to 512 points beyond a patch's end)
+    if (one_pass && (h->d_sorted_z.ensure(bin_slots + 1024) || h->d_sorted_xy.ensure(bin_slots + 1024) || h->d_sorted_idx.ensure(bin_slots) || h->d_plist.ensure(bin_slots))) {
+        one_pass = false;  // the big allocation failed after all (fragmentation): compact layout, two-pass binning
+        bin_slots = compact_slots;
+        (void)hipGetLastError();
+    }
+    if ((rc = h->d_sorted_z.ensure(bin_slots + 1024))) return rc;
+    if ((rc = h->d_sorted_xy.ensure(bin_slots + 1024))) return rc;
+    if ((rc = h->d_sorted_idx.ensure(bin_slots))) return rc;
+    if ((rc = h->d_plist.ensure(bin_slots))) return rc;
 
     h->frames = frames;
     h->mode = mode;
@@ -1229,7 +1301,7 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
         const double v = std::atof(value);
         if (!(v > 0.0 && v <= 1024.0)) return fail(PWPP_E_ARG, "one_pass_scale=%s: a positive number up to 1024 expected", value);
         h->one_pass_scale = v;
-        h->cap_max_n = -1;  // rebuild the capacity table
+        h->table_stale = true;  // rebuild the capacity table
     } else if (k == "overlap_ranges") {
         const int v = std::atoi(value);
         if (v < 2 || v > 64) return fail(PWPP_E_ARG, "overlap_ranges=%s: 2..64 expected", value);
@@ -1240,6 +1312,15 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
         return fail(PWPP_E_ARG, "unknown option '%s'", name);
     }
     return PWPP_OK;
+}
+
+int64_t pwpp_get_workspace_bytes(pwpp_handle *h) {
+    if (!h) return PWPP_E_ARG;
+    auto b = [](size_t cap, size_t elt) { return (int64_t)(cap * elt); };
+    return b(h->d_in.cap, 4) + b(h->d_codes.cap, 2) + b(h->d_sorted_z.cap, 4) + b(h->d_sorted_xy.cap, 8) + b(h->d_sorted_idx.cap, 4) +
+           b(h->d_plist.cap, 4) + b(h->d_out.cap, 4) + b(h->d_ord_a.cap, 8) + b(h->d_ord_b.cap, 8) + b(h->d_bins.cap, 4) +
+           b(h->d_recs.cap, sizeof(PwppPatchRec)) + b(h->d_cls_start.cap, 4) + b(h->d_cls_list.cap, 2) + b(h->d_centers.cap, 4) +
+           b(h->d_normals.cap, 4) + b(h->d_xyz.cap, 4) + b(h->d_hist_stream.cap, 8) + b(h->d_hist_fresh.cap, 8) + b(h->d_hist_snap.cap, 8);
 }
 
 int pwpp_trim_workspace(pwpp_handle *h) {

@@ -110,6 +110,7 @@ struct PwppBatch {
                                  // stored as 0x7fc00000; 0x7fc00000 | (round + 1) marks a point an R-VPF round removed
     float2 *sorted_xy;           // same slots: {x, y}
     int *sorted_idx;             // same slots: cloud index of the point (read by the last fit pass and K6 only)
+    uint32_t *bin_max;           // [B+2] largest count every bin has had in any frame so far (k_czm_scan): sizes the one-pass segments
     const float2 *bin_origin;    // [B] origin of every bin's fixed-point plane-fit sums (its polar centre rounded to 1/8 m)
     int32_t *plist;              // [total points] per patch: ground candidates from the front, non-ground from the back
     PwppPatchRec *recs;          // [frames][B]

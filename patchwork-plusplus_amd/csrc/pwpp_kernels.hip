@@ -407,6 +407,10 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
         Bt.results[f].n_rnr = (int)cnt[Bt.P.num_bins];
         Bt.results[f].n_oor = (int)cnt[Bt.P.num_bins + 1];
     }
+    // what the host sizes the one-pass segments of the NEXT batches from (an overflowed bin reports its clamped
+    // count here; the exact redo that follows reports the true one)
+    for (int b = threadIdx.x; b < NB; b += kBlock)
+        if (cnt[b] > Bt.bin_max[b]) atomicMax(&Bt.bin_max[b], cnt[b]);
     // patches of this frame sorted by size bucket (work lists of the K4 kernels)
     __shared__ unsigned s_cnt[PWPP_NUM_BUCKETS], s_start[PWPP_NUM_BUCKETS + 1], s_cur[PWPP_NUM_BUCKETS];
     const int B = Bt.P.num_bins;
@@ -1543,6 +1547,18 @@ static void launch_clear(const PwppBatch &B, hipStream_t stream) {
 }
 extern "C" int pwpp_launch_clear(const PwppBatch *batch, hipStream_t stream) {
     if (batch->num_frames > 0) launch_clear(*batch, stream);
+    return (int)hipGetLastError();
+}
+
+// K0 + K1 + K2 only: the histogram of a few sample frames (sizes the one-pass segments before the first batch)
+extern "C" int pwpp_launch_histogram(const PwppBatch *batch, hipStream_t stream) {
+    const PwppBatch &B = *batch;
+    const int F = B.num_frames;
+    if (F <= 0) return 0;
+    const unsigned gx = (unsigned)((B.max_n + kPtsPerBlock - 1) / kPtsPerBlock);
+    launch_clear(B, stream);
+    if (gx > 0) hipLaunchKernelGGL(k_czm_bin, dim3(gx, F), dim3(kBlock), 0, stream, B);
+    hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
     return (int)hipGetLastError();
 }
 

@@ -103,6 +103,8 @@ def load():
         L.pwpp_get_fxp_origins.argtypes = [vp, vp, ci]
         L.pwpp_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
         L.pwpp_trim_workspace.argtypes = [vp]
+        L.pwpp_get_workspace_bytes.argtypes = [vp]
+        L.pwpp_get_workspace_bytes.restype = ctypes.c_int64
         L.pwpp_get_one_pass_stats.argtypes = [vp, vp, vp]
         L.pwpp_set_output_order.argtypes = [vp, ci]
         L.pwpp_set_overlap.argtypes = [vp, ci]
@@ -365,6 +367,9 @@ class Handle:
         """Tuning / test switches (pwpp_set_option): fit_plan, fit_concurrent, one_pass, one_pass_min_frames,
         one_pass_scale, debug_flags.  None of them changes a result."""
         self._check(self._L.pwpp_set_option(self._h, name.encode(), str(value).encode()))
+
+    def workspace_bytes(self):
+        return int(self._L.pwpp_get_workspace_bytes(self._h))
 
     def trim_workspace(self):
         """Free the per-batch workspaces (results of the last call are gone afterwards)."""

@@ -131,7 +131,7 @@ def test_multi_stream_one_pass_with_state_restore(kitti, oracle):
     h.set_num_streams(S)
     ests = [ol.Estimator(oracle, arith=ol.ARITH_FXP) for _ in range(S)]
     redone = []
-    for t in range(12):   # (the hold-off after the overflow lasts 8 batches)
+    for t in range(12):
         frames = [kitti[(s + t) % 6] for s in range(S)]
         if t == 1:
             frames[3] = wedge
@@ -139,7 +139,8 @@ def test_multi_stream_one_pass_with_state_restore(kitti, oracle):
         for s in range(S):
             assert_frame_equal(h, s, ests[s].run(frames[s]), frames[s].shape[0], state_index=s)
         redone.append(h.one_pass_stats())
-    assert redone[0] == (1, 0) and redone[1] == (2, 1) and redone[9] == (2, 1) and redone[11][0] >= 3
+    # (the redo's exact counts size the segments of the following batches: one-pass again, and nothing more is redone)
+    assert redone[0] == (1, 0) and redone[1] == (2, 1) and redone[2] == (3, 1) and redone[11] == (12, 1)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
@@ -484,11 +485,12 @@ def test_c_abi_demo_program(kitti, golden, tmp_path):
 
 def test_one_pass_binning_and_its_overflow_fallback(kitti, oracle):
     """Batches of independent frames bin in one pass into fixed bin segments (k_czm_bin_scatter).
-    (1) the default capacities hold KITTI frames: the one-pass path is taken and nothing is redone;
-    (2) with absurdly small segments every frame overflows: the batch is redone on the exact
-        two-pass path, later batches skip the one-pass attempt for a while; results are the oracle's
-        either way;
-    (3) a cloud with most points in one sector overflows the default capacities, same fallback."""
+    The segments are sized from the bins' largest counts so far (1.5 x + 256 slots; before the first batch from
+    a histogram of sample frames).
+    (1) KITTI frames: the one-pass path is taken and nothing is redone;
+    (3) a cloud with most points in one sector overflows segments sized for KITTI frames: the batch is redone
+        on the exact two-pass path, whose counts then size the segments -- the same cloud fits afterwards;
+    (2) with absurdly small segments every frame overflows, same fallback; results are the oracle's either way."""
     frames = [kitti[i % 6] for i in range(7)]
     refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(p) for p in frames[:6]]
     h = pwpp_hip.Handle()
@@ -509,10 +511,14 @@ def test_one_pass_binning_and_its_overflow_fallback(kitti, oracle):
     for i, pts in enumerate(odd):
         assert_frame_equal(h, i, ol.Estimator(oracle, arith=ol.ARITH_FXP).run(pts), pts.shape[0])
     assert h.one_pass_stats() == (2, 1)
-    h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)  # hold-off: straight to the two-pass path
+    h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
     for i, pts in enumerate(frames):
         assert_frame_equal(h, i, refs[i % 6], pts.shape[0])
-    assert h.one_pass_stats() == (2, 1)
+    assert h.one_pass_stats() == (3, 1)
+    h.estimate_ground_batch(odd, mode=pwpp_hip.MODE_FRESH)  # the wedge fits the rebuilt segments
+    for i in (0, 3, 4):
+        assert_frame_equal(h, i, ol.Estimator(oracle, arith=ol.ARITH_FXP).run(odd[i]), odd[i].shape[0])
+    assert h.one_pass_stats() == (4, 1)
     # (2)
     h2 = pwpp_hip.Handle()
     h2.set_option("one_pass_scale", 0.05)
