@@ -444,6 +444,12 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
     bt.dbg = h->d_dbg.p;
 
     bt.bin_max = h->d_bin_max.p;
+    {   // k_emit: one wave per bin copies a list of a few thousand entries well; the bins of a dense cloud get more
+        uint32_t biggest = 0;
+        for (size_t b = 0; b < h->observed.size(); ++b) biggest = h->observed[b] > biggest ? h->observed[b] : biggest;  // (pseudo-bins included)
+        const int parts = (int)(biggest / 8192u) + 1;
+        bt.emit_parts = parts > 8 ? 8 : parts;
+    }
 }
 
 // Launches the pipeline over the batch described by h->descs (buffers sized, inputs on the device).

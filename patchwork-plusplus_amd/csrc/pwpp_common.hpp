@@ -312,38 +312,10 @@ struct PlaneFit {
     double d;
 };
 
-__device__ __forceinline__ void plane_from_totals(long long n, const long long s1[3], const __int128 s2[6], int shift,
-                                                  float ox, float oy, float z0, int debug, PlaneFit &out) {
-    const double inv = __longlong_as_double((long long)(1023 - shift) << 52);  // 2^-shift, exactly what 1.0 / (1 << shift) gives, without the division
-    const double den = (double)n * (double)(n - 1);
-    float mean[3], cov[9];
-    const double org[3] = {(double)ox, (double)oy, (double)z0};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) mean[a] = (float)(((double)s1[a] / (double)n) * inv + org[a]);
-    const int map[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int b = a; b < 3; ++b) {
-            const __int128 num = (__int128)n * s2[map[a * 3 + b]] - (__int128)s1[a] * (__int128)s1[b];
-            const float c = (float)((i128_to_double(num) / den) * (inv * inv));
-            cov[a * 3 + b] = c;
-            cov[b * 3 + a] = c;
-        }
-    }
+// (mean, covariance) -> plane: Eigen's JacobiSVD on the float covariance, normal = U.col(2) flipped to z >= 0, d
+__device__ __forceinline__ void plane_from_cov(const float mean[3], const float cov[9], int debug, PlaneFit &out) {
     float u[9], sv[3];
-    if (debug & 1) {  // timing ablation only: no eigen-solve
-#pragma unroll
-        for (int k = 0; k < 9; ++k) u[k] = cov[k];
-        sv[0] = cov[0];
-        sv[1] = cov[4];
-        sv[2] = cov[8];
-        u[2] = 0.01f;
-        u[5] = 0.01f;
-        u[8] = 0.9999f;
-    } else {
-        jacobi_svd3(cov, u, sv);
-    }
+    jacobi_svd3(cov, u, sv);
     float nx = u[2], ny = u[5], nz = u[8];  // U.col(2), ref :66
     if (nz < 0) {                           // ref :68
         nx *= -1;
@@ -361,6 +333,59 @@ __device__ __forceinline__ void plane_from_totals(long long n, const long long s
     out.sv[1] = sv[1];
     out.sv[2] = sv[2];
     out.d = -dot;
+}
+
+// output o of the moments -> (mean, covariance) step: o = 0..2 mean[o], o = 3..8 cov of the pair (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+__device__ __forceinline__ float moment_output(int o, long long n, const long long s1[3], const __int128 s2[6], int shift, const double org[3]) {
+    const double inv = __longlong_as_double((long long)(1023 - shift) << 52);  // 2^-shift, exactly what 1.0 / (1 << shift) gives, without the division
+    if (o < 3) {
+        const long long v = o == 0 ? s1[0] : (o == 1 ? s1[1] : s1[2]);
+        const double g = o == 0 ? org[0] : (o == 1 ? org[1] : org[2]);
+        return (float)(((double)v / (double)n) * inv + g);
+    }
+    const int k = o - 3;  // pair index
+    const int a = k < 3 ? 0 : (k < 5 ? 1 : 2), b = k < 3 ? k : (k < 5 ? k - 2 : 2);
+    const long long sa = a == 0 ? s1[0] : (a == 1 ? s1[1] : s1[2]), sb = b == 0 ? s1[0] : (b == 1 ? s1[1] : s1[2]);
+    __int128 m2 = s2[0];
+#pragma unroll
+    for (int q = 1; q < 6; ++q) m2 = k == q ? s2[q] : m2;
+    const __int128 num = (__int128)n * m2 - (__int128)sa * (__int128)sb;
+    const double den = (double)n * (double)(n - 1);
+    return (float)((i128_to_double(num) / den) * (inv * inv));
+}
+
+__device__ __forceinline__ void plane_from_totals(long long n, const long long s1[3], const __int128 s2[6], int shift,
+                                                  float ox, float oy, float z0, int debug, PlaneFit &out) {
+    const double org[3] = {(double)ox, (double)oy, (double)z0};
+    float mean[3], cov[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) mean[a] = moment_output(a, n, s1, s2, shift, org);
+    const int map[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+    float c6[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c6[k] = moment_output(3 + k, n, s1, s2, shift, org);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cov[k] = c6[map[k]];
+    plane_from_cov(mean, cov, debug, out);
+}
+
+// The same when every lane of the wave holds the SAME totals (the four-waves-per-patch kernel): the nine outputs --
+// nine IEEE double divisions and six 128-bit products, a third of the solve's instructions -- are computed by nine
+// lanes side by side and handed round with v_readlane; only the Jacobi iteration stays serial.
+__device__ __forceinline__ void plane_from_totals_uniform(long long n, const long long s1[3], const __int128 s2[6], int shift,
+                                                          float ox, float oy, float z0, int debug, PlaneFit &out) {
+    const double org[3] = {(double)ox, (double)oy, (double)z0};
+    const int o = lane_id() & 15;
+    const float mine = moment_output(o < 9 ? o : 0, n, s1, s2, shift, org);
+    float mean[3], c6[6], cov[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) mean[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), a));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c6[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), 3 + k));
+    const int map[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cov[k] = c6[map[k]];
+    plane_from_cov(mean, cov, debug, out);
 }
 
 // ref :551-554  (float products, float adds left to right, one double add)

@@ -125,7 +125,7 @@ struct PwppBatch {
     // host side only (the kernels never read these)
     const char *fit_plan;        // option "fit_plan": overrides the plan pwpp_launch_fit would choose; null or empty = automatic
     int32_t fit_concurrent;      // option "fit_concurrent": the classes of a plan side by side on two streams
-    int32_t pad1_;
+    int32_t emit_parts;          // waves per bin in k_emit (1..8, from the largest bin seen so far)
 };
 
 #endif

@@ -1350,7 +1350,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt, bool keep_cat
     const int f = blockIdx.y, seg = blockIdx.x;
     // the frame's counters are final since K5: hand them to the host through its pinned mirror (eight posted
     // PCIe writes) instead of a copy command behind the pipeline (a dispatch of its own, ~9 us of a single frame)
-    if (seg == 0 && threadIdx.x == 0) Bt.results_host[f] = Bt.results[f];
+    if (seg == 0 && blockIdx.z == 0 && threadIdx.x == 0) Bt.results_host[f] = Bt.results[f];
     const PwppDevParams &P = Bt.P;
     const int B = P.num_bins, NB = B + 2;
     const unsigned n = Bt.bin_count[(size_t)f * NB + seg];
@@ -1360,23 +1360,34 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt, bool keep_cat
     int *out = Bt.out_idx + fd.base;
     const unsigned da = Bt.dst_a[(size_t)f * NB + seg];
     const bool whole = seg >= B || (uint64_t)n < P.min_pts;
-    if (whole) {
+    // blockIdx.z = part of the list this wave copies (long lists -- dense clouds have bins of 10^4 points -- are
+    // dealt out in blocks of 512 entries to gridDim.z waves; eight loads in flight per lane)
+    const unsigned part = blockIdx.z, parts = gridDim.z;
+    constexpr int kU = 8;
+    if (whole) {  // (the out-of-range pseudo-bin of a sensor that sees beyond max_range holds 10^5 points)
         const int *src = Bt.sorted_idx + fd.sbase + off;
-        for (unsigned i = threadIdx.x; i < n; i += kEmitBlock) out[da + i] = src[i];
+        for (unsigned i0 = part * (kU * kEmitBlock) + threadIdx.x; i0 < n; i0 += parts * (kU * kEmitBlock)) {
+            int v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) v[u] = i0 + u * kEmitBlock < n ? src[i0 + u * kEmitBlock] : 0;
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if (i0 + u * kEmitBlock < n) out[da + i0 + u * kEmitBlock] = v[u];
+        }
         return;
     }
     const int *src = Bt.plist + fd.sbase + off;
     const unsigned ng = (unsigned)Bt.recs[(size_t)f * B + seg].n_ground;
     const unsigned db = Bt.dst_b[(size_t)f * NB + seg];
-    for (unsigned i0 = threadIdx.x; i0 < n; i0 += 4 * kEmitBlock) {  // four loads in flight per thread
-        int v[4];
+    for (unsigned i0 = part * (kU * kEmitBlock) + threadIdx.x; i0 < n; i0 += parts * (kU * kEmitBlock)) {
+        int v[kU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kU; ++u) {
             const unsigned i = i0 + u * kEmitBlock;
             v[u] = i < n ? src[i] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kU; ++u) {
             const unsigned i = i0 + u * kEmitBlock;
             if (i < n) {
                 if (i < ng)
@@ -1595,7 +1606,7 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     else
         hipLaunchKernelGGL(k_gle_tgr<false>, dim3(F), dim3(kBlock), 0, stream, B);
     if (ev) (void)hipEventRecord(ev[10], stream);
-    hipLaunchKernelGGL(k_emit, dim3(NB, F), dim3(kEmitBlock), 0, stream, B, order_a != nullptr);
+    hipLaunchKernelGGL(k_emit, dim3(NB, F, B.emit_parts > 1 ? B.emit_parts : 1), dim3(kEmitBlock), 0, stream, B, order_a != nullptr);
     if (ev) (void)hipEventRecord(ev[11], stream);
     if (order_a) {
         hipLaunchKernelGGL((k_order_sublists<64, 256, 0>), dim3(NB, F), dim3(64), 0, stream, B, order_a, order_b);
