@@ -100,9 +100,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    world, rank, local_rank = pwpp_dist.init("nccl", dev)  # RCCL; no-op for a single process
+    # Test hooks for the N > 1 code path where only one GPU can be leased (tests/test_gpu_parity.py::
+    # test_bench_two_ranks_on_one_gpu): PWPP_BENCH_SHARE_DEVICE=1 puts every rank on GPU 0, PWPP_BENCH_BACKEND=gloo
+    # replaces RCCL (two ranks cannot share a GPU under RCCL).  The driver's runs use neither.
+    gpu_index = 0 if os.environ.get("PWPP_BENCH_SHARE_DEVICE") else local_rank
+    backend = os.environ.get("PWPP_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
+    world, rank, local_rank = pwpp_dist.init(backend, dev)  # "nccl" = RCCL over xGMI; no-op for a single process
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d was started as %d process(es): launch it with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
 
     import pwpp_hip
 
@@ -123,7 +131,7 @@ def main():
     if args.workload == "dense":  # BASELINE.json configs[4]: 36-sector CZM
         for k in range(4):
             params.num_sectors_each_zone[k] = 36
-    h = pwpp_hip.Handle(params, device=local_rank)
+    h = pwpp_hip.Handle(params, device=gpu_index)
     batch = h.make_device_batch(ptrs, ns)
 
     def step():
@@ -157,7 +165,7 @@ def main():
     torch.cuda.synchronize()
     pwpp_dist.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed, total_frames = pwpp_dist.aggregate(elapsed, F * args.steps, dev)  # MAX time, SUM frames over ranks
+    elapsed, total_frames = pwpp_dist.aggregate(elapsed, F * args.steps, dev if backend == "nccl" else None)  # MAX time, SUM frames over ranks
     if not args.no_profile_events:  # kernel times of the single-stream schedule, outside the timed region
         h.set_profiling(True)
         h.reset_kernel_profile()

@@ -33,7 +33,17 @@ int main(int argc, char **argv) {
         for (int i = 0; i < ground.rows(); ++i) aligned = aligned && ground(i, 2) == cloud(ground_idx(i), 2);
         std::printf("Origianl Points  #: %d\nGround Points    #: %d\nNonground Points #: %d\npatches: %d idxsum: %lld aligned: %d\n",
                     (int)cloud.rows(), (int)ground.rows(), (int)nonground.rows(), (int)centers.rows(), s, aligned ? 1 : 0);
-        (void)nonground_idx; (void)normals;
+        // expressions that only compile when the getters return real Eigen objects (proxies did not)
+        auto nrm = Patchworkpp.getNormals();
+        const float nz0 = nrm.col(2)(0);
+        const float x0 = Patchworkpp.getGround().row(0)(0);
+        const auto gt = Patchworkpp.getGround().transpose();
+        std::printf("eigen expressions: nz0 %s normals(0,2), x0 %s ground(0,0), transpose %dx%d\n", nz0 == normals(0, 2) ? "==" : "!=",
+                    x0 == ground(0, 0) ? "==" : "!=", (int)gt.rows(), (int)gt.cols());
+        patchwork_parameters.verbose = true;  // the reference's "Time taken : ..." line (patchworkpp.cpp:323-333)
+        patchwork::PatchWorkpp verbose_one(patchwork_parameters);
+        verbose_one.estimateGround(cloud);
+        (void)nonground_idx;
     } catch (const std::exception &e) { std::printf("error: %s\n", e.what()); return 1; }
     return 0;
 }

@@ -5,10 +5,13 @@
 //   patchwork::Params        (:42-112)  same field names, types and defaults
 //   patchwork::PatchWorkpp   (:114-163) same constructor, estimateGround(), and getters
 // so that code written against the reference header compiles against this one (see
-// INTEGRATION.md).  Eigen is optional here: the container/no-network build has none, so the
-// primary overloads take raw pointers and return small row-major containers; when
-// <Eigen/Dense> is available the reference's exact signatures are provided on top
-// (Eigen::MatrixXf in, Eigen::MatrixX3f / Eigen::VectorXi out).
+// INTEGRATION.md).  Eigen is optional here (the container / no-network build has none):
+//  * with <Eigen/Dense> on the include path the class has the reference's EXACT signatures --
+//    estimateGround(Eigen::MatrixXf), getGround() etc. return real Eigen::MatrixX3f / Eigen::VectorXi
+//    objects, so `pw.getGround().row(i)`, `.transpose()`, `auto g = pw.getNormals(); g.col(2)` compile
+//    as against the reference;
+//  * without it (or with PWPP_NO_EIGEN) the getters return the small row-major containers below and
+//    estimateGround takes a raw pointer.
 //
 // Differences a caller can observe, all documented in DESIGN.md section 6:
 //  * index and point lists hold the same SETS as the reference, ordered by the device
@@ -197,7 +200,9 @@ public:
 
     // estimateGround, reference patchworkpp.cpp:151.  `data` is rows x cols float32, cols = 3 or 4.
     void estimateGround(const float *data, int rows, int cols, bool row_major = true) {
+        if (params_.verbose) check(pwpp_set_profiling(h_, 1));
         check(pwpp_estimate_ground(h_, data, rows, cols, row_major ? PWPP_LAYOUT_ROW_MAJOR : PWPP_LAYOUT_COL_MAJOR));
+        if (params_.verbose) report_times();
     }
 #ifdef PWPP_HAVE_EIGEN
     void estimateGround(Eigen::MatrixXf cloud_in) {  // the reference's exact signature
@@ -211,12 +216,27 @@ public:
     // patchworkpp.cpp:199) instead of the scatter order; same sets either way (pwpp.h, pwpp_set_output_order)
     void setReferenceOrder(bool on) { check(pwpp_set_output_order(h_, on ? PWPP_ORDER_REFERENCE : PWPP_ORDER_SCATTER)); }
 
+#ifdef PWPP_HAVE_EIGEN
+    // the reference's return types (fresh objects on every call, as the reference's toEigenCloud / toIndices, :8-26)
+    Eigen::MatrixX3f getGround() { return to_eigen(xyz(true)); }               // reference :157
+    Eigen::MatrixX3f getNonground() { return to_eigen(xyz(false)); }           // reference :158
+    Eigen::VectorXi getGroundIndices() { return to_eigen(idx(true)); }         // reference :159
+    Eigen::VectorXi getNongroundIndices() { return to_eigen(idx(false)); }     // reference :160
+    Eigen::MatrixX3f getCenters() { return to_eigen(rows(true)); }             // reference :162
+    Eigen::MatrixX3f getNormals() { return to_eigen(rows(false)); }            // reference :163
+#else
     Cloud getGround() { return xyz(true); }          // reference :157
     Cloud getNonground() { return xyz(false); }      // reference :158
     Indices getGroundIndices() { return idx(true); }      // reference :159
     Indices getNongroundIndices() { return idx(false); }  // reference :160
     Cloud getCenters() { return rows(true); }        // reference :162
     Cloud getNormals() { return rows(false); }       // reference :163
+#endif
+    // the same results as plain containers, whatever the build (row-major (rows, 3) floats / int32)
+    Cloud groundCloud() { return xyz(true); }
+    Cloud nongroundCloud() { return xyz(false); }
+    Indices groundIndexList() { return idx(true); }
+    Indices nongroundIndexList() { return idx(false); }
 
     pwpp_handle *handle() { return h_; }  // escape hatch to the batch API of include/pwpp.h
 
@@ -224,8 +244,33 @@ private:
     patchwork::Params params_;
     pwpp_handle *h_;
 
+#ifdef PWPP_HAVE_EIGEN
+    static Eigen::MatrixX3f to_eigen(const Cloud &c) {
+        Eigen::MatrixX3f m(c.rows(), 3);
+        for (int i = 0; i < c.rows(); ++i)
+            for (int j = 0; j < 3; ++j) m(i, j) = c(i, j);
+        return m;
+    }
+    static Eigen::VectorXi to_eigen(const Indices &v) {
+        Eigen::VectorXi m(v.rows());
+        for (int i = 0; i < v.rows(); ++i) m(i) = v(i);
+        return m;
+    }
+#endif
     static void check(int rc) {
         if (rc < 0) throw std::runtime_error(std::string("patchworkpp (HIP): ") + pwpp_last_error());
+    }
+    // the reference's verbose lines (patchworkpp.cpp:323-335), with GPU times: czm = binning kernels, sort = 0 (this
+    // design has no sort), pca = the fit kernels, estimate = GLE / TGR + the index lists
+    void report_times() {
+        double ms[PWPP_NUM_KERNELS];
+        int64_t launches[PWPP_NUM_KERNELS];
+        check(pwpp_get_kernel_profile(h_, ms, launches));
+        check(pwpp_reset_kernel_profile(h_));
+        const double czm = ms[0] + ms[1] + ms[2], pca = ms[3] + ms[4] + ms[5] + ms[6] + ms[7] + ms[8], est = ms[9] + ms[10];
+        std::cout << "Time taken : " << pwpp_get_time_us(h_) / 1e6 << "(sec) ~ " << czm / 1e3 << "(czm) + " << 0.0 << "(sort) + "
+                  << pca / 1e3 << "(pca) + " << est / 1e3 << "(estimate)" << std::endl;
+        std::cout << "\033[1;32m" << "PatchWorkpp::estimateGround() - Estimation is finished !" << "\033[0m" << std::endl;
     }
     void counts(int32_t &g, int32_t &n, int32_t &p) { check(pwpp_get_counts(h_, 0, &g, &n, &p)); }
     Cloud xyz(bool ground) {
