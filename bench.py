@@ -132,6 +132,7 @@ def main():
         for k in range(4):
             params.num_sectors_each_zone[k] = 36
     h = pwpp_hip.Handle(params, device=gpu_index)
+    h.set_overlap(not args.no_overlap)
     batch = h.make_device_batch(ptrs, ns)
 
     def step():
@@ -154,9 +155,6 @@ def main():
     # The timed region runs the library's default schedule (overlap mode for batches of 128+ frames) with no
     # profiling events in it; the per-kernel times and the roofline line come from a SEPARATE single-stream pass
     # after the timed region (HIP events around every launch would serialise the two frame ranges).
-    h.set_overlap(not args.no_overlap)
-    for _ in range(2):
-        step()
     pwpp_dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

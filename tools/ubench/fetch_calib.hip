@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void k_read(const T *p, size_t n, T *sink) {
         unsigned char *b = reinterpret_cast<unsigned char *>(&acc);
         for (unsigned k = 0; k < sizeof(T); ++k) b[k] ^= a[k];
     }
-    if (reinterpret_cast<unsigned char *>(&acc)[0] == 0x5a && threadIdx.x == 1234567) *sink = acc;
+    if (reinterpret_cast<unsigned char *>(&acc)[0] == 0x5a) sink[blockIdx.x & 1] = acc;  // (data dependent: the loads stay)
 }
 __global__ __launch_bounds__(256) void k_read_4_8(const float *z, const float2 *xy, size_t n, float *sink) {
     float acc = 0.f;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_read_4_8(const float *z, const float2 *
         const float2 v = xy[i];
         acc += z[i] + v.x + v.y;
     }
-    if (acc == 1.2345f) *sink = acc;
+    if (acc == 1.2345f) sink[blockIdx.x & 1] = acc;
 }
 template <class T>
 __global__ __launch_bounds__(256) void k_write(T *p, size_t n, T v) {
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void k_write(T *p, size_t n, T v) {
 int main() {
     const size_t bytes = (size_t)1 << 30;
     void *buf, *sink;
-    if (hipMalloc(&buf, bytes) != hipSuccess || hipMalloc(&sink, 64) != hipSuccess) return 1;
+    if (hipMalloc(&buf, bytes) != hipSuccess || hipMalloc(&sink, 256) != hipSuccess) return 1;
     (void)hipMemset(buf, 1, bytes);
     const dim3 g(256 * 16), b(256);
     hipLaunchKernelGGL(k_read<float>, g, b, 0, 0, (const float *)buf, bytes / 4, (float *)sink);
