@@ -21,7 +21,8 @@
 #include "pwpp_dev.h"
 
 extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
-                                    hipEvent_t aux_fork, hipEvent_t aux_join, unsigned long long *order_a, unsigned long long *order_b);
+                                    hipEvent_t aux_fork, hipEvent_t aux_join, unsigned long long *order_a, unsigned long long *order_b,
+                                    int stages);
 extern "C" int pwpp_launch_clear(const PwppBatch *batch, hipStream_t stream);
 extern "C" int pwpp_launch_histogram(const PwppBatch *batch, hipStream_t stream);
 extern "C" int pwpp_launch_gather_xyz(const PwppFrameDesc *fd, const int *idx, int count, float *out, hipStream_t stream);
@@ -106,8 +107,13 @@ struct pwpp_handle {
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;  // second stream for the latency plan (few frames)
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
-    bool overlap = true;   // pwpp_set_overlap: big batches as frame ranges on the two streams (default on)
-    int overlap_ranges = 2;
+    bool overlap = true;   // pwpp_set_overlap: big batches as a pipeline of frame ranges over the two streams (default on)
+    int overlap_ranges = 2;  // (more ranges were slower at every setting tried: each range's fit kernels end with the tail of their
+                             // longest waves -- DESIGN.md section 9)
+    int overlap_mode = 1;  // option "overlap_mode": 1 = memory stream / fit stream pipeline, 0 = whole ranges alternating between the streams
+    std::vector<hipEvent_t> ev_ranges;  // two per frame range: binned, fitted
+    int num_fit_streams = 2;            // option "fit_streams": streams the ranges' fit stages are dealt to (aux_stream + extra_streams)
+    std::vector<hipStream_t> extra_streams;
     // tuning / test options (pwpp_set_option; the PWPP_* environment variables are read ONCE, in pwpp_create)
     int debug_flags = 0;
     std::string fit_plan;
@@ -151,14 +157,16 @@ struct pwpp_handle {
     DevBuf<float2> d_sorted_xy;
     DevBuf<int> d_sorted_idx;
     DevBuf<float2> d_bin_origin;  // [B] origins of the fixed-point plane-fit sums
+    DevBuf<float4> d_bin_bbox;    // [B] {xmin, xmax, ymin, ymax} of every bin (the fit kernels' skip test of the high parts)
     DevBuf<int32_t> d_plist;
     DevBuf<int32_t> d_out;
     DevBuf<unsigned long long> d_ord_a, d_ord_b;  // scratch of the reference-order mode (long sub-lists)
     int output_order = PWPP_ORDER_SCATTER;
-    DevBuf<uint32_t> d_bins;  // 5 slabs of frames*(B+2): count, off, cursor, dst_a, dst_b
+    DevBuf<uint32_t> d_bins;   // 4 slabs of frames*(B+2): bin_count, bin_off, dst_a, dst_b
+    DevBuf<uint32_t> d_parts;  // 3 slabs of frames*(2B+2): part_count, part_off, part_cursor (pwpp_dev.h: a bin is stored in two parts)
     DevBuf<uint32_t> d_cls_start;  // frames * 8
-    DevBuf<uint32_t> d_cap_off;    // B + 3 segment starts of the one-pass path
-    DevBuf<uint32_t> d_bin_max;    // B + 2: largest count of every bin so far (k_czm_scan)
+    DevBuf<uint32_t> d_cap_off;    // 2B + 3 segment starts of the one-pass path (one segment per part)
+    DevBuf<uint32_t> d_bin_max;    // 2B + 2: largest count of every part so far (k_czm_scan)
     std::vector<uint32_t> observed, cap_table;  // host copies: d_bin_max as last read; capacities of the table on the device
     bool have_observation = false, table_stale = true;
     DevBuf<PwppFrameDesc> d_frames_probe;
@@ -216,6 +224,34 @@ void fxp_geometry(const PwppDevParams &d, std::vector<float2> &origin, int &shif
     int s = 21;
     while (s > 0 && (rmax + 0.01) * (double)(1 << s) > 67108864.0) --s;
     shift = s;
+}
+
+// Bounding box {xmin, xmax, ymin, ymax} of every bin: an annular sector reaches its extremes at its four corners or where
+// it crosses an axis.  A little generous (1e-4 of the radius + 1 mm; the binning itself decides in double, and a point on
+// the positive x axis belongs to the LAST sector, patchworkpp.cpp:570): the fit kernels only use it to prove that no point
+// of a bin's high part can lie below a plane (stage_needs_hi, pwpp_fit.hip), so too large is safe and too small is not.
+void bin_boxes(const PwppDevParams &d, std::vector<float4> &box) {
+    box.clear();
+    for (int z = 0; z < 4; ++z)
+        for (int r = 0; r < d.rings[z]; ++r)
+            for (int k = 0; k < d.sectors[z]; ++k) {
+                const double r0 = d.min_ranges[z] + r * d.ring_sizes[z];
+                const double r1 = (r == d.rings[z] - 1) ? (z == 3 ? d.max_range : d.min_ranges[z + 1]) : r0 + d.ring_sizes[z];
+                const double t0 = k * d.sector_sizes[z], t1 = (k == d.sectors[z] - 1) ? 2 * M_PI : (k + 1) * d.sector_sizes[z];
+                std::vector<double> th = {t0, t1};
+                for (int q = 0; q <= 4; ++q)
+                    if (q * (M_PI / 2) > t0 && q * (M_PI / 2) < t1) th.push_back(q * (M_PI / 2));
+                double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+                for (double t : th)
+                    for (double rr : {std::min(r0, r1), std::max(r0, r1)}) {
+                        xmin = std::min(xmin, rr * std::cos(t));
+                        xmax = std::max(xmax, rr * std::cos(t));
+                        ymin = std::min(ymin, rr * std::sin(t));
+                        ymax = std::max(ymax, rr * std::sin(t));
+                    }
+                const double m = 1e-4 * std::max(r0, r1) + 1e-3;
+                box.push_back(make_float4((float)(xmin - m), (float)(xmax + m), (float)(ymin - m), (float)(ymax + m)));
+            }
 }
 
 int build_dev_params(const pwpp_params &p, PwppDevParams &d) {
@@ -338,7 +374,7 @@ int grow_stream_histories(pwpp_handle *h, int new_cap) {
 // path, whose counts enter d_bin_max, and the table is rebuilt.
 int build_capacity_table(pwpp_handle *h, int max_n) {
     const PwppDevParams &P = h->dp;
-    const int B = P.num_bins, NB = B + 2;
+    const int NB = PWPP_NUM_PARTS(P.num_bins);  // one segment per part
     const double scale = 1.5 * h->one_pass_scale / 4.0;
     std::vector<uint32_t> off((size_t)NB + 1);
     h->cap_table.assign((size_t)NB, 0u);
@@ -347,7 +383,8 @@ int build_capacity_table(pwpp_handle *h, int max_n) {
         off[(size_t)b] = (uint32_t)run;
         double cap = scale * (double)h->observed[(size_t)b] + (h->one_pass_scale >= 1.0 ? 256.0 : 16.0);
         if (cap > (double)max_n + 16.0) cap = (double)max_n + 16.0;
-        const uint64_t c = ((uint64_t)cap + 15u) & ~(uint64_t)15u;
+        uint64_t c = ((uint64_t)cap + 15u) & ~(uint64_t)15u;
+        if (b < 2 * P.num_bins && (b & 1) && b / 2 >= P.split_end) c = 0;  // the high part of a bin that is not split: never used
         h->cap_table[(size_t)b] = (uint32_t)c;
         run += c;
         if (run >= ((uint64_t)1 << 32)) return fail(PWPP_E_NOMEM, "one-pass capacity table overflows 32-bit offsets");
@@ -365,7 +402,7 @@ int build_capacity_table(pwpp_handle *h, int max_n) {
 void fill_batch(pwpp_handle *h, PwppBatch &bt);
 
 int read_observed(pwpp_handle *h) {
-    const size_t NB = (size_t)h->dp.num_bins + 2;
+    const size_t NB = (size_t)PWPP_NUM_PARTS(h->dp.num_bins);
     h->observed.resize(NB);
     HIPCHK(hipMemcpy(h->observed.data(), h->d_bin_max.p, NB * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return PWPP_OK;
@@ -422,18 +459,21 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
         bt.st_hist = h->d_hist_stream.p;
     }
     bt.codes = h->d_codes.p;
-    const size_t slab = (size_t)h->frames * NB;
+    const size_t slab = (size_t)h->frames * NB, pslab = (size_t)h->frames * PWPP_NUM_PARTS(B);
     bt.bin_count = h->d_bins.p;
     bt.bin_off = h->d_bins.p + slab;
-    bt.bin_cursor = h->d_bins.p + 2 * slab;
-    bt.dst_a = h->d_bins.p + 3 * slab;
-    bt.dst_b = h->d_bins.p + 4 * slab;
+    bt.dst_a = h->d_bins.p + 2 * slab;
+    bt.dst_b = h->d_bins.p + 3 * slab;
+    bt.part_count = h->d_parts.p;
+    bt.part_off = h->d_parts.p + pslab;
+    bt.part_cursor = h->d_parts.p + 2 * pslab;
     bt.cls_start = h->d_cls_start.p;
     bt.cls_list = h->d_cls_list.p;
     bt.sorted_z = h->d_sorted_z.p;
     bt.sorted_xy = h->d_sorted_xy.p;
     bt.sorted_idx = h->d_sorted_idx.p;
     bt.bin_origin = h->d_bin_origin.p;
+    bt.bin_bbox = h->d_bin_bbox.p;
     bt.plist = h->d_plist.p;
     bt.recs = h->d_recs.p;
     bt.out_idx = h->d_out.p;
@@ -445,8 +485,11 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
 
     bt.bin_max = h->d_bin_max.p;
     {   // k_emit: one wave per bin copies a list of a few thousand entries well; the bins of a dense cloud get more
-        uint32_t biggest = 0;
-        for (size_t b = 0; b < h->observed.size(); ++b) biggest = h->observed[b] > biggest ? h->observed[b] : biggest;  // (pseudo-bins included)
+        uint32_t biggest = 0;  // (observed: per part; a bin's two parts are neighbours, the pseudo-bins the last two entries)
+        for (size_t b = 0; b + 1 < h->observed.size(); b += 2) {
+            const uint32_t both = b < 2 * (size_t)B ? h->observed[b] + h->observed[b + 1] : (h->observed[b] > h->observed[b + 1] ? h->observed[b] : h->observed[b + 1]);
+            biggest = both > biggest ? both : biggest;
+        }
         const int parts = (int)(biggest / 8192u) + 1;
         bt.emit_parts = parts > 8 ? 8 : parts;
     }
@@ -455,14 +498,14 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
 // Launches the pipeline over the batch described by h->descs (buffers sized, inputs on the device).
 // one_pass: fixed bin segments (k_czm_bin_scatter); otherwise the exact two-pass binning.
 int launch_prepared(pwpp_handle *h, bool one_pass) {
-    const int B = h->dp.num_bins, NB = B + 2;
+    const int B = h->dp.num_bins, NB = B + 2, NP = PWPP_NUM_PARTS(B);
     const int frames = h->frames;
     // where a frame's bins live in the bin-ordered buffers
     int64_t base = 0;
     for (int f = 0; f < frames; ++f) {
         PwppFrameDesc &d = h->descs[(size_t)f];
         d.sbase = one_pass ? (int64_t)f * h->slots_per_frame : base;
-        base += ((int64_t)d.n + 3 * (int64_t)NB + 3) & ~(int64_t)3;  // compact layout: every bin starts at a multiple of four slots (k_czm_scan)
+        base += ((int64_t)d.n + 3 * (int64_t)NP + 3) & ~(int64_t)3;  // compact layout: every part starts at a multiple of four slots (k_czm_scan)
     }
     // the descriptors on the device are reused when nothing changed (a caller cycling through the same
     // device buffers, a replayed batch): one host-to-device copy less in front of the first kernel
@@ -501,7 +544,9 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
             v.no_clear = 1;
             v.bin_count += (size_t)f0 * NB;
             v.bin_off += (size_t)f0 * NB;
-            v.bin_cursor += (size_t)f0 * NB;
+            v.part_count += (size_t)f0 * NP;
+            v.part_off += (size_t)f0 * NP;
+            v.part_cursor += (size_t)f0 * NP;
             v.dst_a += (size_t)f0 * NB;
             v.dst_b += (size_t)f0 * NB;
             v.cls_start += (size_t)f0 * PWPP_CLS_STRIDE;
@@ -513,37 +558,82 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
             v.results_host += f0;
             return v;
         };
-        // R frame ranges of whole groups of eight frames (K1' deals frames to the 8 XCDs), alternating between the
-        // two streams: while one range is in its plane fits the other one is binning or writing its lists.  Every
-        // range is launched with the fit plan of the WHOLE batch (the machine is shared, not split).
+        // R frame ranges of whole groups of eight frames (K1' deals frames to the 8 XCDs).  Every range is launched
+        // with the fit plan of the WHOLE batch (the machine is shared, not split).
         int R = h->overlap_ranges < 2 ? 2 : h->overlap_ranges;
         while (R > 2 && frames / R < 64) --R;
         static const char *kBigPlan = "W16:1023,W64.2:65535";
         const double eff = (double)frames * (double)h->max_n / 125000.0;
         if (!bt.fit_plan && eff > 640.0) bt.fit_plan = kBigPlan;
-        lrc = pwpp_launch_clear(&bt, h->stream);
-        HIPCHK(hipEventRecord(h->aux_fork, h->stream));
-        HIPCHK(hipStreamWaitEvent(h->aux_stream, h->aux_fork, 0));
-        int f0 = 0;
-        for (int r = 0; r < R && lrc == 0; ++r) {
-            int f1 = r == R - 1 ? frames : (int)(((int64_t)frames * (r + 1) / R + 7) / 8 * 8);
-            if (f1 > frames) f1 = frames;
-            if (f1 > f0) {
-                const PwppBatch v = range(f0, f1 - f0);
-                lrc = pwpp_launch_pipeline(&v, (r & 1) ? h->aux_stream : h->stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-            }
-            f0 = f1;
+        std::vector<int> first((size_t)R + 1, 0);
+        for (int r = 1; r <= R; ++r) {
+            int f1 = r == R ? frames : (int)(((int64_t)frames * r / R + 7) / 8 * 8);
+            first[(size_t)r] = f1 > frames ? frames : f1;
         }
-        HIPCHK(hipEventRecord(h->aux_join, h->aux_stream));
-        HIPCHK(hipStreamWaitEvent(h->stream, h->aux_join, 0));
+        lrc = pwpp_launch_clear(&bt, h->stream);
+        if (h->overlap_mode == 1) {
+            // A software pipeline over the two streams: the MEMORY stream bins range r + 2 and then writes the lists of
+            // range r, the FIT stream runs the plane fits (and K5) of range r + 1 meanwhile -- the streams never run the
+            // same kind of stage at the same time (two whole-range pipelines side by side start in lock step: both
+            // binning, then both fitting).  Events: range binned -> its fits may start; range fitted -> its lists.
+            while (h->ev_ranges.size() < 2 * (size_t)R) {
+                hipEvent_t e = nullptr;
+                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                h->ev_ranges.push_back(e);
+            }
+            auto stage = [&](int r, int stages, hipStream_t st) {
+                if (lrc != 0 || first[(size_t)r + 1] <= first[(size_t)r]) return;
+                const PwppBatch v = range(first[(size_t)r], first[(size_t)r + 1] - first[(size_t)r]);
+                lrc = pwpp_launch_pipeline(&v, st, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stages);
+            };
+            // (the fit stages go round a few streams: a fit kernel ends with the tail of its longest waves, and the next
+            // range's kernels fill the machine meanwhile)
+            while ((int)h->extra_streams.size() + 1 < h->num_fit_streams) {
+                hipStream_t st = nullptr;
+                HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                h->extra_streams.push_back(st);
+            }
+            hipStream_t mem = h->stream;
+            auto bin = [&](int r) {
+                const int k = r % h->num_fit_streams;
+                hipStream_t fit = k == 0 ? h->aux_stream : h->extra_streams[(size_t)k - 1];
+                stage(r, 1, mem);
+                (void)hipEventRecord(h->ev_ranges[2 * (size_t)r], mem);
+                (void)hipStreamWaitEvent(fit, h->ev_ranges[2 * (size_t)r], 0);
+                stage(r, 2, fit);
+                (void)hipEventRecord(h->ev_ranges[2 * (size_t)r + 1], fit);
+            };
+            auto lists = [&](int r) {
+                (void)hipStreamWaitEvent(mem, h->ev_ranges[2 * (size_t)r + 1], 0);
+                stage(r, 4, mem);
+            };
+            bin(0);
+            if (R > 1) bin(1);
+            for (int r = 0; r < R; ++r) {
+                lists(r);
+                if (r + 2 < R) bin(r + 2);
+            }
+            // (the memory stream ends with the lists of the last range, which wait for its fits: h->stream is the join)
+        } else {
+            // whole ranges alternating between the two streams
+            HIPCHK(hipEventRecord(h->aux_fork, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->aux_stream, h->aux_fork, 0));
+            for (int r = 0; r < R && lrc == 0; ++r)
+                if (first[(size_t)r + 1] > first[(size_t)r]) {
+                    const PwppBatch v = range(first[(size_t)r], first[(size_t)r + 1] - first[(size_t)r]);
+                    lrc = pwpp_launch_pipeline(&v, (r & 1) ? h->aux_stream : h->stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 7);
+                }
+            HIPCHK(hipEventRecord(h->aux_join, h->aux_stream));
+            HIPCHK(hipStreamWaitEvent(h->stream, h->aux_join, 0));
+        }
     } else {
         lrc = pwpp_launch_pipeline(&bt, h->stream, h->profiling ? h->ev_k : nullptr, h->aux_stream, h->aux_fork, h->aux_join,
-                                   ordered ? h->d_ord_a.p : nullptr, ordered ? h->d_ord_b.p : nullptr);
+                                   ordered ? h->d_ord_a.p : nullptr, ordered ? h->d_ord_b.p : nullptr, 7);
     }
     if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
     if (one_pass)  // the bins' largest counts, for the segment sizes of the next batches (finish_pending)
-        HIPCHK(hipMemcpyAsync(h->h_bin_max.p, h->d_bin_max.p, (size_t)NB * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_bin_max.p, h->d_bin_max.p, (size_t)NP * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     h->profile_pending = h->profiling;
     h->one_pass = one_pass;
     g_slot0_one_pass = one_pass;
@@ -707,6 +797,10 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
     std::vector<float2> origin;
     fxp_geometry(dp, origin, dp.fxp_shift);
     dp.fxp_zr = (float)(67108864.0 / (double)(1 << dp.fxp_shift));
+    std::vector<float4> boxes;
+    bin_boxes(dp, boxes);
+    dp.hi_split = 0.6f;  // option "hi_split"
+    dp.split_end = dp.bin_base[1];  // option "hi_split_zones": the zones whose bins are stored in two parts (default: the first)
     pwpp_handle *h = new pwpp_handle;
     h->params = *p;
     h->dp = dp;
@@ -718,17 +812,22 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
     h->no_one_pass = std::getenv("PWPP_NO_ONE_PASS") != nullptr;
     if (const char *e = std::getenv("PWPP_ONE_PASS_MIN_FRAMES")) h->one_pass_min_frames = std::atoi(e);
     if (const char *e = std::getenv("PWPP_OVERLAP_RANGES")) h->overlap_ranges = std::atoi(e) < 2 ? 2 : std::atoi(e);
+    if (const char *e = std::getenv("PWPP_OVERLAP_MODE")) h->overlap_mode = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PWPP_FIT_STREAMS")) h->num_fit_streams = std::atoi(e) < 1 ? 1 : (std::atoi(e) > 8 ? 8 : std::atoi(e));
+    if (const char *e = std::getenv("PWPP_HI_SPLIT")) h->dp.hi_split = (float)std::atof(e);
+    if (const char *e = std::getenv("PWPP_HI_SPLIT_ZONES")) h->dp.split_end = h->dp.bin_base[std::atoi(e) < 0 ? 0 : (std::atoi(e) > 4 ? 4 : std::atoi(e))];
     if (const char *e = std::getenv("PWPP_ONE_PASS_SCALE")) {
         const double v = std::atof(e);
         if (v > 0.0 && v <= 1024.0) h->one_pass_scale = v;
         else std::fprintf(stderr, "pwpp: ignoring PWPP_ONE_PASS_SCALE=%s (a positive number up to 1024 expected)\n", e);
     }
     if (h->debug_flags || !h->fit_plan.empty() || h->fit_concurrent || h->no_one_pass || std::getenv("PWPP_ONE_PASS_MIN_FRAMES") ||
-        std::getenv("PWPP_ONE_PASS_SCALE") || std::getenv("PWPP_OVERLAP") || std::getenv("PWPP_OVERLAP_RANGES"))
+        std::getenv("PWPP_ONE_PASS_SCALE") || std::getenv("PWPP_OVERLAP") || std::getenv("PWPP_OVERLAP_RANGES") || std::getenv("PWPP_HI_SPLIT") ||
+        std::getenv("PWPP_HI_SPLIT_ZONES"))
         std::fprintf(stderr, "pwpp: tuning options taken from the environment (PWPP_*): debug_flags=%d fit_plan='%s' fit_concurrent=%d "
-                             "no_one_pass=%d one_pass_min_frames=%d one_pass_scale=%g overlap=%d\n", h->debug_flags, h->fit_plan.c_str(),
-                     (int)h->fit_concurrent, (int)h->no_one_pass, h->one_pass_min_frames, h->one_pass_scale,
-                     std::getenv("PWPP_OVERLAP") ? std::atoi(std::getenv("PWPP_OVERLAP")) : 1);
+                             "no_one_pass=%d one_pass_min_frames=%d one_pass_scale=%g overlap=%d hi_split=%g (first %d bins)\n", h->debug_flags,
+                     h->fit_plan.c_str(), (int)h->fit_concurrent, (int)h->no_one_pass, h->one_pass_min_frames, h->one_pass_scale,
+                     std::getenv("PWPP_OVERLAP") ? std::atoi(std::getenv("PWPP_OVERLAP")) : 1, (double)h->dp.hi_split, h->dp.split_end);
     const int storage = p->max_elevation_storage > p->max_flatness_storage ? p->max_elevation_storage : p->max_flatness_storage;
     h->stream_hist_cap = storage + max_near_sectors + 1024;
     h->max_pushes_per_frame = max_near_sectors;
@@ -746,9 +845,13 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
         return fail(PWPP_E_HIP, "stream/event creation failed: %s", hipGetErrorString(se));
     }
     int rc = pwpp_set_num_streams(h, 1);
-    if (!rc) rc = h->h_bin_max.ensure((size_t)dp.num_bins + 2);
-    if (!rc) rc = h->d_bin_max.ensure((size_t)dp.num_bins + 2);
-    if (!rc && hipMemset(h->d_bin_max.p, 0, ((size_t)dp.num_bins + 2) * sizeof(uint32_t)) != hipSuccess) rc = fail(PWPP_E_HIP, "hipMemset failed");
+    const size_t NP = (size_t)PWPP_NUM_PARTS(dp.num_bins);
+    if (!rc) rc = h->h_bin_max.ensure(NP);
+    if (!rc) rc = h->d_bin_max.ensure(NP);
+    if (!rc && hipMemset(h->d_bin_max.p, 0, NP * sizeof(uint32_t)) != hipSuccess) rc = fail(PWPP_E_HIP, "hipMemset failed");
+    if (!rc) rc = h->d_bin_bbox.ensure(boxes.size());
+    if (!rc && hipMemcpy(h->d_bin_bbox.p, boxes.data(), boxes.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(PWPP_E_HIP, "uploading the bin boxes failed");
     if (!rc) rc = h->d_bin_origin.ensure(origin.size());
     if (!rc && hipMemcpy(h->d_bin_origin.p, origin.data(), origin.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(PWPP_E_HIP, "uploading the bin origins failed");
@@ -774,6 +877,8 @@ int pwpp_destroy(pwpp_handle *h) {
     h->d_sorted_xy.release();
     h->d_sorted_idx.release();
     h->d_bin_origin.release();
+    h->d_bin_bbox.release();
+    h->d_parts.release();
     h->d_bin_max.release();
     h->h_bin_max.release();
     h->d_frames_probe.release();
@@ -802,6 +907,8 @@ int pwpp_destroy(pwpp_handle *h) {
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     for (int k = 0; k <= PWPP_NUM_KERNELS; ++k)
         if (h->ev_k[k]) (void)hipEventDestroy(h->ev_k[k]);
+    for (hipEvent_t e : h->ev_ranges) (void)hipEventDestroy(e);
+    for (hipStream_t st : h->extra_streams) (void)hipStreamDestroy(st);
     if (h->aux_fork) (void)hipEventDestroy(h->aux_fork);
     if (h->aux_join) (void)hipEventDestroy(h->aux_join);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
@@ -868,7 +975,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     if (mode == PWPP_MODE_STREAMS && frames > h->num_streams)
         return fail(PWPP_E_ARG, "%d frames but only %d streams (pwpp_set_num_streams)", frames, h->num_streams);
 
-    const int B = h->dp.num_bins, NB = B + 2;
+    const int B = h->dp.num_bins, NB = B + 2, NP = PWPP_NUM_PARTS(B);
     int64_t total = 0, total_in = 0;
     int max_n = 0;
     for (int f = 0; f < frames; ++f) {
@@ -893,7 +1000,8 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
         if ((rc = h->d_ord_a.ensure(tp))) return rc;
         if ((rc = h->d_ord_b.ensure(tp))) return rc;
     }
-    if ((rc = h->d_bins.ensure((size_t)frames * NB * 5))) return rc;
+    if ((rc = h->d_bins.ensure((size_t)frames * NB * 4))) return rc;
+    if ((rc = h->d_parts.ensure((size_t)frames * NP * 3 + 4))) return rc;  // (+4: k_clear zeroes whole 16-byte words)
     if ((rc = h->d_recs.ensure((size_t)frames * B))) return rc;
     if ((rc = h->d_cls_start.ensure((size_t)frames * PWPP_CLS_STRIDE))) return rc;
     if ((rc = h->d_cls_list.ensure((size_t)frames * B))) return rc;
@@ -964,13 +1072,13 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     // bin-ordered buffers hold frames x slots_per_frame records instead of one per point.  Used when the memory
     // is there; any overflow is caught when the batch lands and the batch is redone exactly.
     bool one_pass = false;
-    const size_t compact_slots = tp + (size_t)frames * (size_t)(3 * NB + 4);  // bins padded to multiples of four slots
+    const size_t compact_slots = tp + (size_t)frames * (size_t)(3 * NP + 4);  // parts padded to multiples of four slots
     size_t bin_slots = compact_slots;
     if (h->one_pass_holdoff > 0) {
         --h->one_pass_holdoff;
     } else if (!h->no_one_pass && frames >= h->one_pass_min_frames && max_n > 0) {
         if (2 * (int64_t)max_n < h->cap_max_n) {  // a much smaller sensor than the table was built for: start over
-            HIPCHK(hipMemsetAsync(h->d_bin_max.p, 0, (size_t)NB * sizeof(uint32_t), h->stream));
+            HIPCHK(hipMemsetAsync(h->d_bin_max.p, 0, (size_t)NP * sizeof(uint32_t), h->stream));
             h->have_observation = false;
         }
         if (!h->have_observation) {
@@ -1308,10 +1416,33 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
         if (!(v > 0.0 && v <= 1024.0)) return fail(PWPP_E_ARG, "one_pass_scale=%s: a positive number up to 1024 expected", value);
         h->one_pass_scale = v;
         h->table_stale = true;  // rebuild the capacity table
+    } else if (k == "fit_streams") {
+        const int v = std::atoi(value);
+        if (v < 1 || v > 8) return fail(PWPP_E_ARG, "fit_streams=%s: 1..8 expected", value);
+        h->num_fit_streams = v;
+    } else if (k == "overlap_mode") {
+        const int v = std::atoi(value);
+        if (v != 0 && v != 1) return fail(PWPP_E_ARG, "overlap_mode=%s: 0 (whole ranges side by side) or 1 (memory / fit pipeline) expected", value);
+        h->overlap_mode = v;
     } else if (k == "overlap_ranges") {
         const int v = std::atoi(value);
         if (v < 2 || v > 64) return fail(PWPP_E_ARG, "overlap_ranges=%s: 2..64 expected", value);
         h->overlap_ranges = v;
+    } else if (k == "hi_split") {
+        // height over the ground level where the high part of a bin begins (pwpp_dev.h); results never depend on it
+        const double v = std::atof(value);
+        if (!(v >= -1e30 && v <= 1e30)) return fail(PWPP_E_ARG, "hi_split=%s: a number of metres expected (1e30: no high parts)", value);
+        h->dp.hi_split = (float)v;
+        HIPCHK(hipMemsetAsync(h->d_bin_max.p, 0, (size_t)PWPP_NUM_PARTS(h->dp.num_bins) * sizeof(uint32_t), h->stream));
+        h->have_observation = false;  // the parts change: size the one-pass segments anew
+        h->table_stale = true;
+    } else if (k == "hi_split_zones") {
+        const int v = std::atoi(value);
+        if (v < 0 || v > 4) return fail(PWPP_E_ARG, "hi_split_zones=%s: 0..4 expected", value);
+        h->dp.split_end = h->dp.bin_base[v];
+        HIPCHK(hipMemsetAsync(h->d_bin_max.p, 0, (size_t)PWPP_NUM_PARTS(h->dp.num_bins) * sizeof(uint32_t), h->stream));
+        h->have_observation = false;
+        h->table_stale = true;
     } else if (k == "debug_flags") {
         h->debug_flags = std::atoi(value);
     } else {
@@ -1324,7 +1455,7 @@ int64_t pwpp_get_workspace_bytes(pwpp_handle *h) {
     if (!h) return PWPP_E_ARG;
     auto b = [](size_t cap, size_t elt) { return (int64_t)(cap * elt); };
     return b(h->d_in.cap, 4) + b(h->d_codes.cap, 2) + b(h->d_sorted_z.cap, 4) + b(h->d_sorted_xy.cap, 8) + b(h->d_sorted_idx.cap, 4) +
-           b(h->d_plist.cap, 4) + b(h->d_out.cap, 4) + b(h->d_ord_a.cap, 8) + b(h->d_ord_b.cap, 8) + b(h->d_bins.cap, 4) +
+           b(h->d_plist.cap, 4) + b(h->d_out.cap, 4) + b(h->d_ord_a.cap, 8) + b(h->d_ord_b.cap, 8) + b(h->d_bins.cap, 4) + b(h->d_parts.cap, 4) +
            b(h->d_recs.cap, sizeof(PwppPatchRec)) + b(h->d_cls_start.cap, 4) + b(h->d_cls_list.cap, 2) + b(h->d_centers.cap, 4) +
            b(h->d_normals.cap, 4) + b(h->d_xyz.cap, 4) + b(h->d_hist_stream.cap, 8) + b(h->d_hist_fresh.cap, 8) + b(h->d_hist_snap.cap, 8);
 }

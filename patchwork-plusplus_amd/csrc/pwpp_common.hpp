@@ -388,6 +388,11 @@ __device__ __forceinline__ void plane_from_totals_uniform(long long n, const lon
     plane_from_cov(mean, cov, debug, out);
 }
 
+// The height that separates the two parts of a frame's bins (pwpp_dev.h): k_czm_bin / k_czm_bin_scatter compare every z
+// with it, the fit kernels build their skip tests on it.  sensor_height = the frame's state BEFORE this call (K5 updates
+// the state after the fits).
+__device__ __forceinline__ float hi_split_z(const PwppDevParams &P, double sensor_height) { return (float)(-sensor_height + (double)P.hi_split); }
+
 // ref :551-554  (float products, float adds left to right, one double add)
 __device__ __forceinline__ double plane_dist(float nx, float ny, float nz, double d, float x, float y, float z) {
     return nx * x + ny * y + nz * z + d;

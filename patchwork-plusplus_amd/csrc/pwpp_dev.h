@@ -17,6 +17,14 @@
 #define PWPP_CODE_RNR(B) ((B))        // reflected-noise hit      (patchworkpp.cpp:391-396)
 #define PWPP_CODE_OOR(B) ((B) + 1)    // outside (min,max] range  (patchworkpp.cpp:595,618)
 #define PWPP_CODE_DROP 0xFFFFu        // z == FLT_MIN in the input: the reference silently drops it (:591)
+// A bin is stored in two PARTS: the points below the split height (z < -sensor_height + hi_split: the "low" part)
+// and the others (the "high" part: z at or above it, or NaN).  The fit kernels skip the high part of a patch in every
+// pass that provably cannot use it (pwpp_fit.hip).  Parts are numbered in memory order -- the two parts of a bin are
+// neighbours, so a bin's slot range [first slot of its low part, +points of the bin) exists in every layout:
+//   2 b, 2 b + 1   low / high part of bin b;   2 B, 2 B + 1   the two pseudo-bins (RNR hits, out of range)
+#define PWPP_PART_LO(bin) (2 * (bin))
+#define PWPP_PART_HI(bin) (2 * (bin) + 1)
+#define PWPP_NUM_PARTS(B) (2 * (B) + 2)
 
 struct PwppDevParams {
     int32_t enable_RNR, enable_RVPF, enable_TGR;
@@ -32,6 +40,8 @@ struct PwppDevParams {
     int32_t num_bins;     // B
     int32_t fxp_shift;    // s of the plane-fit arithmetic contract
     float fxp_zr;         // 2^(26 - s) metres: a fit's z coordinates are clamped to z0 +- fxp_zr before they are quantised
+    float hi_split;       // metres above the ground level (-sensor_height) where the high part of a bin begins; huge = no high parts
+    int32_t split_end;    // bins [0, split_end) are stored in two parts, the others keep all their points in the low part
     int32_t max_elev_storage, max_flat_storage;
     int32_t hist_cap;     // doubles per (state, which, ring) history slab
     int32_t near_bins;    // bins with concentric_idx < num_rings_of_interest
@@ -53,8 +63,8 @@ struct PwppFrameDesc {
     int32_t step;      // PWPP_LAYOUT_FIELDS: bytes from one point to the next (sensor_msgs/PointCloud2 point_step) ...
     int32_t off[4];    // ... and the byte offsets of x, y, z, intensity inside a point (intensity < 0: none)
     int32_t pad2_[3];
-    int64_t sbase;     // first slot of this frame in the bin-ordered workspaces (sorted_*, plist); == base
-                       // on the two-pass path, frame * slots_per_frame on the one-pass path (see cap_off)
+    int64_t sbase;     // first slot of this frame in the part-ordered buffers (sorted_*, plist): compact on the two-pass
+                       // path, frame * slots_per_frame on the one-pass path (see cap_off)
 };
 
 struct PwppStateScalar {  // = pwpp_state
@@ -74,7 +84,8 @@ struct PwppPatchRec {  // one per (frame, bin); written by k_patch_fit, finished
     int32_t n_points;
     int32_t n_nonground;
     int32_t decision;
-    int32_t valid;  // 0: no fit ran in this bin (empty bin let through by num_min_pts <= 0)
+    int32_t valid;  // 0: no fit ran in this bin (empty bin let through by num_min_pts <= 0); bit 1: the last pass skipped the
+                    // high part (its points are non-ground and have no plist entries: k_emit takes them from sorted_idx)
 };
 
 struct PwppFrameResult {
@@ -96,23 +107,27 @@ struct PwppBatch {
     int32_t debug;               // option "debug_flags": 4 = timing probes of the fit chain, 16 = exact binning only, 16384 / 32768 =
                                  // force the fall-back paths of the lowest-point selection (tests); results never depend on it
     int32_t no_clear;            // the caller already launched k_clear for these frames (overlap mode: two frame ranges, two streams)
-    const uint32_t *cap_off;     // one-pass binning: [B+3] first slot of every bin's fixed segment inside a frame
-                                 // (cap_off[B+2] = slots per frame); null on the two-pass path
+    const uint32_t *cap_off;     // one-pass binning: [2B+3] first slot of every PART's fixed segment inside a frame
+                                 // (cap_off[2B+2] = slots per frame); null on the two-pass path
     PwppStateScalar *st_scalar;  // [num_states]
     double *st_hist;             // [num_states][2][4][hist_cap]
     uint16_t *codes;             // [total points]
-    uint32_t *bin_count;         // [frames][B+2]
-    uint32_t *bin_off;           // [frames][B+2] exclusive scan of bin_count
-    uint32_t *bin_cursor;        // [frames][B+2]
+    uint32_t *part_count;        // [frames][2B+2] points per part (K1 / K1' histogram)
+    uint32_t *part_off;          // [frames][2B+2] first slot of every part in the sorted_* planes (relative to sbase)
+    uint32_t *part_cursor;       // [frames][2B+2] two-pass scatter cursors
+    uint32_t *bin_count;         // [frames][B+2] points per bin = low + high part (K2); what K5 / K6 size the lists with
+    uint32_t *bin_off;           // [frames][B+2] first slot of the bin (= of its low part), relative to sbase
     uint32_t *cls_start;         // [frames][PWPP_CLS_STRIDE] first entry of each size bucket in cls_list
     uint16_t *cls_list;          // [frames][B] patch bins sorted by size bucket
-    float *sorted_z;             // [total points | frames x slots per frame] z of the points grouped by bin.  A NaN z of the cloud is
+    float *sorted_z;             // [total points | frames x slots per frame] z of the points grouped by part.  A NaN z of the cloud is
                                  // stored as 0x7fc00000; 0x7fc00000 | (round + 1) marks a point an R-VPF round removed
     float2 *sorted_xy;           // same slots: {x, y}
     int *sorted_idx;             // same slots: cloud index of the point (read by the last fit pass and K6 only)
-    uint32_t *bin_max;           // [B+2] largest count every bin has had in any frame so far (k_czm_scan): sizes the one-pass segments
+    uint32_t *bin_max;           // [2B+2] largest count every PART has had in any frame so far (k_czm_scan): sizes the one-pass segments
+    const float4 *bin_bbox;      // [B] {xmin, xmax, ymin, ymax} of every bin (a little generous): the skip test of the high parts
     const float2 *bin_origin;    // [B] origin of every bin's fixed-point plane-fit sums (its polar centre rounded to 1/8 m)
-    int32_t *plist;              // [total points] per patch: ground candidates from the front, non-ground from the back
+    int32_t *plist;              // same slots, per patch (from the first slot of its low part): ground candidates from the front,
+                                 // non-ground from the back of the bin's point count
     PwppPatchRec *recs;          // [frames][B]
     uint32_t *dst_a;             // [frames][B+2] output offset of sub-list A (candidates / whole bin)
     uint32_t *dst_b;             // [frames][B+2] output offset of sub-list B (regionwise non-ground)

@@ -228,7 +228,8 @@ __device__ __forceinline__ void ce(unsigned &a, unsigned &b) {
 // ------------------------------------------------------------------------------------------
 enum { ST_VPF = 0, ST_SEED = 1, ST_ITER = 2, ST_LAZY = 3, ST_DONE = 4 };
 
-__device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &pl, unsigned n, unsigned n_ground) {
+// hi_skipped: the pass that wrote the split did not read the high part (its points are non-ground and have no plist entries)
+__device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &pl, unsigned n, unsigned n_ground, bool hi_skipped) {
     rec->mean[0] = pl.mean[0];
     rec->mean[1] = pl.mean[1];
     rec->mean[2] = pl.mean[2];
@@ -243,29 +244,48 @@ __device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &
     rec->n_ground = (int)n_ground;
     rec->n_nonground = (int)(n - n_ground);
     rec->decision = 0;
-    rec->valid = 1;
+    rec->valid = hi_skipped ? 3 : 1;
 }
 
-// a patch in the bin-ordered planes (pwpp_dev.h): z, {x, y}, cloud index
+// A patch in the part-ordered planes (pwpp_dev.h): the FRAME's planes z, {x, y}, cloud index (the frame is a grid
+// dimension, so these are scalar registers and a load is base + 32-bit lane offset) and the slots of the bin's two
+// parts in them -- the points below the split height zs and the others (z >= zs, or NaN).
 struct PatchRef {
     float *z;
     const float2 *xy;
     const int *idx;
+    unsigned off_lo, n_lo, off_hi, n_hi;
 };
-__device__ __forceinline__ PatchRef patch_ref(const PwppBatch &Bt, size_t first) {
-    PatchRef r;
-    r.z = Bt.sorted_z + first;
-    r.xy = Bt.sorted_xy + first;
-    r.idx = Bt.sorted_idx + first;
-    return r;
+// Chunks are numbered through the low part and then through the high part; a pass that skips the high part
+// (stage_needs_hi) simply finds no points in the chunks above the low part's.
+struct PartSel {
+    unsigned off, n, c;  // first slot and points of the part the chunk lies in, chunk index inside that part
+};
+// slot of the i-th point of the patch, low part first (the kernels that walk a patch point by point)
+__device__ __forceinline__ unsigned patch_slot(const PatchRef &p, unsigned i) { return i < p.n_lo ? p.off_lo + i : p.off_hi + (i - p.n_lo); }
+template <int G>
+__device__ __forceinline__ unsigned part_chunks(unsigned n) { return (n + 8u * G - 1u) / (8u * G); }
+template <int G>
+__device__ __forceinline__ unsigned patch_chunks(const PatchRef &p, bool use_hi) {
+    return part_chunks<G>(p.n_lo) + (use_hi ? part_chunks<G>(p.n_hi) : 0u);
+}
+template <int G>
+__device__ __forceinline__ PartSel chunk_sel(const PatchRef &p, unsigned c, bool use_hi, bool on = true) {
+    const unsigned nc_lo = part_chunks<G>(p.n_lo);
+    const bool h = c >= nc_lo;
+    PartSel s;
+    s.off = h ? p.off_hi : p.off_lo;
+    s.n = !on ? 0u : (h ? (use_hi ? p.n_hi : 0u) : p.n_lo);
+    s.c = h ? c - nc_lo : c;
+    return s;
 }
 // R-VPF removes a point from the patch's working set (ref :495-503) by overwriting its z with a NaN whose
 // payload is the R-VPF round (1-based): the coordinates of a removed point are not needed again, and k_czm_*
 // store a NaN z of the cloud as the payload-free 0x7fc00000, so the mark is unambiguous.  The round matters
 // to the reference-order output mode: the reference appends the points a round removes to
 // regionwise_nonground_ round by round (ref :500).
-__device__ __forceinline__ void strip_point(const PatchRef &pr, unsigned i, int round) {
-    pr.z[i] = __uint_as_float(0x7fc00000u | (unsigned)((round + 1) & 0xff));
+__device__ __forceinline__ void strip_point(const PatchRef &pr, unsigned slot, int round) {
+    pr.z[slot] = __uint_as_float(0x7fc00000u | (unsigned)((round + 1) & 0xff));
 }
 __device__ __forceinline__ bool z_stripped(float z) { return (int)__float_as_uint(z) > 0x7fc00000; }
 // what the last R-GPF round writes for a non-ground point: its cloud index, plus in bits 24-31 the
@@ -312,24 +332,24 @@ __device__ __forceinline__ unsigned chunk_valid(unsigned n, unsigned c, unsigned
 // consecutive points per lane the four-waves-per-patch kernel took it for the largest patch of KITTI frame 0:
 // 6.6 -> 40 us).  Which lane sees which point is free per pass.
 template <int G>
-__device__ __forceinline__ void load_chunk_z(ChunkZ &cp, const PatchRef &pr, unsigned n, unsigned c) {
+__device__ __forceinline__ void load_chunk_z(ChunkZ &cp, const PatchRef &pr, const PartSel &sel) {
     const unsigned j = (unsigned)lane_id() & (G - 1);
     cp.valid = 0;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
-        const unsigned i = c * (8u * G) + (unsigned)k * G + j;
-        cp.z[k] = pr.z[i < n ? i : 0u];
-        if (i < n) cp.valid |= 1u << k;
+        const unsigned i = sel.c * (8u * G) + (unsigned)k * G + j;
+        cp.z[k] = pr.z[sel.off + (i < sel.n ? i : 0u)];
+        if (i < sel.n) cp.valid |= 1u << k;
     }
 }
 template <int G>
-__device__ __forceinline__ void load_chunk(ChunkPts &cp, const PatchRef &pr, unsigned n, unsigned c) {
+__device__ __forceinline__ void load_chunk(ChunkPts &cp, const PatchRef &pr, const PartSel &sel) {
     const unsigned j = (unsigned)lane_id() & (G - 1);
-    cp.valid = chunk_valid<G>(n, c, j);
+    cp.valid = chunk_valid<G>(sel.n, sel.c, j);
     if constexpr (G == 64) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const unsigned p1 = chunk_point<G>(c, 4 * q, j), p0 = p1 < n ? p1 : 0u;
+            const unsigned p1 = chunk_point<G>(sel.c, 4 * q, j), p0 = sel.off + (p1 < sel.n ? p1 : 0u);
             const float4 v = *reinterpret_cast<const float4 *>(pr.z + p0);
             const float4 a = *reinterpret_cast<const float4 *>(pr.xy + p0), b = *reinterpret_cast<const float4 *>(pr.xy + p0 + 2);
             cp.z[4 * q] = v.x;
@@ -348,7 +368,7 @@ __device__ __forceinline__ void load_chunk(ChunkPts &cp, const PatchRef &pr, uns
     } else {
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
-            const unsigned i1 = chunk_point<G>(c, k, j), i = i1 < n ? i1 : 0u;
+            const unsigned i1 = chunk_point<G>(sel.c, k, j), i = sel.off + (i1 < sel.n ? i1 : 0u);
             const float2 v = pr.xy[i];
             cp.z[k] = pr.z[i];
             cp.x[k] = v.x;
@@ -356,6 +376,9 @@ __device__ __forceinline__ void load_chunk(ChunkPts &cp, const PatchRef &pr, uns
         }
     }
 }
+// the slot of point k of this lane (what strip_point marks)
+template <int G>
+__device__ __forceinline__ unsigned chunk_slot(const PartSel &sel, int k, unsigned j) { return sel.off + chunk_point<G>(sel.c, k, j); }
 // the points of a chunk that are still in the patch's working set (not removed by R-VPF); evaluated
 // where the chunk is consumed, so that a chunk loaded ahead does not have to land early
 template <class C>
@@ -368,14 +391,14 @@ __device__ __forceinline__ unsigned chunk_act(const C &cp) {
 }
 // the cloud indices of a chunk (only the pass that writes the split needs them)
 template <int G>
-__device__ __forceinline__ void load_chunk_idx(int w[kPPT], const PatchRef &pr, unsigned n, unsigned c) {
+__device__ __forceinline__ void load_chunk_idx(int w[kPPT], const PatchRef &pr, const PartSel &sel) {
     const unsigned j = (unsigned)lane_id() & (G - 1);
     if constexpr (G == 64) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const unsigned p0 = chunk_point<G>(c, 4 * q, j);
+            const unsigned p0 = chunk_point<G>(sel.c, 4 * q, j);
             int4 v = make_int4(0, 0, 0, 0);
-            if (p0 < n) v = *reinterpret_cast<const int4 *>(pr.idx + p0);  // (a patch's slots are padded to a multiple of four)
+            if (p0 < sel.n) v = *reinterpret_cast<const int4 *>(pr.idx + sel.off + p0);  // (a part's slots are padded to a multiple of four)
             w[4 * q] = v.x;
             w[4 * q + 1] = v.y;
             w[4 * q + 2] = v.z;
@@ -384,8 +407,8 @@ __device__ __forceinline__ void load_chunk_idx(int w[kPPT], const PatchRef &pr, 
     } else {
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
-            const unsigned i = chunk_point<G>(c, k, j);
-            w[k] = i < n ? pr.idx[i] : 0;
+            const unsigned i = chunk_point<G>(sel.c, k, j);
+            w[k] = i < sel.n ? pr.idx[sel.off + i] : 0;
         }
     }
 }
@@ -454,16 +477,19 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~Row<64>::
 // of the row's lowest points: ~1e-3 of the rows for G = 64, a few % for G = 16) a second pass
 // gathers every key below T (<= 8 per lane) and sums those, topped up with copies of T; if even
 // that overflows, an exact but slow extraction by distinct values runs.
+// The two parts of the bin: every z of the low part is below every z of the high part (and a NaN, the largest
+// key, lives in the high part), so if the low part alone holds num_lpr eligible points the lowest num_lpr of
+// the patch are all there and the high part is not read; otherwise the pass goes on through the high part.
 template <int G>
-__device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max, bool need, bool use_cutoff, double cutoff,
+__device__ double srow_lpr(const PatchRef &pts, bool need, bool use_cutoff, double cutoff,
                            int num_lpr, int force = 0 /* tests: 1 = take the second pass, 2 = and the exact extraction (PWPP_DEBUG_FLAGS 16384 / 32768) */) {
     const int j = lane_id() & (G - 1);
     const unsigned INF = 0xFFFFFFFFu;
     unsigned k0 = INF, k1 = INF, k2 = INF, k3 = INF, dropped = INF;
     int elig = 0;
-    for (unsigned c = 0; c < nchunk_max; ++c) {
+    auto rank_chunk = [&](const PartSel &sel) {
         ChunkZ cp;
-        load_chunk_z<G>(cp, pts, need ? n : 0u, c);
+        load_chunk_z<G>(cp, pts, sel);
         const unsigned act = chunk_act(cp);
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
@@ -476,8 +502,28 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
             dropped = x < dropped ? x : dropped;
             elig += e ? 1 : 0;
         }
+    };
+    const unsigned nc_lo = wave_max_u32(need ? part_chunks<G>(pts.n_lo) : 0u);
+    for (unsigned c = 0; c < nc_lo; ++c) {
+        PartSel sel;
+        sel.off = pts.off_lo;
+        sel.n = need ? pts.n_lo : 0u;
+        sel.c = c;
+        rank_chunk(sel);
     }
-    const int total = Row<G>::sum_i32(elig);
+    int total = Row<G>::sum_i32(elig);
+    const bool use_hi = need && pts.n_hi > 0u && total < num_lpr;  // row-uniform
+    if (__any(use_hi)) {
+        const unsigned nc_hi = wave_max_u32(use_hi ? part_chunks<G>(pts.n_hi) : 0u);
+        for (unsigned c = 0; c < nc_hi; ++c) {
+            PartSel sel;
+            sel.off = pts.off_hi;
+            sel.n = use_hi ? pts.n_hi : 0u;
+            sel.c = c;
+            rank_chunk(sel);
+        }
+        total = Row<G>::sum_i32(elig);
+    }
     const int keff = total < num_lpr ? total : num_lpr;  // row-uniform
     double sum = 0.0;
     unsigned T = 0;
@@ -505,9 +551,10 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
 #pragma unroll
         for (int q = 0; q < 8; ++q) key[q] = INF;
         bool overflow = false;
+        const unsigned nchunk_max = wave_max_u32(fast ? patch_chunks<G>(pts, use_hi) : 0u);
         for (unsigned c = 0; c < nchunk_max; ++c) {
             ChunkZ cp;
-            load_chunk_z<G>(cp, pts, fast ? n : 0u, c);
+            load_chunk_z<G>(cp, pts, chunk_sel<G>(pts, c, use_hi, fast));
             const unsigned act = chunk_act(cp);
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) {
@@ -561,9 +608,10 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
             if (!__any(remaining > 0)) break;
             unsigned vmin = INF;
             int vcnt = 0;
+            const unsigned nchunk_max = wave_max_u32(remaining > 0 ? patch_chunks<G>(pts, use_hi) : 0u);
             for (unsigned c = 0; c < nchunk_max; ++c) {
                 ChunkZ cp;
-                load_chunk_z<G>(cp, pts, remaining > 0 ? n : 0u, c);
+                load_chunk_z<G>(cp, pts, chunk_sel<G>(pts, c, use_hi, remaining > 0));
                 const unsigned act = chunk_act(cp);
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k) {
@@ -603,21 +651,60 @@ __device__ double srow_lpr(const PatchRef &pts, unsigned n, unsigned nchunk_max,
 // what every fit kernel needs of a patch before its chain starts
 struct PatchCtx {
     int bin, zone;
-    unsigned n, off;
-    float ox, oy;  // origin of the bin's fixed-point sums
+    unsigned n;                           // points of the bin = n_lo + n_hi
+    unsigned off_lo, n_lo, off_hi, n_hi;  // its two parts (slots relative to the frame's first)
+    float ox, oy;                         // origin of the bin's fixed-point sums
 };
 __device__ __forceinline__ PatchCtx patch_ctx(const PwppBatch &Bt, int f, unsigned slot, bool alive) {
     const PwppDevParams &P = Bt.P;
-    const int NB = P.num_bins + 2;
+    const int NP = PWPP_NUM_PARTS(P.num_bins);
     PatchCtx c;
     c.bin = alive ? (int)Bt.cls_list[(size_t)f * P.num_bins + slot] : 0;
-    c.n = alive ? Bt.bin_count[(size_t)f * NB + c.bin] : 0u;
-    c.off = alive ? Bt.bin_off[(size_t)f * NB + c.bin] : 0u;
+    const uint2 cnt = *reinterpret_cast<const uint2 *>(Bt.part_count + (size_t)f * NP + PWPP_PART_LO(c.bin));  // (low, high: neighbours)
+    const uint2 off = *reinterpret_cast<const uint2 *>(Bt.part_off + (size_t)f * NP + PWPP_PART_LO(c.bin));
+    c.n_lo = alive ? cnt.x : 0u;
+    c.n_hi = alive ? cnt.y : 0u;
+    c.off_lo = alive ? off.x : 0u;
+    c.off_hi = alive ? off.y : 0u;
+    c.n = c.n_lo + c.n_hi;
     c.zone = c.bin < P.bin_base[1] ? 0 : (c.bin < P.bin_base[2] ? 1 : (c.bin < P.bin_base[3] ? 2 : 3));
     const float2 o = Bt.bin_origin[c.bin];
     c.ox = o.x;
     c.oy = o.y;
     return c;
+}
+__device__ __forceinline__ PatchRef patch_ref(const PwppBatch &Bt, const PwppFrameDesc &fd, unsigned off_lo, unsigned n_lo, unsigned off_hi, unsigned n_hi) {
+    PatchRef r;
+    r.z = Bt.sorted_z + fd.sbase;
+    r.xy = Bt.sorted_xy + fd.sbase;
+    r.idx = Bt.sorted_idx + fd.sbase;
+    r.off_lo = off_lo;
+    r.n_lo = n_lo;
+    r.off_hi = off_hi;
+    r.n_hi = n_hi;
+    return r;
+}
+__device__ __forceinline__ PatchRef patch_ref(const PwppBatch &Bt, const PwppFrameDesc &fd, const PatchCtx &pc) {
+    return patch_ref(Bt, fd, pc.off_lo, pc.n_lo, pc.off_hi, pc.n_hi);
+}
+
+// Does a pass of this stage have to read the high part of the patch (n_hi points with z >= zs or NaN, x and y inside bb)?
+//   seed stages (ref :108,145: z < lpr + th)        no, if the largest threshold of the pass is not above zs;
+//   R-GPF round (ref :525: n . p + d < th_dist)     no, if plane_dist is not below th_dist at the corner of the box
+//       bb x [zs, inf) where the plane is lowest: plane_dist is a chain of correctly rounded -- hence monotone --
+//       operations in every coordinate (no FMA contraction: -ffp-contract=off is part of the contract), so every
+//       point of the box gets at least the corner's value, bit for bit.  (nz >= 0 since ref :68; a NaN anywhere
+//       fails the comparison and the part is read.)
+// An R-VPF strip (|dist| < th_dist_v around a near-vertical plane) always reads it.
+__device__ __forceinline__ bool stage_needs_hi(int kind, unsigned n_hi, double thr_seed_max, double th_dist, const PlaneFit &pl,
+                                               const float4 &bb, float zs) {
+    if (n_hi == 0u) return false;
+    if (kind == ST_ITER) {
+        if (!(pl.nz >= 0.0f)) return true;
+        const float cx = pl.nx >= 0.0f ? bb.x : bb.y, cy = pl.ny >= 0.0f ? bb.z : bb.w;
+        return !(plane_dist(pl.nx, pl.ny, pl.nz, pl.d, cx, cy, zs) >= th_dist);
+    }
+    return !(thr_seed_max <= (double)zs);
 }
 __device__ __forceinline__ void plane_clear(PlaneFit &pl) {
     pl.nx = pl.ny = pl.nz = 0.0f;
@@ -652,13 +739,14 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
     const int bin = pc.bin, zone = pc.zone;
     const unsigned n = pc.n;
     const PwppFrameDesc fd = Bt.frames[f];
-    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + pc.off);
-    int *plist = Bt.plist + fd.sbase + pc.off;
+    const PatchRef pts = patch_ref(Bt, fd, pc);
+    int *plist = Bt.plist + fd.sbase + pc.off_lo;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;
+    const float zs = hi_split_z(P, sensor_height);
+    const float4 bb = Bt.bin_bbox[bin];
     const bool use_cutoff = zone == 0;
     const double scale = (double)(1 << P.fxp_shift);
-    const unsigned nchunk_max = wave_max_u32((n + 8u * G - 1u) / (8u * G));
     const bool wide = __any(n > 2047u);  // wave-uniform: some row's second moments may leave int64 in the cross-lane sum
 
     PlaneFit pl;
@@ -674,7 +762,7 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
         if (!__any(kind != ST_DONE)) break;
         const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
         if (__any(need_lpr)) {
-            const double l = srow_lpr<G>(pts, n, nchunk_max, need_lpr, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
+            const double l = srow_lpr<G>(pts, need_lpr, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
             if (need_lpr) {
                 lpr = l;
                 lpr_valid = true;
@@ -687,16 +775,19 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
         }
         const double thr_seed = lpr + ((kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds);
         const bool last = kind == ST_ITER && it == P.num_iter - 1;
+        const bool on = kind != ST_DONE;
+        const bool use_hi = on && stage_needs_hi(kind, pc.n_hi, thr_seed, P.th_dist, pl, bb, zs);  // row-uniform
+        const unsigned nchunk_max = wave_max_u32(on ? patch_chunks<G>(pts, use_hi) : 0u);
         Moments m;
         m.clear();
         unsigned run_g = 0, run_n = 0;
         ChunkPts cp;
-        load_chunk<G>(cp, pts, kind != ST_DONE ? n : 0u, 0u);
+        load_chunk<G>(cp, pts, chunk_sel<G>(pts, 0u, use_hi, on));
         for (unsigned c = 0; c < nchunk_max; ++c) {
             ChunkPts nx;  // the next chunk is in flight while this one is accumulated
-            load_chunk<G>(nx, pts, kind != ST_DONE ? n : 0u, c + 1u);
+            load_chunk<G>(nx, pts, chunk_sel<G>(pts, c + 1u, use_hi, on));
             int w[kPPT];
-            if (__any(last)) load_chunk_idx<G>(w, pts, last ? n : 0u, c);
+            if (__any(last)) load_chunk_idx<G>(w, pts, chunk_sel<G>(pts, c, use_hi, last));
             const unsigned gmask = lane_stage_accum(cp, chunk_act(cp), kind, thr_seed, P.th_dist, pl, scale, org, m);
             if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                 const unsigned gm = last ? gmask : 0u;
@@ -732,24 +823,27 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
             }
             if (kind != ST_DONE && cnt > 0) plane_from_totals(cnt, s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug, pl);  // empty: ref :49
         }
-        if (kind == ST_VPF) {
-            const bool vertical = (double)pl.nz < P.uprightness_thr;  // ref :489
-            if (__any(vertical)) {
-                bool any = false;
-                for (unsigned c = 0; c < nchunk_max; ++c) {
-                    ChunkPts cs2;
-                    load_chunk<G>(cs2, pts, vertical ? n : 0u, c);
-                    const unsigned hit = lane_strip(cs2, chunk_act(cs2), vertical, pl, P.th_dist_v);
+        // (the rows of a wave may be at different stages: everything wave-wide -- wave_max_u32 -- stays outside the per-stage branches)
+        const bool vertical = kind == ST_VPF && (double)pl.nz < P.uprightness_thr;  // ref :489
+        if (__any(vertical)) {
+            bool any = false;
+            const unsigned nstrip_max = wave_max_u32(vertical ? patch_chunks<G>(pts, true) : 0u);
+            for (unsigned c = 0; c < nstrip_max; ++c) {
+                ChunkPts cs2;
+                const PartSel sel = chunk_sel<G>(pts, c, true, vertical);
+                load_chunk<G>(cs2, pts, sel);
+                const unsigned hit = lane_strip(cs2, chunk_act(cs2), vertical, pl, P.th_dist_v);
 #pragma unroll
-                    for (int k = 0; k < kPPT; ++k) {
-                        if (hit >> k & 1u) {
-                            strip_point(pts, chunk_point<G>(c, k, (unsigned)j), it);
-                        }
+                for (int k = 0; k < kPPT; ++k) {
+                    if (hit >> k & 1u) {
+                        strip_point(pts, chunk_slot<G>(sel, k, (unsigned)j), it);
                     }
-                    any = any || hit != 0;
                 }
-                if (Row<G>::ballot(any) != 0ull) lpr_valid = false;  // the working set changed
+                any = any || hit != 0;
             }
+            if (Row<G>::ballot(any) != 0ull) lpr_valid = false;  // the working set changed
+        }
+        if (kind == ST_VPF) {
             ++it;
             if (!vertical || it >= P.num_iter) {
                 kind = ST_SEED;
@@ -761,7 +855,7 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
             kind = ST_ITER;
         } else if (kind == ST_ITER) {
             if (last) {
-                if (j == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt);
+                if (j == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt, !use_hi && pc.n_hi > 0u);
                 kind = ST_DONE;
             }
             ++it;
@@ -790,15 +884,16 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo,
 // ------------------------------------------------------------------------------------------
 template <bool DUAL>
 struct W64Patch {
-    unsigned off, n;
+    unsigned off_lo, n_lo, off_hi, n_hi;  // the two parts of the bin
     int kind;        // stage of the coming points phase; ST_DONE = nothing to do
-    int flags;       // bit0: last R-GPF round (write the split), bit1: zone-0 cut-off applies, bit2: dual seed pass
+    int flags;       // bit0: last R-GPF round (write the split), bit1: zone-0 cut-off applies, bit2: dual seed pass,
+                     // bit3: the pass reads the high part too, bit4: an R-VPF strip removed something; bits 8-15: the R-VPF
+                     // round of the strip in progress (reference-order output)
     float nx, ny, nz;
-    int vpf_round;   // the R-VPF round of the strip in progress (reference-order output)
+    float z0;        // z origin of the patch's fixed-point sums
     double d;
-    double thr_seed;
-    float ox, oy, z0; // origin of the patch's fixed-point sums
-    float pad_;
+    double thr_seed; // (the lowest-point phase hands the representative to the owner lane through this slot)
+    float ox, oy;    // x, y origin
     double thr_band[DUAL ? 1 : 0];  // dual seed pass: upper end of the band [thr_seed, thr_band)
 };
 template <int PW, bool DUAL, int MW>
@@ -806,8 +901,6 @@ struct W64Shared {
     W64Patch<DUAL> p[PW];
     long long mom[PW][MW];
     long long mom2[DUAL ? PW : 1][MW];  // dual seed pass: moments of the band; then the stashed seed totals of the R-GPF stage
-    double lpr[PW];
-    int stripped[PW];
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -844,6 +937,7 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
     int *frame_plist = Bt.plist + fd.sbase;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;  // ref :90
+    const float zs = hi_split_z(P, sensor_height);
     const double scale = (double)(1 << P.fxp_shift);
 
     // ---- owner lane: patch `ln` of this wave (lanes >= PW own nothing)
@@ -852,6 +946,7 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
     const PatchCtx pc = patch_ctx(Bt, f, slot, alive);
     const int bin = pc.bin, zone = pc.zone;
     const unsigned n = pc.n;
+    const float4 bb = Bt.bin_bbox[bin];
     PlaneFit pl;
     plane_clear(pl);
     double lpr = 0.0;
@@ -859,6 +954,7 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
     float z0 = 0.0f;
     int kind = !alive ? ST_DONE : ((P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED);
     int it = 0;
+    bool hi_skipped = false;  // the last points phase of this patch did not read the high part
     // Dual seed pass (big bins, G == 64): the R-VPF round and the R-GPF seed stage of a zone-0 patch
     // select seeds from the same working set with the same lowest-point representative and two
     // thresholds (th_seeds_v / th_seeds, ref :480,:511).  The R-VPF pass therefore accumulates the
@@ -869,14 +965,15 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
     const bool v_is_hi = P.th_seeds_v >= P.th_seeds;
     bool stash_valid = false, dual_now = false;
     if (ln < PW) {
-        sh.p[ln].off = pc.off;
-        sh.p[ln].n = n;
+        sh.p[ln].off_lo = pc.off_lo;
+        sh.p[ln].n_lo = pc.n_lo;
+        sh.p[ln].off_hi = pc.off_hi;
+        sh.p[ln].n_hi = pc.n_hi;
         sh.p[ln].kind = ST_DONE;
         sh.p[ln].flags = zone == 0 ? 2 : 0;
         sh.p[ln].ox = pc.ox;
         sh.p[ln].oy = pc.oy;
         sh.p[ln].z0 = 0.0f;
-        sh.stripped[ln] = 0;
     }
     wave_lds_sync();
 
@@ -891,15 +988,14 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
                 if (((lpr_mask >> (R * sb)) & ((1ull << R) - 1ull)) == 0ull) continue;
                 const int q = R * sb + row;
                 const bool need_row = (lpr_mask >> q) & 1ull;
-                const unsigned qn = sh.p[q].n, qoff = sh.p[q].off;
                 const bool use_cutoff = (sh.p[q].flags & 2) != 0;
-                const unsigned nchunk_max = wave_max_u32(need_row ? (qn + 8u * G - 1u) / (8u * G) : 0u);
-                const double l = srow_lpr<G>(patch_ref(Bt, (size_t)fd.sbase + qoff), qn, nchunk_max, need_row, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
-                if (need_row && j == 0) sh.lpr[q] = l;
+                const PatchRef qpts = patch_ref(Bt, fd, sh.p[q].off_lo, sh.p[q].n_lo, sh.p[q].off_hi, sh.p[q].n_hi);
+                const double l = srow_lpr<G>(qpts, need_row, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
+                if (need_row && j == 0) sh.p[q].thr_seed = l;
             }
             wave_lds_sync();
             if (need_lpr) {
-                lpr = sh.lpr[ln];
+                lpr = sh.p[ln].thr_seed;
                 lpr_valid = true;
                 if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative
                     z0 = fxp_z_origin(lpr);
@@ -914,16 +1010,21 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
         const int pub_kind = from_stash ? ST_DONE : kind;
         if (ln < PW) {
             const bool last = kind == ST_ITER && it == P.num_iter - 1;
+            const double th = (kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds;
+            const double thr_seed = lpr + (dual_now ? (v_is_hi ? P.th_seeds : P.th_seeds_v) : th);
+            const double thr_band = lpr + (v_is_hi ? P.th_seeds_v : P.th_seeds);
+            const bool use_hi = pub_kind != ST_DONE &&
+                                stage_needs_hi(kind, pc.n_hi, dual_now && thr_band > thr_seed ? thr_band : thr_seed, P.th_dist, pl, bb, zs);
+            if (pub_kind != ST_DONE) hi_skipped = !use_hi && pc.n_hi > 0u;
             sh.p[ln].kind = pub_kind;
-            sh.p[ln].flags = (zone == 0 ? 2 : 0) | (last ? 1 : 0) | (dual_now ? 4 : 0);
+            sh.p[ln].flags = (zone == 0 ? 2 : 0) | (last ? 1 : 0) | (dual_now ? 4 : 0) | (use_hi ? 8 : 0);
             sh.p[ln].nx = pl.nx;
             sh.p[ln].ny = pl.ny;
             sh.p[ln].nz = pl.nz;
             sh.p[ln].d = pl.d;
             sh.p[ln].z0 = z0;
-            const double th = (kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds;
-            sh.p[ln].thr_seed = lpr + (dual_now ? (v_is_hi ? P.th_seeds : P.th_seeds_v) : th);
-            if constexpr (DUAL) sh.p[ln].thr_band[0] = lpr + (v_is_hi ? P.th_seeds_v : P.th_seeds);
+            sh.p[ln].thr_seed = thr_seed;
+            if constexpr (DUAL) sh.p[ln].thr_band[0] = thr_band;
         }
         wave_lds_sync();
 
@@ -935,16 +1036,17 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
             const W64Patch<DUAL> pp = sh.p[q];
             const bool on = pp.kind != ST_DONE;
             const bool last = on && (pp.flags & 1);
+            const bool use_hi = (pp.flags & 8) != 0;
             PlaneFit qpl;
             qpl.nx = pp.nx;
             qpl.ny = pp.ny;
             qpl.nz = pp.nz;
             qpl.d = pp.d;
             const FxpOrg org = fxp_org(pp.ox, pp.oy, pp.z0, scale, P.fxp_zr);
-            const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + pp.off);
-            int *plist = frame_plist + pp.off;
-            const unsigned qn = on ? pp.n : 0u;
-            const unsigned nchunk_max = wave_max_u32((qn + 8u * G - 1u) / (8u * G));
+            const PatchRef pts = patch_ref(Bt, fd, pp.off_lo, pp.n_lo, pp.off_hi, pp.n_hi);
+            int *plist = frame_plist + pp.off_lo;
+            const unsigned qn = pp.n_lo + pp.n_hi;
+            const unsigned nchunk_max = wave_max_u32(on ? patch_chunks<G>(pts, use_hi) : 0u);
             const bool dual = DUAL && on && (pp.flags & 4);
             Moments m, m2;
             m.clear();
@@ -952,9 +1054,9 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
             unsigned run_g = 0, run_n = 0;
             for (unsigned c = 0; c < nchunk_max; ++c) {
                 ChunkPts cp;
-                load_chunk<G>(cp, pts, qn, c);
+                load_chunk<G>(cp, pts, chunk_sel<G>(pts, c, use_hi, on));
                 int w[kPPT];
-                if (__any(last)) load_chunk_idx<G>(w, pts, last ? qn : 0u, c);
+                if (__any(last)) load_chunk_idx<G>(w, pts, chunk_sel<G>(pts, c, use_hi, last));
                 const unsigned act = chunk_act(cp);
                 const unsigned gmask = lane_stage_accum(cp, act, pp.kind, pp.thr_seed, P.th_dist, qpl, scale, org, m);
                 if constexpr (DUAL) {
@@ -1046,8 +1148,7 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
                 sh.p[ln].ny = pl.ny;
                 sh.p[ln].nz = pl.nz;
                 sh.p[ln].d = pl.d;
-                sh.p[ln].vpf_round = it;
-                sh.stripped[ln] = 0;
+                sh.p[ln].flags = (sh.p[ln].flags & 0xef) | (it << 8);  // nothing removed yet; the round
             }
             wave_lds_sync();
             for (int sb = 0; sb < NSB; ++sb) {
@@ -1060,26 +1161,27 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
                 qpl.ny = pp.ny;
                 qpl.nz = pp.nz;
                 qpl.d = pp.d;
-                const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + pp.off);
-                const unsigned qn = vrow ? pp.n : 0u;
-                const unsigned nchunk_max = wave_max_u32((qn + 8u * G - 1u) / (8u * G));
+                const PatchRef pts = patch_ref(Bt, fd, pp.off_lo, pp.n_lo, pp.off_hi, pp.n_hi);
+                const int vpf_round = (pp.flags >> 8) & 0xff;
+                const unsigned nchunk_max = wave_max_u32(vrow ? patch_chunks<G>(pts, true) : 0u);
                 bool any = false;
                 for (unsigned c = 0; c < nchunk_max; ++c) {
                     ChunkPts cp;
-                    load_chunk<G>(cp, pts, qn, c);
+                    const PartSel sel = chunk_sel<G>(pts, c, true, vrow);
+                    load_chunk<G>(cp, pts, sel);
                     const unsigned hit = lane_strip(cp, chunk_act(cp), vrow, qpl, P.th_dist_v);
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k) {
                         if (hit >> k & 1u) {
-                            strip_point(pts, chunk_point<G>(c, k, (unsigned)j), pp.vpf_round);
+                            strip_point(pts, chunk_slot<G>(sel, k, (unsigned)j), vpf_round);
                         }
                     }
                     any = any || hit != 0;
                 }
-                if (Row<G>::ballot(any) != 0ull && j == 0) sh.stripped[q] = 1;
+                if (Row<G>::ballot(any) != 0ull && j == 0) sh.p[q].flags = pp.flags | 16;
             }
             wave_lds_sync();
-            if (vertical && sh.stripped[ln]) {  // the working set changed
+            if (vertical && (sh.p[ln].flags & 16)) {  // the working set changed
                 lpr_valid = false;
                 stash_valid = false;
             }
@@ -1098,7 +1200,7 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
             kind = ST_ITER;
         } else if (kind == ST_ITER) {
             if (it == P.num_iter - 1) {
-                write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt);
+                write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt, hi_skipped);
                 kind = ST_DONE;
             }
             ++it;
@@ -1213,7 +1315,8 @@ __device__ void reduce_and_fit(FitShared &sh, const MomentsWide &m, int shift, f
 // num_lpr smallest z among the others, summed in ascending order in double (:99-102).
 // A 4-pass 8-bit radix select finds the k-th smallest key; the elements below its 24-bit
 // prefix are gathered in the last pass, the rest is implied by the last histogram.
-__device__ double block_lpr(FitShared &sh, const PatchRef &pts, unsigned n, bool use_cutoff, double cutoff, int num_lpr) {
+// (reads both parts of the bin: this is the rare exact path, and k_fit_stream's)
+__device__ double block_lpr(FitShared &sh, const PatchRef &pts, bool use_cutoff, double cutoff, int num_lpr) {
     const int ln = lane_id(), wv = wave_id();
     unsigned prefix = 0;
     for (int pass = 0; pass < 4; ++pass) {
@@ -1221,8 +1324,8 @@ __device__ double block_lpr(FitShared &sh, const PatchRef &pts, unsigned n, bool
         sh.hist[threadIdx.x] = 0;  // kBlock == 256 counters
         if (threadIdx.x == 0 && pass == 3) sh.sel_count = 0;
         __syncthreads();
-        for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-            const float pz = pts.z[i];
+        for (unsigned i = threadIdx.x; i < pts.n_lo + pts.n_hi; i += kBlock) {
+            const float pz = pts.z[patch_slot(pts, i)];
             if (z_stripped(pz)) continue;
             if (use_cutoff && (double)pz < cutoff) continue;  // init_idx prefix, ref :88-96
             const unsigned key = z_key(pz);
@@ -1338,18 +1441,21 @@ struct BRowShared {
     FitShared fs;  // for block_lpr, the exact fall-back of the lowest-point selection
 };
 
-// LPR (ref :84-103) with the points of the patch dealt out to the four waves chunk by chunk
-__device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsigned nchunk, bool use_cutoff, double cutoff, int num_lpr,
+// LPR (ref :84-103) with the points of the patch dealt out to the four waves chunk by chunk.  `use_hi`: read the high
+// part too; `total` = eligible points seen (the caller reads the low part alone first and comes back with the high part
+// if it held fewer than num_lpr: see srow_lpr).
+__device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, bool use_hi, bool use_cutoff, double cutoff, int num_lpr, int &total_out,
                            int force = 0) {
     const unsigned INF = 0xFFFFFFFFu;
     const int wv = wave_id(), ln = lane_id();
+    const unsigned nchunk = patch_chunks<64>(pts, use_hi);
     unsigned k0 = INF, k1 = INF, k2 = INF, k3 = INF, dropped = INF;
     int elig = 0;
     ChunkZ cp;
-    load_chunk_z<64>(cp, pts, n, (unsigned)wv);
+    load_chunk_z<64>(cp, pts, chunk_sel<64>(pts, (unsigned)wv, use_hi));
     for (unsigned c = (unsigned)wv; c < nchunk; c += kWaves) {
         ChunkZ nx;  // the next chunk is in flight while this one is ranked (this is the first, cold touch of the patch)
-        load_chunk_z<64>(nx, pts, n, c + kWaves);
+        load_chunk_z<64>(nx, pts, chunk_sel<64>(pts, c + kWaves, use_hi, c + kWaves < nchunk));
         const unsigned act = chunk_act(cp);
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
@@ -1404,6 +1510,7 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsi
         __syncthreads();
         total = sh.elig[0];  // (waves 1-3 hold nothing: they follow wave 0's count and extract INF keys; only wave 0's result is used)
     }
+    total_out = total;
     const int keff = total < num_lpr ? total : num_lpr;
     double sum = 0.0;
     unsigned T = 0;
@@ -1432,7 +1539,7 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, unsigned n, unsi
         dall = sh.dropped[0];
         __syncthreads();
     }
-    if (keff > 0 && (dall < T || force != 0)) return block_lpr(sh.fs, pts, n, use_cutoff, cutoff, num_lpr);  // a lane (pool) held > 4 of the lowest: exact path
+    if (keff > 0 && (dall < T || force != 0)) return block_lpr(sh.fs, pts, use_cutoff, cutoff, num_lpr);  // a lane (pool) held > 4 of the lowest: exact path
     return keff ? sum / (double)keff : 0.0;  // ref :103
 }
 
@@ -1446,15 +1553,16 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
     const int wv = wave_id(), ln = lane_id();
     const PatchCtx pc = patch_ctx(Bt, f, slot, true);
     const int bin = pc.bin, zone = pc.zone;
-    const unsigned n = pc.n;  // (at most 2^19 - 1 points: 2047 per lane, see Moments; pwpp_launch_fit sends larger patches to k_fit_stream)
+    const unsigned n = pc.n;  // (at most 2047 points per lane, see Moments; pwpp_launch_fit sends larger patches to k_fit_stream)
     const PwppFrameDesc fd = Bt.frames[f];
-    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + pc.off);
-    int *plist = Bt.plist + fd.sbase + pc.off;
+    const PatchRef pts = patch_ref(Bt, fd, pc);
+    int *plist = Bt.plist + fd.sbase + pc.off_lo;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;
+    const float zs = hi_split_z(P, sensor_height);
+    const float4 bb = Bt.bin_bbox[bin];
     const bool use_cutoff = zone == 0;
     const double scale = (double)(1 << P.fxp_shift);
-    const unsigned nchunk = (n + 511u) / 512u;
 
     PlaneFit pl;
     plane_clear(pl);
@@ -1496,7 +1604,11 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
             continue;
         }
         if ((kind == ST_VPF || kind == ST_SEED) && !lpr_valid) {
-            lpr = brow_lpr(sh, pts, n, nchunk, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
+            int eligible = 0;
+            for (int both = 0; both < 2; ++both) {  // the low part alone, unless it holds fewer than num_lpr eligible points (srow_lpr)
+                lpr = brow_lpr(sh, pts, both != 0, use_cutoff, cutoff, P.num_lpr, eligible, (Bt.debug >> 14) & 3);
+                if (eligible >= P.num_lpr || pc.n_hi == 0u) break;
+            }
             lpr_valid = true;
             if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative
                 z0 = fxp_z_origin(lpr);
@@ -1509,18 +1621,20 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         const double thr_seed = lpr + (dual_now ? (v_is_hi ? P.th_seeds : P.th_seeds_v) : (kind == ST_LAZY ? P.th_seeds_v : P.th_seeds));
         const double thr_band = lpr + (v_is_hi ? P.th_seeds_v : P.th_seeds);
         const bool last = kind == ST_ITER && it == P.num_iter - 1;
+        const bool use_hi = stage_needs_hi(kind, pc.n_hi, dual_now && thr_band > thr_seed ? thr_band : thr_seed, P.th_dist, pl, bb, zs);
+        const unsigned nchunk = patch_chunks<64>(pts, use_hi);
         Moments m, m2;
         m.clear();
         m2.clear();
         ChunkPts cp;
-        load_chunk<64>(cp, pts, n, (unsigned)wv);
+        load_chunk<64>(cp, pts, chunk_sel<64>(pts, (unsigned)wv, use_hi));
         int w[kPPT];
-        if (last) load_chunk_idx<64>(w, pts, n, (unsigned)wv);
+        if (last) load_chunk_idx<64>(w, pts, chunk_sel<64>(pts, (unsigned)wv, use_hi));
         for (unsigned c = (unsigned)wv; c < nchunk; c += kWaves) {
             ChunkPts nx;  // this wave's next chunk (and, in the round that writes the split, its cloud indices) is in flight while this one is accumulated
-            load_chunk<64>(nx, pts, n, c + kWaves);
+            load_chunk<64>(nx, pts, chunk_sel<64>(pts, c + kWaves, use_hi));
             int wnx[kPPT];
-            if (last) load_chunk_idx<64>(wnx, pts, n, c + kWaves);
+            if (last) load_chunk_idx<64>(wnx, pts, chunk_sel<64>(pts, c + kWaves, use_hi));
             const unsigned act = chunk_act(cp);
             const unsigned gmask = lane_stage_accum(cp, act, kind, thr_seed, P.th_dist, pl, scale, org, m);
             if (dual_now) {  // the band [thr_seed, thr_band)
@@ -1616,13 +1730,15 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
             const bool vertical = (double)pl.nz < P.uprightness_thr;  // ref :489
             if (vertical) {
                 int any = 0;
-                for (unsigned c = (unsigned)wv; c < nchunk; c += kWaves) {
+                const unsigned nstrip = patch_chunks<64>(pts, true);
+                for (unsigned c = (unsigned)wv; c < nstrip; c += kWaves) {
                     ChunkPts cs2;
-                    load_chunk<64>(cs2, pts, n, c);
+                    const PartSel sel = chunk_sel<64>(pts, c, true);
+                    load_chunk<64>(cs2, pts, sel);
                     const unsigned hit = lane_strip(cs2, chunk_act(cs2), true, pl, P.th_dist_v);
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k)
-                        if (hit >> k & 1u) strip_point(pts, chunk_point<64>(c, k, (unsigned)ln), it);
+                        if (hit >> k & 1u) strip_point(pts, chunk_slot<64>(sel, k, (unsigned)ln), it);
                     any |= hit != 0u;
                 }
                 if (__syncthreads_or(any)) {  // the working set changed (and the marks are visible)
@@ -1641,7 +1757,7 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
             kind = ST_ITER;
         } else if (kind == ST_ITER) {
             if (last) {
-                if (threadIdx.x == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt);
+                if (threadIdx.x == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt, !use_hi && pc.n_hi > 0u);
                 kind = ST_DONE;
             }
             ++it;
@@ -1679,8 +1795,8 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
     const unsigned n = pc.n;
     PwppPatchRec *rec = Bt.recs + (size_t)f * P.num_bins + bin;
     const PwppFrameDesc fd = Bt.frames[f];
-    const PatchRef pts = patch_ref(Bt, (size_t)fd.sbase + pc.off);
-    int *plist = Bt.plist + fd.sbase + pc.off;
+    const PatchRef pts = patch_ref(Bt, fd, pc);  // (always both parts: a patch this large is rare)
+    int *plist = Bt.plist + fd.sbase + pc.off_lo;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;  // ref :90
     const bool use_cutoff = zone == 0;
@@ -1701,7 +1817,7 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
     float z0 = 0.0f;
     FxpOrg org = fxp_org(pc.ox, pc.oy, 0.0f, scale, P.fxp_zr);
     auto new_lpr = [&]() {
-        lpr = block_lpr(sh, pts, n, use_cutoff, cutoff, P.num_lpr);
+        lpr = block_lpr(sh, pts, use_cutoff, cutoff, P.num_lpr);
         lpr_valid = true;
         if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative
             z0 = fxp_z_origin(lpr);
@@ -1718,9 +1834,10 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
             const double thr = lpr + P.th_seeds_v;  // ref :108
             m.clear();
             for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-                const float z = pts.z[i];
+                const unsigned sl = patch_slot(pts, i);
+                const float z = pts.z[sl];
                 if (!z_stripped(z) && (double)z < thr) {
-                    const float2 xy = pts.xy[i];
+                    const float2 xy = pts.xy[sl];
                     m.add(xy.x, xy.y, z, scale, org);
                 }
             }
@@ -1730,12 +1847,13 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
             if (zone == 0 && (double)nz < P.uprightness_thr) {  // ref :489
                 int any = 0;
                 for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-                    const float z = pts.z[i];
+                    const unsigned sl = patch_slot(pts, i);
+                    const float z = pts.z[sl];
                     if (z_stripped(z)) continue;
-                    const float2 xy = pts.xy[i];
+                    const float2 xy = pts.xy[sl];
                     const double dist = plane_dist(nx, ny, nz, d, xy.x, xy.y, z);
                     if (fabs(dist) < P.th_dist_v) {  // ref :499 -> non_ground_dst
-                        strip_point(pts, i, it);
+                        strip_point(pts, sl, it);
                         any = 1;
                     }
                 }
@@ -1752,9 +1870,10 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
         const double thr = lpr + P.th_seeds;  // ref :145
         m.clear();
         for (unsigned i = threadIdx.x; i < n; i += kBlock) {
-            const float z = pts.z[i];
+            const unsigned sl = patch_slot(pts, i);
+            const float z = pts.z[sl];
             if (!z_stripped(z) && (double)z < thr) {
-                const float2 xy = pts.xy[i];
+                const float2 xy = pts.xy[sl];
                 m.add(xy.x, xy.y, z, scale, org);
             }
         }
@@ -1771,9 +1890,10 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
             const bool in = i < n;
             float z = 0.0f;
             float2 xy = make_float2(0.0f, 0.0f);
+            const unsigned sl = in ? patch_slot(pts, i) : pts.off_lo;
             if (in) {
-                z = pts.z[i];
-                xy = pts.xy[i];
+                z = pts.z[sl];
+                xy = pts.xy[sl];
             }
             const bool active = in && !z_stripped(z);
             bool g = false;
@@ -1785,7 +1905,7 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
             if (last) {
                 // regionwise_ground_ from the front, regionwise_nonground_ (R-VPF strips included,
                 // ref :500,532) from the back of this patch's slot range
-                const int idx = in ? pts.idx[i] : 0;
+                const int idx = in ? pts.idx[sl] : 0;
                 const unsigned long long mg = __ballot(g);
                 const unsigned long long mn = __ballot(in && !g);
                 const unsigned long long lt = (1ull << ln) - 1ull;
@@ -1900,9 +2020,10 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
             if (sscanf(p + 1, "%d:%u", &g, &upper) != 2) return (int)hipErrorInvalidValue;
         }
         if (g != 8 && g != 16 && g != 32 && g != 64) return (int)hipErrorInvalidValue;
-        // A lane adds up at most 2047 points (Moments): G lanes per patch hold 2047 G points, four waves 2^19 - 1;
-        // rows of 16 lanes in k_fit_w64 keep their ten totals in int64, which also ends at 2047 points.
-        const unsigned lane_cap = mode == 'B' || mode == 'H' ? 524287u : (mode == 'W' && g == 16 ? 2047u : 2047u * (unsigned)g);
+        // A lane adds up at most 2047 points (Moments).  A patch is dealt out in chunks of 8 points per lane, its two
+        // parts separately, the chunks of the four-waves kernel four at a time: a lane sees up to n / G + 16 (n / 256 + 24)
+        // points.  Rows of 16 lanes in k_fit_w64 keep their ten totals in int64, which ends at 2047 points per PATCH.
+        const unsigned lane_cap = mode == 'B' || mode == 'H' ? 2023u * 256u : (mode == 'W' && g == 16 ? 2047u : 2031u * (unsigned)g);
         if (upper > lane_cap) upper = lane_cap;
         if (upper > 65535u && mode != 'B' && mode != 'H') upper = 65535u;  // one wave per patch: keep the classes short
         const int k_hi = pwpp_size_bucket(upper + 1u);
@@ -1916,11 +2037,11 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
             else if (mode == 'S' && g == 32) hipLaunchKernelGGL(k_fit_srows<32>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'S' && g == 64) hipLaunchKernelGGL(k_fit_srows<64>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'H') {  // "H64:<n>": up to n points a wave per patch, four waves above (up to 2^19 - 1 points), everything in one launch
-                const int k_top = pwpp_size_bucket(524288u);
+                const int k_top = pwpp_size_bucket(2023u * 256u + 1u);
                 const unsigned nb_big = cap(pwpp_bucket_floor(k_hi));
                 hipLaunchKernelGGL(k_fit_hybrid, dim3(F, nb_big + (patches + kWaves - 1) / kWaves), dim3(kBlock), 0, ls, B, k_hi, k_top, nb_big);
                 k_lo = k_top;
-                n_lo = 524288u;
+                n_lo = pwpp_bucket_floor(k_top);
                 ++slot;
                 while (*p && *p != ',') ++p;
                 if (*p == ',') ++p;

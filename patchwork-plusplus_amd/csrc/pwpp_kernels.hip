@@ -228,20 +228,35 @@ __device__ __forceinline__ unsigned czm_code(const PwppDevParams &P, const float
     return bin_code_exact(P, x, y);
 }
 
+// the PART a point goes to (pwpp_dev.h): the low or the high part of its bin, by its height over the ground level
+// the frame's adaptive state reports (hi_split_z, pwpp_common.hpp: the fit kernels compute the same value)
+__device__ __forceinline__ unsigned part_of(const PwppDevParams &P, unsigned code, float z, float zs) {
+    if (code == PWPP_CODE_DROP) return code;
+    const unsigned B = (unsigned)P.num_bins;
+    // Only the first split_end bins are split (the near zone: the big bins, where the fit passes are bound by the points
+    // they stream -- the small patches further out are bound by their solves, and twice as many non-empty parts cost the
+    // one-pass binning more than they save).  A NaN z goes to the high part: every key of a low part is then below every
+    // key of its high part (srow_lpr, pwpp_fit.hip).
+    if (code < (unsigned)P.split_end) return 2u * code + (z < zs ? 0u : 1u);
+    return code < B ? 2u * code : code + B;
+}
+
 __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
-    __shared__ unsigned s_hist[PWPP_MAX_BINS + 2];
+    extern __shared__ unsigned s_dyn[];  // [parts of this model] -- sized at launch (binning_lds_bytes): 4 KB for the default
+    unsigned *s_hist = s_dyn;            // model instead of the 16 KB of the largest one
     __shared__ float4 s_zt[8];
     const int f = blockIdx.y;
     const PwppFrameDesc fd = Bt.frames[f];
     const int first = blockIdx.x * kPtsPerBlock;
     if (first >= fd.n) return;
     const PwppDevParams &P = Bt.P;
-    const int NB = P.num_bins + 2;
+    const int NB = PWPP_NUM_PARTS(P.num_bins);
     for (int b = threadIdx.x; b < NB; b += kBlock) s_hist[b] = 0;
     fill_zone_table(P, s_zt);
     __syncthreads();
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const float rnr_z_guard = (float)(-sensor_height - 0.8) + 1e-3f;
+    const float zs = hi_split_z(P, sensor_height);
     uint16_t *codes = Bt.codes + fd.base;
     unsigned dropped = 0;
     unsigned pcode[kPtsPerBlock / kBlock];
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
         if (i < fd.n) {
             float x, y, z, w;
             load_point(fd, i, x, y, z, w);
-            const unsigned code = czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0);
+            const unsigned code = part_of(P, czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0), z, zs);
             codes[i] = (uint16_t)code;
             if (code == PWPP_CODE_DROP) ++dropped;
             pcode[j] = code;
@@ -263,10 +278,10 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
         wave_run_count(s_hist, pcode[j], pcode[j] != PWPP_CODE_DROP);
     }
     __syncthreads();
-    unsigned *gcount = Bt.bin_count + (size_t)f * NB;
+    unsigned *gcount = Bt.part_count + (size_t)f * NB;
     for (int b = threadIdx.x; b < NB; b += kBlock) {
         const unsigned c = s_hist[b];
-        if (c) atomicAdd(&gcount[b], c);  // one global atomic per non-empty bin per 1024 points
+        if (c) atomicAdd(&gcount[b], c);  // one global atomic per non-empty part per 1024 points
     }
     dropped = wave_sum_u32(dropped);
     if (lane_id() == 0 && dropped) atomicAdd((unsigned *)&Bt.results[f].n_dropped, dropped);
@@ -284,9 +299,11 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
 // batch on the exact two-pass path, so the result never depends on the capacities.
 // ------------------------------------------------------------------------------------------
 constexpr int kOnePassPts = 1024;  // points per workgroup of K1'
-__global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt, int tiles_per_frame) {
-    __shared__ unsigned s_cnt[PWPP_MAX_BINS + 2];     // points of this workgroup per bin, then its first slot in the bin
-    __shared__ unsigned s_seg[PWPP_MAX_BINS + 3];     // segment starts
+__global__ __launch_bounds__(kBlock, 8) void k_czm_bin_scatter(PwppBatch Bt, int tiles_per_frame) {
+    extern __shared__ unsigned s_dyn[];  // sized at launch (binning_lds_bytes): 8 KB for the default model
+    const int NB = PWPP_NUM_PARTS(Bt.P.num_bins);
+    unsigned *s_cnt = s_dyn;             // [parts] points of this workgroup per part, then its first slot in the part
+    unsigned *s_seg = s_dyn + NB;        // [parts + 1] segment starts
     __shared__ float4 s_zt[8];
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and the
     // scattered 12-byte / 4-byte records of a bin merge into full lines only if the workgroups that write
@@ -298,29 +315,34 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt, int ti
     const int first = (slot % tiles_per_frame) * kOnePassPts;
     if (first >= fd.n) return;
     const PwppDevParams &P = Bt.P;
-    const int NB = P.num_bins + 2;
+    constexpr int kPer = kOnePassPts / kBlock;
+    unsigned pc[kPer];  // code | rank inside the workgroup << 16
+    float px[kPer], py[kPer], pz[kPer], pw[kPer];
+    // the points first: their loads are under way while the tables are set up (the kernel is a latency chain per
+    // workgroup -- at half its occupancy it takes 1.4 x as long -- and the barrier below would otherwise stand
+    // between the table loads and these)
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = first + j * kBlock + threadIdx.x;
+        px[j] = py[j] = pz[j] = pw[j] = 0.0f;
+        if (i < fd.n) load_point(fd, i, px[j], py[j], pz[j], pw[j]);
+    }
     for (int b = threadIdx.x; b < NB; b += kBlock) s_cnt[b] = 0;
     for (int b = threadIdx.x; b <= NB; b += kBlock) s_seg[b] = Bt.cap_off[b];
     fill_zone_table(P, s_zt);
     __syncthreads();
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const float rnr_z_guard = (float)(-sensor_height - 0.8) + 1e-3f;
-    constexpr int kPer = kOnePassPts / kBlock;
-    unsigned pc[kPer];  // code | rank inside the workgroup << 16
-    float px[kPer], py[kPer], pz[kPer];
+    const float zs = hi_split_z(P, sensor_height);
     unsigned dropped = 0;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const int i = first + j * kBlock + threadIdx.x;
         unsigned code = PWPP_CODE_DROP;
-        px[j] = py[j] = pz[j] = 0.0f;
         if (i < fd.n) {
-            float x, y, z, w;
-            load_point(fd, i, x, y, z, w);
-            code = czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0);
+            const float x = px[j], y = py[j], z = pz[j], w = pw[j];
+            code = part_of(P, czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0), z, zs);
             if (code == PWPP_CODE_DROP) ++dropped;
-            px[j] = x;
-            py[j] = y;
             pz[j] = binned_z(z);
         }
         unsigned pos;
@@ -328,10 +350,26 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt, int ti
         pc[j] = code | ((old + pos) << 16);
     }
     __syncthreads();
-    unsigned *gcount = Bt.bin_count + (size_t)f * NB;
-    for (int b = threadIdx.x; b < NB; b += kBlock) {
-        const unsigned c = s_cnt[b];
-        s_cnt[b] = c ? atomicAdd(&gcount[b], c) : 0u;  // histogram and range reservation in one
+    unsigned *gcount = Bt.part_count + (size_t)f * NB;
+    // histogram and range reservation in one: a global atomic per non-empty part.  Four parts per thread at a time, all
+    // four atomics in flight before the first result is needed (as a plain loop every atomic waited for the one before)
+    for (int b0 = 0; b0 < NB; b0 += 4 * kBlock) {
+        unsigned c[4], base[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + q * kBlock + (int)threadIdx.x;
+            c[q] = b < NB ? s_cnt[b] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + q * kBlock + (int)threadIdx.x;
+            base[q] = c[q] ? atomicAdd(&gcount[b], c[q]) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + q * kBlock + (int)threadIdx.x;
+            if (b < NB) s_cnt[b] = base[q];
+        }
     }
     dropped = wave_sum_u32(dropped);
     if (lane_id() == 0 && dropped) atomicAdd((unsigned *)&Bt.results[f].n_dropped, dropped);
@@ -364,29 +402,28 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin_scatter(PwppBatch Bt, int ti
 __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     __shared__ unsigned s_part[kBlock];
     const int f = blockIdx.x;
-    const int NB = Bt.P.num_bins + 2;
-    unsigned *cnt = Bt.bin_count + (size_t)f * NB;
-    unsigned *off = Bt.bin_off + (size_t)f * NB;
-    if (Bt.cap_off) {  // one-pass binning: fixed segments; a bin never reports more points than its segment holds
-        for (int b = threadIdx.x; b < NB; b += kBlock) {
-            const unsigned seg = Bt.cap_off[b], cap = Bt.cap_off[b + 1] - seg;
-            off[b] = seg;
-            if (cnt[b] > cap) {
-                cnt[b] = cap;
+    const int B = Bt.P.num_bins, NB = B + 2, NP = PWPP_NUM_PARTS(B);
+    unsigned *pcnt = Bt.part_count + (size_t)f * NP;
+    unsigned *poff = Bt.part_off + (size_t)f * NP;
+    if (Bt.cap_off) {  // one-pass binning: fixed segments; a part never reports more points than its segment holds
+        for (int p = threadIdx.x; p < NP; p += kBlock) {
+            const unsigned seg = Bt.cap_off[p], cap = Bt.cap_off[p + 1] - seg;
+            poff[p] = seg;
+            if (pcnt[p] > cap) {
+                pcnt[p] = cap;
                 Bt.results[f].overflow = 1;
             }
         }
-        __syncthreads();
     } else {
-        constexpr int kPer = (PWPP_MAX_BINS + 2 + kBlock - 1) / kBlock;
+        constexpr int kPer = (PWPP_NUM_PARTS(PWPP_MAX_BINS) + kBlock - 1) / kBlock;
         unsigned local[kPer];
         unsigned sum = 0;
-        const int b0 = threadIdx.x * kPer;
+        const int p0 = threadIdx.x * kPer;
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
-            const int b = b0 + j;
-            local[j] = b < NB ? ((cnt[b] + 3u) & ~3u) : 0u;  // every bin starts at a multiple of four slots: the fit kernels
-            sum += local[j];                                 // fetch four points (16 / 32 bytes) per lane and load
+            const int p = p0 + j;
+            local[j] = p < NP ? ((pcnt[p] + 3u) & ~3u) : 0u;  // every part starts at a multiple of four slots: the fit kernels
+            sum += local[j];                                  // fetch four points (16 / 32 bytes) per lane and load
         }
         // inclusive scan inside the wave (DPP), then the four wave totals through LDS: one barrier
         // instead of the sixteen of a Hillis-Steele scan over 256 partials (a single frame waits for this)
@@ -398,22 +435,35 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
         unsigned run = before + incl - sum;  // exclusive
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
-            const int b = b0 + j;
-            if (b < NB) off[b] = run;
+            const int p = p0 + j;
+            if (p < NP) poff[p] = run;
             run += local[j];
         }
     }
-    if (threadIdx.x == 0) {
-        Bt.results[f].n_rnr = (int)cnt[Bt.P.num_bins];
-        Bt.results[f].n_oor = (int)cnt[Bt.P.num_bins + 1];
-    }
-    // what the host sizes the one-pass segments of the NEXT batches from (an overflowed bin reports its clamped
+    __syncthreads();  // (the part counts / offsets written above are read by other threads below)
+    // what the host sizes the one-pass segments of the NEXT batches from (an overflowed part reports its clamped
     // count here; the exact redo that follows reports the true one)
-    for (int b = threadIdx.x; b < NB; b += kBlock)
-        if (cnt[b] > Bt.bin_max[b]) atomicMax(&Bt.bin_max[b], cnt[b]);
+    for (int p = threadIdx.x; p < NP; p += kBlock)
+        if (pcnt[p] > Bt.bin_max[p]) atomicMax(&Bt.bin_max[p], pcnt[p]);
+    // the bins: a bin's points = its two parts, its slots begin where its low part begins
+    unsigned *cnt = Bt.bin_count + (size_t)f * NB;
+    unsigned *off = Bt.bin_off + (size_t)f * NB;
+    for (int b = threadIdx.x; b < NB; b += kBlock) {
+        if (b < B) {
+            cnt[b] = pcnt[PWPP_PART_LO(b)] + pcnt[PWPP_PART_HI(b)];
+            off[b] = poff[PWPP_PART_LO(b)];
+        } else {
+            cnt[b] = pcnt[B + b];
+            off[b] = poff[B + b];
+        }
+    }
+    if (threadIdx.x == 0) {
+        Bt.results[f].n_rnr = (int)pcnt[2 * B];
+        Bt.results[f].n_oor = (int)pcnt[2 * B + 1];
+    }
+    __syncthreads();
     // patches of this frame sorted by size bucket (work lists of the K4 kernels)
     __shared__ unsigned s_cnt[PWPP_NUM_BUCKETS], s_start[PWPP_NUM_BUCKETS + 1], s_cur[PWPP_NUM_BUCKETS];
-    const int B = Bt.P.num_bins;
     if (threadIdx.x < PWPP_NUM_BUCKETS) {
         s_cnt[threadIdx.x] = 0;
         s_cur[threadIdx.x] = 0;
@@ -455,13 +505,14 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
 // K3  scatter into bin order
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_czm_scatter(PwppBatch Bt) {
-    __shared__ unsigned s_cnt[PWPP_MAX_BINS + 2];   // points of this block per bin
-    __shared__ unsigned s_base[PWPP_MAX_BINS + 2];  // first slot reserved for this block in that bin
+    extern __shared__ unsigned s_dyn[];  // sized at launch (binning_lds_bytes)
+    const int NB = PWPP_NUM_PARTS(Bt.P.num_bins);
+    unsigned *s_cnt = s_dyn;             // [parts] points of this block per part
+    unsigned *s_base = s_dyn + NB;       // [parts] first slot reserved for this block in that part
     const int f = blockIdx.y;
     const PwppFrameDesc fd = Bt.frames[f];
     const int first = blockIdx.x * kPtsPerBlock;
     if (first >= fd.n) return;
-    const int NB = Bt.P.num_bins + 2;
     for (int b = threadIdx.x; b < NB; b += kBlock) s_cnt[b] = 0;
     __syncthreads();
     const uint16_t *codes = Bt.codes + fd.base;
@@ -483,13 +534,13 @@ __global__ __launch_bounds__(kBlock) void k_czm_scatter(PwppBatch Bt) {
         }
     }
     __syncthreads();
-    unsigned *cursor = Bt.bin_cursor + (size_t)f * NB;
+    unsigned *cursor = Bt.part_cursor + (size_t)f * NB;
     for (int b = threadIdx.x; b < NB; b += kBlock) {
         const unsigned c = s_cnt[b];
-        if (c) s_base[b] = atomicAdd(&cursor[b], c);  // reserve a contiguous range in the bin
+        if (c) s_base[b] = atomicAdd(&cursor[b], c);  // reserve a contiguous range in the part
     }
     __syncthreads();
-    const unsigned *off = Bt.bin_off + (size_t)f * NB;
+    const unsigned *off = Bt.part_off + (size_t)f * NB;
     float *sorted_z = Bt.sorted_z + fd.sbase;
     float2 *sorted_xy = Bt.sorted_xy + fd.sbase;
     int *sorted_idx = Bt.sorted_idx + fd.sbase;
@@ -1360,31 +1411,55 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt, bool keep_cat
     int *out = Bt.out_idx + fd.base;
     const unsigned da = Bt.dst_a[(size_t)f * NB + seg];
     const bool whole = seg >= B || (uint64_t)n < P.min_pts;
+    // the bin's high part (pwpp_dev.h): `n_lo` points at `off`, the others at `off_hi`
+    // (a pseudo-bin is one part: its own count / offset stand in, no branch in front of the loads)
+    const unsigned n_lo = Bt.part_count[(size_t)f * PWPP_NUM_PARTS(B) + (seg < B ? PWPP_PART_LO(seg) : B + seg)];
+    const unsigned off_hi = Bt.part_off[(size_t)f * PWPP_NUM_PARTS(B) + (seg < B ? PWPP_PART_HI(seg) : B + seg)];
+    const int *idx_lo = Bt.sorted_idx + fd.sbase + off, *idx_hi = Bt.sorted_idx + fd.sbase + off_hi;
     // blockIdx.z = part of the list this wave copies (long lists -- dense clouds have bins of 10^4 points -- are
     // dealt out in blocks of 512 entries to gridDim.z waves; eight loads in flight per lane)
     const unsigned part = blockIdx.z, parts = gridDim.z;
     constexpr int kU = 8;
     if (whole) {  // (the out-of-range pseudo-bin of a sensor that sees beyond max_range holds 10^5 points)
-        const int *src = Bt.sorted_idx + fd.sbase + off;
         for (unsigned i0 = part * (kU * kEmitBlock) + threadIdx.x; i0 < n; i0 += parts * (kU * kEmitBlock)) {
             int v[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) v[u] = i0 + u * kEmitBlock < n ? src[i0 + u * kEmitBlock] : 0;
+            for (int u = 0; u < kU; ++u) {
+                const unsigned i = i0 + u * kEmitBlock;
+                v[u] = i < n ? (i < n_lo ? idx_lo[i] : idx_hi[i - n_lo]) : 0;
+            }
 #pragma unroll
             for (int u = 0; u < kU; ++u)
                 if (i0 + u * kEmitBlock < n) out[da + i0 + u * kEmitBlock] = v[u];
         }
         return;
     }
+    // A patch: the last fit pass left the ground candidates at the front of the bin's plist range and the others at its
+    // back.  If that pass skipped the high part (rec.valid bit 1), the n - n_lo entries in between were never written:
+    // they are the high part's points, all of them non-ground, taken from the part itself.
     const int *src = Bt.plist + fd.sbase + off;
-    const unsigned ng = (unsigned)Bt.recs[(size_t)f * B + seg].n_ground;
+    const PwppPatchRec *rec = Bt.recs + (size_t)f * B + seg;
+    const unsigned ng = (unsigned)rec->n_ground;
+    const unsigned n_gap = (rec->valid & 2) ? n - n_lo : 0u;
+    const float *z_hi = Bt.sorted_z + fd.sbase + off_hi;
     const unsigned db = Bt.dst_b[(size_t)f * NB + seg];
     for (unsigned i0 = part * (kU * kEmitBlock) + threadIdx.x; i0 < n; i0 += parts * (kU * kEmitBlock)) {
         int v[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const unsigned i = i0 + u * kEmitBlock;
-            v[u] = i < n ? src[i] : 0;
+            v[u] = 0;
+            if (i < n) {
+                if (i - ng < n_gap) {  // (i >= ng and i < ng + n_gap)
+                    v[u] = idx_hi[i - ng];
+                    if (keep_cat) {  // the R-VPF round that removed the point, if one did (see nonground_entry, pwpp_fit.hip)
+                        const unsigned zb = __float_as_uint(z_hi[i - ng]);
+                        if ((int)zb > 0x7fc00000) v[u] |= (int)((zb & 0xffu) << 24);
+                    }
+                } else {
+                    v[u] = src[i];
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
@@ -1547,14 +1622,14 @@ __global__ __launch_bounds__(kBlock) void k_clear(uint4 *slabs, size_t n16, Pwpp
     }
 }
 
-// count (+ off, cursor on the two-pass path: adjacent slabs) and the result counters start at zero
+// part_count (+ part_off, part_cursor on the two-pass path: adjacent slabs) and the result counters start at zero
 static void launch_clear(const PwppBatch &B, hipStream_t stream) {
-    const int F = B.num_frames, NB = B.P.num_bins + 2;
+    const int F = B.num_frames, NB = PWPP_NUM_PARTS(B.P.num_bins);
     const size_t words = (size_t)(B.cap_off ? 1 : 3) * (size_t)F * (size_t)NB;
-    const size_t n16 = (words + 3) / 4;  // the slabs are followed by dst_a / dst_b, which K5 rewrites: rounding up is harmless
+    const size_t n16 = (words + 3) / 4;  // (the slabs are allocated with a few words to spare: rounding up is harmless)
     const size_t items = n16 > (size_t)F ? n16 : (size_t)F;
     hipLaunchKernelGGL(k_clear, dim3((unsigned)((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                       reinterpret_cast<uint4 *>(B.bin_count), n16, B.results, F);
+                       reinterpret_cast<uint4 *>(B.part_count), n16, B.results, F);
 }
 extern "C" int pwpp_launch_clear(const PwppBatch *batch, hipStream_t stream) {
     if (batch->num_frames > 0) launch_clear(*batch, stream);
@@ -1562,55 +1637,68 @@ extern "C" int pwpp_launch_clear(const PwppBatch *batch, hipStream_t stream) {
 }
 
 // K0 + K1 + K2 only: the histogram of a few sample frames (sizes the one-pass segments before the first batch)
+// dynamic LDS of the binning kernels: one (K1), two (K3) or two-and-a-bit (K1') words per part of this model
+static size_t binning_lds_bytes(const PwppBatch &B, int words_per_part) {
+    return ((size_t)words_per_part * (size_t)PWPP_NUM_PARTS(B.P.num_bins) + 4u) * sizeof(unsigned);
+}
 extern "C" int pwpp_launch_histogram(const PwppBatch *batch, hipStream_t stream) {
     const PwppBatch &B = *batch;
     const int F = B.num_frames;
     if (F <= 0) return 0;
     const unsigned gx = (unsigned)((B.max_n + kPtsPerBlock - 1) / kPtsPerBlock);
     launch_clear(B, stream);
-    if (gx > 0) hipLaunchKernelGGL(k_czm_bin, dim3(gx, F), dim3(kBlock), 0, stream, B);
+    if (gx > 0) hipLaunchKernelGGL(k_czm_bin, dim3(gx, F), dim3(kBlock), binning_lds_bytes(B, 1), stream, B);
     hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
     return (int)hipGetLastError();
 }
 
+// stages: bit 0 = binning (K0-K3), bit 1 = plane fits + K5, bit 2 = index lists (K6, K7); the overlap schedule of
+// pwpp_capi.cpp launches the stages of a frame range on different streams
 extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev /* PWPP_NUM_KERNELS + 1 events or null */,
                                     hipStream_t aux, hipEvent_t aux_fork, hipEvent_t aux_join,
                                     unsigned long long *order_a /* reference-order mode: two scratch arrays, else null */,
-                                    unsigned long long *order_b) {
+                                    unsigned long long *order_b, int stages) {
     const PwppBatch &B = *batch;
     const int F = B.num_frames;
     if (F <= 0) return 0;
     const int NB = B.P.num_bins + 2;
     const unsigned gx = (unsigned)((B.max_n + kPtsPerBlock - 1) / kPtsPerBlock);
-    if (!B.no_clear) launch_clear(B, stream);
-    if (ev) (void)hipEventRecord(ev[0], stream);
-    if (B.cap_off) {  // one-pass binning (fixed bin segments)
-        const unsigned gx1 = (unsigned)((B.max_n + kOnePassPts - 1) / kOnePassPts);
-        if (gx1 > 0) hipLaunchKernelGGL(k_czm_bin_scatter, dim3(gx1 * (unsigned)((F + 7) / 8 * 8)), dim3(kBlock), 0, stream, B, (int)gx1);
-        if (ev) (void)hipEventRecord(ev[1], stream);
-        hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
-        if (ev) (void)hipEventRecord(ev[2], stream);
-    } else {
-        if (gx > 0) hipLaunchKernelGGL(k_czm_bin, dim3(gx, F), dim3(kBlock), 0, stream, B);
-        if (ev) (void)hipEventRecord(ev[1], stream);
-        hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
-        if (ev) (void)hipEventRecord(ev[2], stream);
-        if (gx > 0) hipLaunchKernelGGL(k_czm_scatter, dim3(gx, F), dim3(kBlock), 0, stream, B);
+    if (stages & 1) {
+        if (!B.no_clear) launch_clear(B, stream);
+        if (ev) (void)hipEventRecord(ev[0], stream);
+        if (B.cap_off) {  // one-pass binning (fixed bin segments)
+            const unsigned gx1 = (unsigned)((B.max_n + kOnePassPts - 1) / kOnePassPts);
+            if (gx1 > 0)
+                hipLaunchKernelGGL(k_czm_bin_scatter, dim3(gx1 * (unsigned)((F + 7) / 8 * 8)), dim3(kBlock), binning_lds_bytes(B, 2), stream, B, (int)gx1);
+            if (ev) (void)hipEventRecord(ev[1], stream);
+            hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
+            if (ev) (void)hipEventRecord(ev[2], stream);
+        } else {
+            if (gx > 0) hipLaunchKernelGGL(k_czm_bin, dim3(gx, F), dim3(kBlock), binning_lds_bytes(B, 1), stream, B);
+            if (ev) (void)hipEventRecord(ev[1], stream);
+            hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
+            if (ev) (void)hipEventRecord(ev[2], stream);
+            if (gx > 0) hipLaunchKernelGGL(k_czm_scatter, dim3(gx, F), dim3(kBlock), binning_lds_bytes(B, 2), stream, B);
+        }
     }
-    const int frc = pwpp_launch_fit(batch, stream, ev ? ev + 3 : nullptr, aux, aux_fork, aux_join);  // records ev[3..9]
-    if (frc) return frc;
-    if (B.P.min_pts == 0)
-        hipLaunchKernelGGL(k_gle_tgr_seq, dim3(F), dim3(64), 0, stream, B);  // empty bins inherit planes: serial
-    else if (F <= 64)  // every workgroup alone on a CU: the big-LDS variant
-        hipLaunchKernelGGL(k_gle_tgr<true>, dim3(F), dim3(kBlock), 0, stream, B);
-    else
-        hipLaunchKernelGGL(k_gle_tgr<false>, dim3(F), dim3(kBlock), 0, stream, B);
-    if (ev) (void)hipEventRecord(ev[10], stream);
-    hipLaunchKernelGGL(k_emit, dim3(NB, F, B.emit_parts > 1 ? B.emit_parts : 1), dim3(kEmitBlock), 0, stream, B, order_a != nullptr);
-    if (ev) (void)hipEventRecord(ev[11], stream);
-    if (order_a) {
-        hipLaunchKernelGGL((k_order_sublists<64, 256, 0>), dim3(NB, F), dim3(64), 0, stream, B, order_a, order_b);
-        hipLaunchKernelGGL((k_order_sublists<256, 4096, 256>), dim3(NB, F), dim3(256), 0, stream, B, order_a, order_b);
+    if (stages & 2) {
+        const int frc = pwpp_launch_fit(batch, stream, ev ? ev + 3 : nullptr, aux, aux_fork, aux_join);  // records ev[3..9]
+        if (frc) return frc;
+        if (B.P.min_pts == 0)
+            hipLaunchKernelGGL(k_gle_tgr_seq, dim3(F), dim3(64), 0, stream, B);  // empty bins inherit planes: serial
+        else if (F <= 64)  // every workgroup alone on a CU: the big-LDS variant
+            hipLaunchKernelGGL(k_gle_tgr<true>, dim3(F), dim3(kBlock), 0, stream, B);
+        else
+            hipLaunchKernelGGL(k_gle_tgr<false>, dim3(F), dim3(kBlock), 0, stream, B);
+        if (ev) (void)hipEventRecord(ev[10], stream);
+    }
+    if (stages & 4) {
+        hipLaunchKernelGGL(k_emit, dim3(NB, F, B.emit_parts > 1 ? B.emit_parts : 1), dim3(kEmitBlock), 0, stream, B, order_a != nullptr);
+        if (ev) (void)hipEventRecord(ev[11], stream);
+        if (order_a) {
+            hipLaunchKernelGGL((k_order_sublists<64, 256, 0>), dim3(NB, F), dim3(64), 0, stream, B, order_a, order_b);
+            hipLaunchKernelGGL((k_order_sublists<256, 4096, 256>), dim3(NB, F), dim3(256), 0, stream, B, order_a, order_b);
+        }
     }
     return (int)hipGetLastError();
 }
