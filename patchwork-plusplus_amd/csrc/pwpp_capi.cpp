@@ -112,6 +112,7 @@ struct pwpp_handle {
                              // longest waves -- DESIGN.md section 9)
     int overlap_mode = 1;  // option "overlap_mode": 1 = memory stream / fit stream pipeline, 0 = whole ranges alternating between the streams
     std::vector<hipEvent_t> ev_ranges;  // two per frame range: binned, fitted
+    int bin_block = 256;                // option "bin_block": threads per workgroup of the one-pass binning kernel
     int num_fit_streams = 2;            // option "fit_streams": streams the ranges' fit stages are dealt to (aux_stream + extra_streams)
     std::vector<hipStream_t> extra_streams;
     // tuning / test options (pwpp_set_option; the PWPP_* environment variables are read ONCE, in pwpp_create)
@@ -449,6 +450,7 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
     bt.debug = h->debug_flags;
     bt.fit_plan = h->fit_plan.empty() ? nullptr : h->fit_plan.c_str();
     bt.fit_concurrent = h->fit_concurrent ? 1 : 0;
+    bt.bin_block = h->bin_block;
     if (h->mode == PWPP_MODE_FRESH) {
         bt.P.hist_cap = h->fresh_hist_cap;
         bt.st_scalar = h->d_st_fresh.p;
@@ -813,6 +815,7 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
     if (const char *e = std::getenv("PWPP_ONE_PASS_MIN_FRAMES")) h->one_pass_min_frames = std::atoi(e);
     if (const char *e = std::getenv("PWPP_OVERLAP_RANGES")) h->overlap_ranges = std::atoi(e) < 2 ? 2 : std::atoi(e);
     if (const char *e = std::getenv("PWPP_OVERLAP_MODE")) h->overlap_mode = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PWPP_BIN_BLOCK")) h->bin_block = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 512 ? 512 : (std::atoi(e) == 1024 ? 1024 : 256));
     if (const char *e = std::getenv("PWPP_FIT_STREAMS")) h->num_fit_streams = std::atoi(e) < 1 ? 1 : (std::atoi(e) > 8 ? 8 : std::atoi(e));
     if (const char *e = std::getenv("PWPP_HI_SPLIT")) h->dp.hi_split = (float)std::atof(e);
     if (const char *e = std::getenv("PWPP_HI_SPLIT_ZONES")) h->dp.split_end = h->dp.bin_base[std::atoi(e) < 0 ? 0 : (std::atoi(e) > 4 ? 4 : std::atoi(e))];
@@ -1416,6 +1419,10 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
         if (!(v > 0.0 && v <= 1024.0)) return fail(PWPP_E_ARG, "one_pass_scale=%s: a positive number up to 1024 expected", value);
         h->one_pass_scale = v;
         h->table_stale = true;  // rebuild the capacity table
+    } else if (k == "bin_block") {
+        const int v = std::atoi(value);
+        if (v != 128 && v != 256 && v != 512 && v != 1024) return fail(PWPP_E_ARG, "bin_block=%s: 128, 256, 512 or 1024 expected", value);
+        h->bin_block = v;
     } else if (k == "fit_streams") {
         const int v = std::atoi(value);
         if (v < 1 || v > 8) return fail(PWPP_E_ARG, "fit_streams=%s: 1..8 expected", value);

@@ -298,8 +298,12 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
 // frame's overflow flag (points beyond the segment are not written); the host then redoes the
 // batch on the exact two-pass path, so the result never depends on the capacities.
 // ------------------------------------------------------------------------------------------
-constexpr int kOnePassPts = 1024;  // points per workgroup of K1'
-__global__ __launch_bounds__(kBlock, 8) void k_czm_bin_scatter(PwppBatch Bt, int tiles_per_frame) {
+// BLOCK threads, four points each.  The per-workgroup set-up (zeroing the counters, fetching the segment table, the
+// reservation atomics) does not depend on the tile size, so a larger workgroup halves it per point.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void k_czm_bin_scatter(PwppBatch Bt, int tiles_per_frame) {
+    constexpr int kBlock = BLOCK;
+    constexpr int kOnePassPts = 4 * BLOCK;  // points per workgroup
     extern __shared__ unsigned s_dyn[];  // sized at launch (binning_lds_bytes): 8 KB for the default model
     const int NB = PWPP_NUM_PARTS(Bt.P.num_bins);
     unsigned *s_cnt = s_dyn;             // [parts] points of this workgroup per part, then its first slot in the part
@@ -1667,9 +1671,15 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
         if (!B.no_clear) launch_clear(B, stream);
         if (ev) (void)hipEventRecord(ev[0], stream);
         if (B.cap_off) {  // one-pass binning (fixed bin segments)
-            const unsigned gx1 = (unsigned)((B.max_n + kOnePassPts - 1) / kOnePassPts);
-            if (gx1 > 0)
-                hipLaunchKernelGGL(k_czm_bin_scatter, dim3(gx1 * (unsigned)((F + 7) / 8 * 8)), dim3(kBlock), binning_lds_bytes(B, 2), stream, B, (int)gx1);
+            const int bb = B.bin_block == 1024 ? 1024 : (B.bin_block == 512 ? 512 : (B.bin_block == 128 ? 128 : 256));
+            const unsigned gx1 = (unsigned)((B.max_n + 4 * bb - 1) / (4 * bb));
+            const dim3 grid(gx1 * (unsigned)((F + 7) / 8 * 8));
+            if (gx1 > 0) {
+                if (bb == 128) hipLaunchKernelGGL(k_czm_bin_scatter<128>, grid, dim3(128), binning_lds_bytes(B, 2), stream, B, (int)gx1);
+                else if (bb == 256) hipLaunchKernelGGL(k_czm_bin_scatter<256>, grid, dim3(256), binning_lds_bytes(B, 2), stream, B, (int)gx1);
+                else if (bb == 512) hipLaunchKernelGGL(k_czm_bin_scatter<512>, grid, dim3(512), binning_lds_bytes(B, 2), stream, B, (int)gx1);
+                else hipLaunchKernelGGL(k_czm_bin_scatter<1024>, grid, dim3(1024), binning_lds_bytes(B, 2), stream, B, (int)gx1);
+            }
             if (ev) (void)hipEventRecord(ev[1], stream);
             hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
             if (ev) (void)hipEventRecord(ev[2], stream);

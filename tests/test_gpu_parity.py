@@ -383,6 +383,63 @@ def test_every_fit_kernel_variant(kitti, oracle, plan):
         assert_frame_equal(h, k, ol.Estimator(oracle, arith=ol.ARITH_FXP).run(pts), pts.shape[0])
 
 
+_SPLIT_REFS = {}
+
+
+@pytest.mark.parametrize("zones", [1, 4])
+@pytest.mark.parametrize("hi_split", [-1.0, 0.0, 0.05, 0.6, 3.0, 1e30])
+def test_results_do_not_depend_on_where_the_bins_are_split(kitti, oracle, hi_split, zones):
+    """A bin is stored in two parts (below / at or above a split height) and the fit passes skip the high part whenever
+    they can prove it irrelevant (pwpp_fit.hip, stage_needs_hi).  Wherever the split lies -- below nearly every point
+    (the lowest-point selection must then go on into the high part, every seed pass needs it), at the ground, far
+    above everything, in the near zone only or in every bin -- and whichever kernel fits the patch, the result is
+    the oracle's, bit for bit.  The synthetic frame adds walls next to the sensor (R-VPF strips points of both
+    parts), +-inf heights and steep ground in the near zone."""
+    rng = np.random.default_rng(99)
+    syn = pwpp_synth.add_edge_cases(pwpp_synth.make_cloud(31, n_boxes=80, undulation=0.6), 31)
+    wall = np.zeros((6000, 4), np.float32)   # vertical walls 4-9 m from the sensor, from below the ground to 2 m above
+    wall[:, 0] = rng.uniform(4.0, 9.0, 6000)
+    wall[:, 1] = np.repeat(rng.uniform(-6.0, 6.0, 12), 500) + rng.normal(0, 0.01, 6000)
+    wall[:, 2] = rng.uniform(-2.2, 0.4, 6000)
+    wall[:, 3] = 0.5
+    odd = np.array([[5.0, 2.0, np.inf, 0.5], [5.1, 2.0, -np.inf, 0.5], [-6.0, 3.0, np.inf, 0.5], [7.0, -2.5, 1e30, 0.5],
+                    [7.0, -2.6, -1e30, 0.5]], np.float32)
+    syn = np.concatenate([syn, wall, odd]).astype(np.float32)
+    frames = [kitti[0], syn, kitti[5]]
+    if not _SPLIT_REFS:
+        for k, pts in enumerate(frames):
+            _SPLIT_REFS[k] = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(pts)
+    for plan in ("", "W16:1023,W64.2:65535", "S16:255,S64:65535", "B64:65535", "S16:100"):
+        h = pwpp_hip.Handle()
+        h.set_option("hi_split", hi_split)
+        h.set_option("hi_split_zones", zones)
+        if plan:
+            h.set_option("fit_plan", plan)
+        h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+        for k, pts in enumerate(frames):
+            assert_frame_equal(h, k, _SPLIT_REFS[k], pts.shape[0])
+
+
+def test_split_bins_in_reference_order_and_one_pass_batches(kitti, oracle):
+    """The two list modes and the two binning paths with split bins: reference order (the R-VPF round of a removed point
+    of a skipped high part comes from the part itself, k_emit), and a one-pass batch whose segments were sized for
+    another split (overflow, exact redo)."""
+    frames = [kitti[k % 6] for k in range(12)]
+    refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(kitti[k]) for k in range(6)]
+    for order in (False, True):
+        h = pwpp_hip.Handle()
+        h.set_output_order(order)
+        for hi_split in (0.6, 0.0, 2.0):
+            h.set_option("hi_split", hi_split)
+            h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+            for k in range(12):
+                assert_frame_equal(h, k, refs[k % 6], kitti[k % 6].shape[0])
+                if order:  # the reference's own order of the lists (ties aside: the z sequence)
+                    z = kitti[k % 6][:, 2]
+                    assert np.array_equal(z[h.ground_indices(k)], z[refs[k % 6].ground_idx])
+                    assert np.array_equal(z[h.nonground_indices(k)], z[refs[k % 6].nonground_idx])
+
+
 def test_ingest_pinned_buffers_and_bulk_index_copy(kitti):
     """frames handed over in page-locked buffers, every index list of the batch
     fetched with one device-to-host copy; same content as the per-frame getters."""

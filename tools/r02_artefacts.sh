@@ -13,3 +13,4 @@ for f in default single_stream dense_1024 dense_128; do python -c "
 import json;d=json.loads(open('$O/bench_$f.json').read().strip().splitlines()[-1])
 print('$f',round(d['value']),round(d['ms_per_step'],3),d.get('binning'),d['latency'],{k:round(v,3) for k,v in d['kernel_ms'].items() if v>0.01}, d.get('cpu_baseline',{}).get('value'))"; done
 tail -5 $O/streams.txt; tail -8 $O/small_batches.txt
+python tools/order_cost.py 256 > $O/order_cost.txt 2>&1; cat $O/order_cost.txt
