@@ -198,7 +198,8 @@ def main():
                                    % (F, F, offs[-1] * 16 / 1e9) if args.workload == "kitti" else
                                    "configs[4]: %d dense synthetic 128-beam ~500k-pt frames per GPU, 36-sector CZM" % F,
                        "frames_per_gpu": F, "points_per_frame": int(np.mean(ns)), "parallelism": "frames sharded, dp%d" % world,
-                       "schedule": ("one stream" if args.no_overlap or F < 128 else "library default: two frame ranges on two streams")
+                       "schedule": ("one stream" if args.no_overlap or F < 128 else
+                                    "library default: two frame ranges, binning and lists on the main stream, each range's plane fits on its own")
                                    + "; kernel_ms / roofline.kernel_ms: separate single-stream pass of %d steps outside the timed region" % args.profile_steps},
             "binning": {"one_pass_batches": h.one_pass_stats()[0], "redone_two_pass": h.one_pass_stats()[1],
                         "workspace_gb": h.workspace_bytes() / 1e9, "input_gb": float(offs[-1]) * 16 / 1e9},
@@ -218,6 +219,8 @@ def main():
             ach = b_alg / (dom_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                               "traffic_source": "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same "
+                                                 "workload on this build (tools/profile_r02.sh), not measured inside this run",
                                "algorithmic_bytes_per_launch": b_alg, "kernel_ms": dom_ms,
                                "pipeline_achieved": b_alg * args.steps / elapsed / 1e9,
                                "pipeline_frac": b_alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}

@@ -239,10 +239,10 @@ int pwpp_get_fxp_origins(pwpp_handle *h, float *out_xy, int capacity_bins);
 enum { PWPP_ORDER_SCATTER = 0, PWPP_ORDER_REFERENCE = 1 };
 int pwpp_set_output_order(pwpp_handle *h, int order);
 
-/* Overlap mode (ON by default): batches of 128 frames or more are processed as two frame ranges with
- * their own launches on the handle's two streams, so that the stages of one range fill the wave slots the
- * other leaves empty (binning and index lists are bound by memory, the plane fits by their dependent chains).
- * Same results; per-kernel profiling (pwpp_set_profiling) and PWPP_ORDER_REFERENCE use the single-stream
+/* Overlap mode (ON by default): batches of 128 frames or more are processed as two frame ranges -- binning
+ * and index lists of both on the handle's main stream, each range's plane fits on a stream of its own -- so
+ * that the stages of one range fill the wave slots the other leaves empty (binning and index lists are bound
+ * by memory, the plane fits by their dependent chains).  Same results; per-kernel profiling (pwpp_set_profiling) and PWPP_ORDER_REFERENCE use the single-stream
  * schedule.  pwpp_set_overlap(h, 0) / PWPP_OVERLAP=0 select that schedule for everything. */
 int pwpp_set_overlap(pwpp_handle *h, int on);
 /* one-pass binning (fixed bin segments; DESIGN.md 3, K1'): batches launched that way and how many of
@@ -252,20 +252,29 @@ int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone);
 
 
 /* Tuning and test switches (no reference counterpart).  The environment variables PWPP_DEBUG_FLAGS,
- * PWPP_FIT_PLAN, PWPP_FIT_CONCURRENT, PWPP_NO_ONE_PASS, PWPP_ONE_PASS_MIN_FRAMES, PWPP_ONE_PASS_SCALE and
- * PWPP_OVERLAP set the same options ONCE, in pwpp_create (which says so on stderr); nothing reads the
+ * PWPP_FIT_PLAN, PWPP_FIT_CONCURRENT, PWPP_NO_ONE_PASS, PWPP_ONE_PASS_MIN_FRAMES, PWPP_ONE_PASS_SCALE,
+ * PWPP_OVERLAP, PWPP_OVERLAP_MODE, PWPP_OVERLAP_RANGES, PWPP_FIT_STREAMS, PWPP_BIN_BLOCK, PWPP_HI_SPLIT and
+ * PWPP_HI_SPLIT_ZONES set the same options ONCE, in pwpp_create (which says so on stderr); nothing reads the
  * environment afterwards.  None of them changes a result.
  *   "fit_plan"            which fit kernel handles which patch sizes, e.g. "W16:1023,W64.2:65535"; "" = automatic
  *   "fit_concurrent"      "1": the classes of a plan side by side on two streams
  *   "one_pass"            "0": always the two-pass binning
  *   "one_pass_min_frames" smallest batch that takes the one-pass binning (default 5)
  *   "one_pass_scale"      segment size of a bin in multiples of its even share of a frame (default 4)
- *   "overlap_ranges"      frame ranges of the overlap mode (default 2; more were slower: 3.49 ms vs 2.98 ms with 4)
+ *   "overlap_ranges"      frame ranges of the overlap mode (default 2; more were slower: 3.38 ms vs 2.86 ms with 4)
+ *   "overlap_mode"        "1" (default): binning and lists on the main stream, the ranges' fits on "fit_streams" more;
+ *                         "0": every range as a whole pipeline, alternating between two streams
+ *   "fit_streams"         streams the ranges' fit stages are dealt to (1..8, default 2)
+ *   "bin_block"           threads per workgroup of the one-pass binning kernel (128 / 256 / 512 / 1024, default 256)
+ *   "hi_split"            metres above the ground level (-sensor_height) where the "high" part of a bin begins
+ *                         (default 0.6; 1e30 = no high parts): the fit passes skip a high part whenever they can
+ *                         prove that none of its points can enter the pass
+ *   "hi_split_zones"      how many zones' bins are stored in two parts (0..4, default 1: the near zone)
  *   "debug_flags"         4: timing probes of the fit chain; 16: exact binning arithmetic only;
  *                         16384 / 32768: force the fall-back paths of the lowest-point selection
  * Returns PWPP_E_ARG for an unknown name or a value out of range. */
 int pwpp_set_option(pwpp_handle *h, const char *name, const char *value);
-/* Frees the per-batch workspaces (a handle that processed one large batch otherwise keeps them, e.g. 52 GB
+/* Frees the per-batch workspaces (a handle that processed one large batch otherwise keeps them, e.g. 9.7 GB
  * after 1024 KITTI frames with one-pass binning); streams' state and results of the last call are kept
  * only as far as they live outside those buffers: fetch results first.  The next call allocates again. */
 int pwpp_trim_workspace(pwpp_handle *h);

@@ -365,7 +365,8 @@ class Handle:
 
     def set_option(self, name, value):
         """Tuning / test switches (pwpp_set_option): fit_plan, fit_concurrent, one_pass, one_pass_min_frames,
-        one_pass_scale, debug_flags.  None of them changes a result."""
+        one_pass_scale, overlap_mode, overlap_ranges, fit_streams, bin_block, hi_split, hi_split_zones, debug_flags.
+        None of them changes a result."""
         self._check(self._L.pwpp_set_option(self._h, name.encode(), str(value).encode()))
 
     def workspace_bytes(self):
