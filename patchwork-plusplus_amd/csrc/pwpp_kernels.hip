@@ -1490,21 +1490,91 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt, bool keep_cat
 // One workgroup per (frame, bin); sub-lists up to 4096 entries are sorted in LDS (bitonic), longer
 // ones tile by tile and then merged through two scratch arrays indexed like out_idx.
 // ------------------------------------------------------------------------------------------
+// The keys of a tile live in LDS with one slot of padding per sixteen (a thread's run of consecutive keys then starts
+// in its own bank group: sixteen 8-byte keys are 128 bytes, and unpadded all lanes would hit the same two banks).
+__device__ __forceinline__ int ord_at(int i) { return i + (i >> 4); }
+
+// compare-exchange of a bitonic network
+__device__ __forceinline__ void ord_ce(unsigned long long &a, unsigned long long &b, bool up) {
+    const bool sw = (a > b) == up;
+    const unsigned long long lo = sw ? b : a, hi = sw ? a : b;
+    a = lo;
+    b = hi;
+}
+
+// Bitonic sort of np = BLOCK * E keys (E a power of two up to 16): the stages whose partners lie within a thread's E
+// consecutive keys run in REGISTERS -- every phase ends with log2(E) of them, the first log2(E) phases consist of
+// nothing else -- and only the others go through LDS: 44 barriers and 45 passes over the tile instead of 78 and 78
+// for 4096 keys (the sort was 1.0 of the 1.3 ms the reference-order mode adds to 256 frames).
+template <int BLOCK, int E>
+__device__ __forceinline__ void ord_sort_blocked(unsigned long long *s_key) {
+    constexpr int np = BLOCK * E;
+    const int t = threadIdx.x, base = t * E;
+    unsigned long long r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) r[e] = s_key[ord_at(base + e)];
+#pragma unroll
+    for (int k = 2; k <= E; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((e & j) == 0) ord_ce(r[e], r[e | j], ((base + e) & k) == 0);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) s_key[ord_at(base + e)] = r[e];
+    __syncthreads();
+    for (int k = 2 * E; k <= np; k <<= 1) {
+        for (int j = k >> 1; j >= E; j >>= 1) {  // partners in different threads' runs: through LDS
+#pragma unroll
+            for (int q = 0; q < E / 2; ++q) {
+                const int p = t + q * BLOCK;
+                const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1)), hi = lo | j;
+                unsigned long long a = s_key[ord_at(lo)], b = s_key[ord_at(hi)];
+                ord_ce(a, b, (lo & k) == 0);
+                s_key[ord_at(lo)] = a;
+                s_key[ord_at(hi)] = b;
+            }
+            __syncthreads();
+        }
+        const bool up = (base & k) == 0;  // (k >= 2 E: the same for the whole run)
+#pragma unroll
+        for (int e = 0; e < E; ++e) r[e] = s_key[ord_at(base + e)];
+#pragma unroll
+        for (int j = E >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((e & j) == 0) ord_ce(r[e], r[e | j], up);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) s_key[ord_at(base + e)] = r[e];
+        __syncthreads();
+    }
+}
+
 template <int BLOCK>
 __device__ __forceinline__ void ord_tile_sort(unsigned long long *s_key, int len) {  // len <= tile size, padded with ~0
     int np = 1;
     while (np < len) np <<= 1;
-    for (int i = len + (int)threadIdx.x; i < np; i += BLOCK) s_key[i] = ~0ull;
+    for (int i = len + (int)threadIdx.x; i < np; i += BLOCK) s_key[ord_at(i)] = ~0ull;
     __syncthreads();
-    for (int k = 2; k <= np; k <<= 1) {
+    switch (np / BLOCK) {  // keys per thread
+        case 16: ord_sort_blocked<BLOCK, 16>(s_key); return;
+        case 8: ord_sort_blocked<BLOCK, 8>(s_key); return;
+        case 4: ord_sort_blocked<BLOCK, 4>(s_key); return;
+        case 2: ord_sort_blocked<BLOCK, 2>(s_key); return;
+        default: break;
+    }
+    for (int k = 2; k <= np; k <<= 1) {  // fewer keys than threads (or a tile size this file does not use)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = threadIdx.x; t < np / 2; t += BLOCK) {
                 const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
                 const bool up = (lo & k) == 0;
-                const unsigned long long a = s_key[lo], b = s_key[hi];
+                const unsigned long long a = s_key[ord_at(lo)], b = s_key[ord_at(hi)];
                 if ((a > b) == up) {
-                    s_key[lo] = b;
-                    s_key[hi] = a;
+                    s_key[ord_at(lo)] = b;
+                    s_key[ord_at(hi)] = a;
                 }
             }
             __syncthreads();
@@ -1515,7 +1585,7 @@ __device__ __forceinline__ void ord_tile_sort(unsigned long long *s_key, int len
 // <256, 4096, 256> a workgroup for the lists above 256 entries.  Each handles the lists in ITS range.
 template <int BLOCK, int kOrdTile, int kMinLen>
 __global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned long long *scr_a, unsigned long long *scr_b) {
-    __shared__ unsigned long long s_key[kOrdTile];
+    __shared__ unsigned long long s_key[kOrdTile + kOrdTile / 16];  // (padded: ord_at)
     const int f = blockIdx.y, seg = blockIdx.x;
     const PwppDevParams &P = Bt.P;
     const int B = P.num_bins, NB = B + 2;
@@ -1542,10 +1612,10 @@ __global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned
             return ((unsigned long long)cat << 56) | ((unsigned long long)z_key(z) << 24) | (unsigned long long)(unsigned)idx;
         };
         if (len <= kOrdTile) {
-            for (int i = threadIdx.x; i < len; i += BLOCK) s_key[i] = make_key(out[start + i]);
+            for (int i = threadIdx.x; i < len; i += BLOCK) s_key[ord_at(i)] = make_key(out[start + i]);
             __syncthreads();
             ord_tile_sort<BLOCK>(s_key, len);
-            for (int i = threadIdx.x; i < len; i += BLOCK) out[start + i] = (int)(s_key[i] & 0x00ffffffull);
+            for (int i = threadIdx.x; i < len; i += BLOCK) out[start + i] = (int)(s_key[ord_at(i)] & 0x00ffffffull);
             __syncthreads();
             continue;
         }
@@ -1553,10 +1623,10 @@ __global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned
         unsigned long long *a = scr_a + fd.base + start, *b = scr_b + fd.base + start;
         for (int t0 = 0; t0 < len; t0 += kOrdTile) {
             const int tl = len - t0 < kOrdTile ? len - t0 : kOrdTile;
-            for (int i = threadIdx.x; i < tl; i += BLOCK) s_key[i] = make_key(out[start + t0 + i]);
+            for (int i = threadIdx.x; i < tl; i += BLOCK) s_key[ord_at(i)] = make_key(out[start + t0 + i]);
             __syncthreads();
             ord_tile_sort<BLOCK>(s_key, tl);
-            for (int i = threadIdx.x; i < tl; i += BLOCK) a[t0 + i] = s_key[i];
+            for (int i = threadIdx.x; i < tl; i += BLOCK) a[t0 + i] = s_key[ord_at(i)];
             __syncthreads();
         }
         for (int width = kOrdTile; width < len; width <<= 1) {
