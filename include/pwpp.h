@@ -167,6 +167,9 @@ int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32_t *n_non
  * moves a point that lies within ~1e-4 m of a threshold now and then (measured: 0-2 of 480 000 indices on
  * dense synthetic clouds, none on the KITTI samples; plane normals agree to 1e-4 except for ill-conditioned
  * patches, where a float build departs from exact arithmetic by more than this library does).
+ * One known difference: a patch whose FIRST seed set is empty -- possible only when its lowest height is not finite
+ * (z = -inf; NaN heights are undefined in the reference itself) or num_lpr = 0 -- starts from the zero plane here and
+ * from whatever plane the reference object fitted last.
  * The order inside a list is not the reference's unless pwpp_set_output_order asks for it. */
 int pwpp_get_ground_indices(pwpp_handle *h, int frame, int32_t *out);
 int pwpp_get_nonground_indices(pwpp_handle *h, int frame, int32_t *out);
