@@ -8,6 +8,8 @@ elevations within 1e-4 of the reference CPU path.  What is actually enforced is 
 * against the reference's own patchworkpp.cpp (golden fixtures generated from oracle/_ref,
   eigen-f32 flavour): identical index sets on the six KITTI frames, normals/centres < 1e-4.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -283,9 +285,9 @@ def test_dense_128_beam_cloud_36_sectors(oracle):
     assert_frame_equal(h2, 0, ref2, pts.shape[0], state_index=0)
 
 
-def test_large_batch_properties(kitti):
-    """256 frames in one launch set: replays agree with each other and with the single-frame
-    path, every frame is partitioned (size-independent properties, no oracle needed)."""
+def test_large_batch_properties(kitti, oracle):
+    """256 frames in one launch set (the mid-size plans, two frame ranges): replays agree with each other and with
+    the oracle, every frame is partitioned."""
     F = 256
     frames = [kitti[i % 6] for i in range(F)]
     h = pwpp_hip.Handle()
@@ -300,6 +302,9 @@ def test_large_batch_properties(kitti):
     g = h.ground_indices(255)
     n = h.nonground_indices(255)
     assert np.array_equal(np.sort(np.concatenate([g, n])), np.arange(frames[255].shape[0]))
+    refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(k) for k in kitti]
+    for i in (0, 7, 127, 128, 200, 255):
+        assert_frame_equal(h, i, refs[i % 6], frames[i].shape[0])
 
 
 def test_pybind_module_end_to_end(kitti, golden):
@@ -627,10 +632,12 @@ def test_point_order_invariance_and_determinism(kitti):
         assert np.array_equal(first[i][1], h.normals(i), equal_nan=True)
 
 
-def test_full_size_batch_properties(kitti):
+def test_full_size_batch_properties(kitti, oracle, golden):
     """BASELINE.json configs[2] at its full size (1024 replayed frames, device-resident, one-pass
-    binning, the 64 / 2 patches-per-wave plan): every replay of a source frame gives the same counts
-    and planes as its first occurrence, every frame is partitioned, nothing was redone."""
+    binning, the 64 / 2 patches-per-wave plan, the default schedule of frame ranges over three streams): every replay
+    of a source frame gives the same counts and planes as its first occurrence, every frame is partitioned, nothing was
+    redone -- and the frames of the batch ARE the oracle's: the first six and a sample from both frame ranges are
+    compared with the CPU restatement bit for bit and with the reference build's ground masks (IoU == 1.0)."""
     import torch
     F = 1024
     dev = torch.device("cuda", 0)
@@ -649,6 +656,11 @@ def test_full_size_batch_properties(kitti):
         assert np.array_equal(np.sort(h.ground_indices(i)), np.sort(h.ground_indices(i % 6)))
         assert np.array_equal(h.normals(i), h.normals(i % 6), equal_nan=True)
     assert h.one_pass_stats() == (1, 0)
+    refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(k) for k in kitti]
+    for i in (0, 1, 2, 3, 4, 5, 257, 510, 515, 770, 1022):
+        assert_frame_equal(h, i, refs[i % 6], ns[i])
+        mask = np.packbits(ground_mask(h.ground_indices(i), ns[i]))
+        assert np.array_equal(mask, golden["f32/fresh/%d/ground_mask" % (i % 6)])
     single = pwpp_hip.Handle()
     single.estimate_ground_batch([kitti[3]], mode=pwpp_hip.MODE_FRESH)
     assert np.array_equal(np.sort(single.ground_indices(0)), np.sort(h.ground_indices(3)))  # latency plan, two-pass binning
