@@ -30,6 +30,10 @@ import time
 
 import numpy as np
 
+# RCCL / device-memory sharing between the ranks of one node needs dmabuf IPC on this driver (the image exports this
+# already; set here before the HIP runtime starts in case a launcher scrubs the environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "patchwork-plusplus_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
