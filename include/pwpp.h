@@ -197,6 +197,13 @@ int pwpp_set_state(pwpp_handle *h, int stream, const pwpp_state *in);
 /* ... and put a history back: after pwpp_set_state + eight pwpp_set_history calls with what pwpp_get_state /
  * pwpp_get_history returned, a stream continues exactly where the checkpointed one stood. */
 int pwpp_set_history(pwpp_handle *h, int stream, int which /*0 elevation, 1 flatness*/, int ring, const double *values, int count);
+/* The plane members of the reference object (pc_mean_, normal_, singular_values_, d_: patchworkpp.h:177-182) as they
+ * stand after the state's last frame -- {mean[3], normal[3], singular values[3], d}.  They are part of what a stream
+ * carries from frame to frame: a bin that is processed without a fit (an empty bin let through by num_min_pts <= 0, the
+ * ROS launch file's setting) reports whatever plane was fitted last, also across frames (patchworkpp.cpp:49).  Zero for a
+ * new stream; a checkpoint is pwpp_get_state + the histories + this. */
+int pwpp_get_plane_state(pwpp_handle *h, int index, float out[10]);
+int pwpp_set_plane_state(pwpp_handle *h, int stream, const float in[10]);
 
 /* ---- ingest ----------------------------------------------------------------- */
 /* Page-locked host memory: frames handed over in such buffers are DMA'd straight to the device

@@ -186,6 +186,7 @@ struct pwpp_handle {
     int max_pushes_per_frame = 0;  // bins of the widest ring of interest: what one frame can add to a history
     DevBuf<PwppStateScalar> d_st_stream, d_st_fresh;
     DevBuf<double> d_hist_stream, d_hist_fresh;
+    DevBuf<PwppPlaneState> d_pl_stream, d_pl_fresh, d_pl_snap;  // the reference object's plane members after a frame (pwpp_dev.h)
     // one-pass batches of stateful streams: the state of the streams before the batch, so that a redo after an
     // overflow starts from it (the first attempt has already advanced sensor height, thresholds, histories)
     DevBuf<PwppStateScalar> d_st_snap;
@@ -455,10 +456,12 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
         bt.P.hist_cap = h->fresh_hist_cap;
         bt.st_scalar = h->d_st_fresh.p;
         bt.st_hist = h->d_hist_fresh.p;
+        bt.st_plane = h->d_pl_fresh.p;
     } else {
         bt.P.hist_cap = h->stream_hist_cap;
         bt.st_scalar = h->d_st_stream.p;
         bt.st_hist = h->d_hist_stream.p;
+        bt.st_plane = h->d_pl_stream.p;
     }
     bt.codes = h->d_codes.p;
     const size_t slab = (size_t)h->frames * NB, pslab = (size_t)h->frames * PWPP_NUM_PARTS(B);
@@ -670,6 +673,7 @@ int finish_pending(pwpp_handle *h) {
             if (h->mode == PWPP_MODE_STREAMS) {  // back to the streams' state before the first attempt
                 const size_t slab = (size_t)8 * (size_t)h->stream_hist_cap;
                 HIPCHK(hipMemcpyAsync(h->d_st_stream.p, h->d_st_snap.p, (size_t)h->frames * sizeof(PwppStateScalar), hipMemcpyDeviceToDevice, h->stream));
+                HIPCHK(hipMemcpyAsync(h->d_pl_stream.p, h->d_pl_snap.p, (size_t)h->frames * sizeof(PwppPlaneState), hipMemcpyDeviceToDevice, h->stream));
                 HIPCHK(hipMemcpyAsync(h->d_hist_stream.p, h->d_hist_snap.p, (size_t)h->frames * slab * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
             }
             int rc = launch_prepared(h, false);
@@ -776,6 +780,8 @@ int pwpp_set_num_streams(pwpp_handle *h, int streams) {
     if (rc) return rc;
     if ((rc = h->d_st_stream.ensure((size_t)streams))) return rc;
     if ((rc = h->d_hist_stream.ensure((size_t)streams * 8 * (size_t)h->stream_hist_cap))) return rc;
+    if ((rc = h->d_pl_stream.ensure((size_t)streams))) return rc;
+    HIPCHK(hipMemset(h->d_pl_stream.p, 0, (size_t)streams * sizeof(PwppPlaneState)));  // a new object's members
     std::vector<PwppStateScalar> init((size_t)streams);
     for (auto &s : init) fill_default_state(h, s);
     HIPCHK(hipMemcpy(h->d_st_stream.p, init.data(), init.size() * sizeof(PwppStateScalar), hipMemcpyHostToDevice));
@@ -906,6 +912,9 @@ int pwpp_destroy(pwpp_handle *h) {
     h->d_hist_fresh.release();
     h->d_st_snap.release();
     h->d_hist_snap.release();
+    h->d_pl_stream.release();
+    h->d_pl_fresh.release();
+    h->d_pl_snap.release();
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     for (int k = 0; k <= PWPP_NUM_KERNELS; ++k)
@@ -1016,6 +1025,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     if (mode == PWPP_MODE_FRESH) {
         if ((rc = h->d_st_fresh.ensure((size_t)frames))) return rc;
         if ((rc = h->d_hist_fresh.ensure((size_t)frames * 8 * (size_t)h->fresh_hist_cap))) return rc;
+        if ((rc = h->d_pl_fresh.ensure((size_t)frames))) return rc;
     }
     if (from_host && (rc = h->d_in.ensure((size_t)(total_in > 0 ? total_in : 4)))) return rc;
 
@@ -1124,6 +1134,8 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
         const size_t slab = (size_t)8 * (size_t)h->stream_hist_cap;
         if ((rc = h->d_st_snap.ensure((size_t)frames))) return rc;
         if ((rc = h->d_hist_snap.ensure((size_t)frames * slab))) return rc;
+        if ((rc = h->d_pl_snap.ensure((size_t)frames))) return rc;
+        HIPCHK(hipMemcpyAsync(h->d_pl_snap.p, h->d_pl_stream.p, (size_t)frames * sizeof(PwppPlaneState), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_st_snap.p, h->d_st_stream.p, (size_t)frames * sizeof(PwppStateScalar), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_hist_snap.p, h->d_hist_stream.p, (size_t)frames * slab * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
@@ -1295,6 +1307,43 @@ int pwpp_set_state(pwpp_handle *h, int stream, const pwpp_state *in) {
     std::memcpy(&s, in, sizeof(s));
     for (int k = 0; k < 4; ++k) s.elev_len[k] = s.flat_len[k] = 0;
     HIPCHK(hipMemcpy(h->d_st_stream.p + stream, &s, sizeof(s), hipMemcpyHostToDevice));
+    return PWPP_OK;
+}
+
+int pwpp_get_plane_state(pwpp_handle *h, int index, float out[10]) {
+    if (!h || !out) return fail(PWPP_E_ARG, "null argument");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    const bool fresh = h->have_results && h->mode == PWPP_MODE_FRESH;
+    const int limit = fresh ? h->frames : h->num_streams;
+    if (index < 0 || index >= limit) return fail(PWPP_E_ARG, "state index %d out of range [0,%d)", index, limit);
+    PwppPlaneState ps;
+    HIPCHK(hipMemcpy(&ps, (fresh ? h->d_pl_fresh.p : h->d_pl_stream.p) + index, sizeof(ps), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; ++i) {
+        out[i] = ps.mean[i];
+        out[3 + i] = ps.normal[i];
+        out[6 + i] = ps.sv[i];
+    }
+    out[9] = (float)ps.d;  // (d is a float dot product widened to double in the reference, patchworkpp.cpp:74)
+    return PWPP_OK;
+}
+
+int pwpp_set_plane_state(pwpp_handle *h, int stream, const float in[10]) {
+    if (!h || !in) return fail(PWPP_E_ARG, "null argument");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    if (stream < 0 || stream >= h->num_streams) return fail(PWPP_E_ARG, "stream %d out of range", stream);
+    PwppPlaneState ps;
+    for (int i = 0; i < 3; ++i) {
+        ps.mean[i] = in[i];
+        ps.normal[i] = in[3 + i];
+        ps.sv[i] = in[6 + i];
+    }
+    ps.pad_ = 0.0f;
+    ps.d = (double)in[9];
+    HIPCHK(hipMemcpy(h->d_pl_stream.p + stream, &ps, sizeof(ps), hipMemcpyHostToDevice));
     return PWPP_OK;
 }
 

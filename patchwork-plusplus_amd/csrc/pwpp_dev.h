@@ -75,6 +75,15 @@ struct PwppStateScalar {  // = pwpp_state
     int32_t flat_len[4];
 };
 
+// The reference object's plane members (pc_mean_, normal_, singular_values_, d_: patchworkpp.h:177-182) as they stand
+// after a frame: they survive into the next estimateGround() call, where a bin that is processed without any fit -- an
+// empty bin let through by num_min_pts <= 0, the ROS launch file's setting -- reports them (patchworkpp.cpp:49).
+struct PwppPlaneState {
+    float mean[3], normal[3], sv[3];
+    float pad_;
+    double d;
+};
+
 struct PwppPatchRec {  // one per (frame, bin); written by k_patch_fit, finished by k_gle_tgr
     float mean[3];
     float normal[3];
@@ -111,6 +120,7 @@ struct PwppBatch {
                                  // (cap_off[2B+2] = slots per frame); null on the two-pass path
     PwppStateScalar *st_scalar;  // [num_states]
     double *st_hist;             // [num_states][2][4][hist_cap]
+    PwppPlaneState *st_plane;    // [num_states] the plane members after the state's last frame (zero for a new object)
     uint16_t *codes;             // [total points]
     uint32_t *part_count;        // [frames][2B+2] points per part (K1 / K1' histogram)
     uint32_t *part_off;          // [frames][2B+2] first slot of every part in the sorted_* planes (relative to sbase)

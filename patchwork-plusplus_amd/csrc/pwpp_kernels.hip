@@ -661,11 +661,20 @@ __global__ __launch_bounds__(64) void k_gle_tgr_seq(PwppBatch Bt) {
     int concentric_idx = 0;
     int n_ring_flat = 0;  // ringwise_flatness: only cleared when a ring had candidates (ref :292-304)
     int n_patches = 0;
-    PwppPatchRec prev;    // plane members persist across bins in the reference (stale-plane quirk)
+    PwppPatchRec prev;    // plane members persist across bins AND frames in the reference (stale-plane quirk)
     prev.mean[0] = prev.mean[1] = prev.mean[2] = 0.0f;
     prev.normal[0] = prev.normal[1] = prev.normal[2] = 0.0f;
     prev.sv[0] = prev.sv[1] = prev.sv[2] = 0.0f;
     prev.d = 0.0;
+    if (fd.state_in >= 0) {  // what the stream's last frame left in the members
+        const PwppPlaneState ps = Bt.st_plane[fd.state_in];
+        for (int i = 0; i < 3; ++i) {
+            prev.mean[i] = ps.mean[i];
+            prev.normal[i] = ps.normal[i];
+            prev.sv[i] = ps.sv[i];
+        }
+        prev.d = ps.d;
+    }
     unsigned total_ground = 0;
     for (int zone = 0; zone < 4; ++zone) {
         for (int ring = 0; ring < P.rings[zone]; ++ring) {
@@ -873,6 +882,17 @@ __global__ __launch_bounds__(64) void k_gle_tgr_seq(PwppBatch Bt) {
         }
     }
     Bt.st_scalar[fd.state_out] = st;
+    {   // the plane members after this frame
+        PwppPlaneState ps;
+        for (int i = 0; i < 3; ++i) {
+            ps.mean[i] = prev.mean[i];
+            ps.normal[i] = prev.normal[i];
+            ps.sv[i] = prev.sv[i];
+        }
+        ps.pad_ = 0.0f;
+        ps.d = prev.d;
+        Bt.st_plane[fd.state_out] = ps;
+    }
     {   // how full the fullest history is: the host grows the slabs before they run out (pwpp_capi.cpp)
         int mx = 0;
         for (int k = 0; k < 4; ++k) {
@@ -936,6 +956,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     __shared__ double s_ring_mean[PWPP_MAX_ROI], s_ring_std[PWPP_MAX_ROI];
     __shared__ unsigned s_seg_begin[PWPP_MAX_ROI], s_seg_end[PWPP_MAX_ROI];  // slice of s_pseq behind the statistics of ring ci
     __shared__ int s_len0[2][PWPP_MAX_ROI];           // history lengths before this frame
+    __shared__ int s_last_patch;                      // last bin of the frame that was fitted (its plane stays in the object's members)
     const int f = blockIdx.x;
     const PwppDevParams &P = Bt.P;
     const int B = P.num_bins, NB = B + 2;
@@ -951,6 +972,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
 
     if (threadIdx.x == 0) {
         s_dropped = 0;
+        s_last_patch = -1;
         PwppStateScalar st;
         if (fd.state_in >= 0) {
             st = Bt.st_scalar[fd.state_in];
@@ -1016,6 +1038,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         if (j >= per || bin >= B) continue;
         const unsigned n = nn[j];
         if ((uint64_t)n < P.min_pts) continue;  // small bin
+        atomicMax(&s_last_patch, bin);  // (an LDS atomic per fitted bin: two per thread with the default model)
         // concentric index of the bin
         const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
         int ci = (bin - P.bin_base[zone]) / P.sectors[zone];
@@ -1356,6 +1379,25 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
             }
         }
         Bt.st_scalar[fd.state_out] = s_st;
+        {   // the plane members after this frame: those of its last fitted bin, else what the stream's last frame left
+            PwppPlaneState ps;
+            if (s_last_patch >= 0) {
+                const PwppPatchRec lr = recs[s_last_patch];
+                for (int i = 0; i < 3; ++i) {
+                    ps.mean[i] = lr.mean[i];
+                    ps.normal[i] = lr.normal[i];
+                    ps.sv[i] = lr.sv[i];
+                }
+                ps.d = lr.d;
+            } else if (fd.state_in >= 0) {
+                ps = Bt.st_plane[fd.state_in];
+            } else {
+                for (int i = 0; i < 3; ++i) ps.mean[i] = ps.normal[i] = ps.sv[i] = 0.0f;
+                ps.d = 0.0;
+            }
+            ps.pad_ = 0.0f;
+            Bt.st_plane[fd.state_out] = ps;
+        }
         int mx = 0;
         for (int k = 0; k < 4; ++k) {
             mx = s_st.elev_len[k] > mx ? s_st.elev_len[k] : mx;

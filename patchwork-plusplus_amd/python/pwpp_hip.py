@@ -92,6 +92,8 @@ def load():
         L.pwpp_get_history.argtypes = [vp, ci, ci, ci, vp, ci]
         L.pwpp_set_state.argtypes = [vp, ci, ctypes.POINTER(State)]
         L.pwpp_set_history.argtypes = [vp, ci, ci, ci, vp, ci]
+        L.pwpp_get_plane_state.argtypes = [vp, ci, vp]
+        L.pwpp_set_plane_state.argtypes = [vp, ci, vp]
         L.pwpp_get_device_view.argtypes = [vp, ctypes.POINTER(DeviceView)]
         L.pwpp_set_profiling.argtypes = [vp, ci]
         L.pwpp_host_alloc.argtypes = [ctypes.POINTER(vp), ctypes.c_uint64]
@@ -298,16 +300,29 @@ class Handle:
         self._check(self._L.pwpp_set_history(self._h, stream, which, ring, _vp(v) if v.size else None, int(v.size)))
 
     def checkpoint(self, stream=0):
-        """Everything a stream carries from frame to frame (pwpp_get_state + the eight histories)."""
+        """Everything a stream carries from frame to frame (pwpp_get_state + the eight histories + the plane members)."""
         st = self.state(stream)
         return dict(sensor_height=st.sensor_height, elevation_thr=list(st.elevation_thr), flatness_thr=list(st.flatness_thr),
-                    hist=[[self.history(stream, w, r) for r in range(4)] for w in range(2)])
+                    hist=[[self.history(stream, w, r) for r in range(4)] for w in range(2)], plane=self.plane_state(stream))
 
     def restore(self, ck, stream=0):
         self.set_state(stream, ck["sensor_height"], ck["elevation_thr"], ck["flatness_thr"])
         for w in range(2):
             for r in range(4):
                 self.set_history(stream, w, r, ck["hist"][w][r])
+        if "plane" in ck:
+            self.set_plane_state(stream, ck["plane"])
+
+    def plane_state(self, index=0):
+        """{mean[3], normal[3], singular values[3], d} of the plane the stream's last frame fitted last (pwpp_get_plane_state)."""
+        out = np.zeros(10, np.float32)
+        self._check(self._L.pwpp_get_plane_state(self._h, index, _vp(out)))
+        return out
+
+    def set_plane_state(self, stream, values):
+        v = np.ascontiguousarray(values, np.float32)
+        assert v.shape == (10,)
+        self._check(self._L.pwpp_set_plane_state(self._h, stream, _vp(v)))
 
     def history(self, index, which, ring):
         n = self._check(self._L.pwpp_get_history(self._h, index, which, ring, None, 0))

@@ -1067,6 +1067,49 @@ def test_ros_wrapper_parameters_and_pointcloud2_input(kitti, oracle):
             h4.estimate_ground_fields(np.zeros(64, np.uint8), 1, *bad)
 
 
+def test_plane_members_carry_over_between_frames(kitti, oracle):
+    """The reference object's plane members (normal_, pc_mean_, singular_values_, d_) survive from call to call, and with
+    num_min_pts = 0 (the ROS launch file) a bin without points is "processed" and reports them: for a sensor with a
+    blind sector the first bins of frame k carry the plane the LAST bin of frame k - 1 was fitted with.  Sequences of a
+    stream, lock-step streams (one of them with the blind sector), a one-pass batch of streams, and a stream
+    checkpointed after two frames and continued on another handle -- against the oracle, which keeps the members as
+    the reference does."""
+    p = apply_variant(pwpp_hip.default_params(), ROS_LAUNCH)
+    op = to_oracle_params(p)
+
+    def blind(c, lo_deg, hi_deg):
+        a = np.degrees(np.arctan2(c[:, 1], c[:, 0])) % 360.0
+        return np.ascontiguousarray(c[~((a >= lo_deg) & (a < hi_deg)), :3])
+
+    seq = [blind(kitti[k], 0.0, 70.0) for k in range(5)]  # sectors 0-2 of zone 0 and more see nothing
+    est = ol.Estimator(oracle, op, arith=ol.ARITH_FXP)
+    refs = [est.run(c) for c in seq]
+    assert any(r.records["n_points"][0] == 0 for r in refs[1:]), "the first processed bin should be an empty one"
+    h = pwpp_hip.Handle(p)
+    for k, (c, ref) in enumerate(zip(seq, refs)):
+        h.estimate_ground(c)
+        assert_frame_equal(h, 0, ref, c.shape[0], state_index=0)
+        if k == 1:
+            ck = h.checkpoint(0)
+    assert np.abs(h.plane_state(0)[3:6]).max() > 0  # some plane is in the members
+    h2 = pwpp_hip.Handle(p)   # ... continued elsewhere from the checkpoint
+    h2.restore(ck, 0)
+    for c, ref in zip(seq[2:], refs[2:]):
+        h2.estimate_ground(c)
+        assert_frame_equal(h2, 0, ref, c.shape[0], state_index=0)
+    # lock-step streams, small (two-pass binning) and as a one-pass batch of six streams
+    for streams in (2, 6):
+        hs = pwpp_hip.Handle(p)
+        hs.set_num_streams(streams)
+        ests = [ol.Estimator(oracle, op, arith=ol.ARITH_FXP) for _ in range(streams)]
+        for step in range(3):
+            frames = [blind(kitti[(step + i) % 6], 0.0, 70.0) if i % 2 == 0 else np.ascontiguousarray(kitti[(step + i) % 6][:, :3])
+                      for i in range(streams)]
+            hs.estimate_ground_batch(frames, mode=pwpp_hip.MODE_STREAMS)
+            for i, c in enumerate(frames):
+                assert_frame_equal(hs, i, ests[i].run(c), c.shape[0])
+
+
 def test_dense_batch_one_pass_36_sectors(oracle):
     """BASELINE.json configs[4] as a BATCH (bench.py --workload dense): 32 dense 128-beam ~480 k-point frames,
     36-sector CZM, one-pass binning, overlap off and on; every frame against the oracle (only a
