@@ -40,7 +40,7 @@ def random_params(rng):
     if rng.random() < 0.5:
         p.num_lpr = int(rng.choice([3, 5, 10, 20, 40, 64]))
     if rng.random() < 0.5:
-        p.num_min_pts = int(rng.choice([3, 5, 10, 20, 50, 200]))
+        p.num_min_pts = int(rng.choice([0, 0, 1, 3, 5, 10, 20, 50, 200]))  # (0: empty bins are processed and report the plane fitted last)
     if rng.random() < 0.5:
         p.th_seeds = float(rng.choice([0.1, 0.125, 0.2, 0.3, 0.5]))
         p.th_dist = float(rng.choice([0.1, 0.125, 0.2, 0.3]))
@@ -68,6 +68,9 @@ def random_params(rng):
     return p
 
 
+ODD_HEIGHTS = True  # (switched off per case when num_min_pts <= 1: see the comment in random_cloud)
+
+
 def random_cloud(rng, sensor_height):
     beams = int(rng.choice([16, 32, 48, 64]))
     steps = int(rng.choice([400, 900, 1500, 2000]))
@@ -92,16 +95,22 @@ def random_cloud(rng, sensor_height):
         r[:, 2] = -sensor_height + float(rng.uniform(-0.3, 0.3)) * r[:, 0] + rng.normal(0, 0.02, k)
         r[:, 3] = 0.5
         extra.append(r)
-    if rng.random() < 0.4 and not os.environ.get("FUZZ_NO_ODD"):  # odd heights and duplicates
+    if rng.random() < 0.4 and ODD_HEIGHTS and not os.environ.get("FUZZ_NO_ODD"):  # odd heights and duplicates
         k = int(rng.integers(1, 30))
         o = pts[rng.integers(0, len(pts), k)].copy()
         # (no -inf: a patch whose LOWEST height is -inf has an empty first seed set, and the reference then fits with
-        # whatever plane its object computed last -- the one documented difference)
+        # whatever plane its object computed last -- the one documented difference, DESIGN.md section 5.  The same
+        # happens when the lowest height is so large that adding th_seeds does not change it -- a one-point patch at
+        # 1e30 m, possible with num_min_pts <= 1 -- so those parameter sets get no odd heights.)
         o[:, 2] = rng.choice(np.array([np.inf, 1e30, -1e30, 0.0, -0.0, 100.0, -100.0, 3e38, -3e38], np.float32), k)
         extra.append(o)
         extra.append(pts[rng.integers(0, len(pts), int(rng.integers(1, 200)))].copy())
     if rng.random() < 0.3:
         pts = pwpp_synth.add_edge_cases(pts, int(rng.integers(0, 1000)))
+    if rng.random() < 0.3:  # a blind sector (with num_min_pts = 0 its bins report the plane of the bin, or frame, before)
+        a0 = float(rng.uniform(0, 360))
+        ang = np.degrees(np.arctan2(pts[:, 1], pts[:, 0])) % 360.0
+        pts = pts[((ang - a0) % 360.0) > float(rng.uniform(20, 200))]
     if extra:
         pts = np.concatenate([pts] + extra).astype(np.float32)
         rng.shuffle(pts, axis=0)
@@ -113,6 +122,8 @@ def random_cloud(rng, sensor_height):
 def one_case(seed, oracle):
     rng = np.random.default_rng(seed)
     p = random_params(rng)
+    global ODD_HEIGHTS
+    ODD_HEIGHTS = p.num_min_pts > 1
     h = pwpp_hip.Handle(p)
     plan = PLANS[int(rng.integers(0, len(PLANS)))]
     if plan:
