@@ -167,9 +167,7 @@ int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32_t *n_non
  * moves a point that lies within ~1e-4 m of a threshold now and then (measured: 0-2 of 480 000 indices on
  * dense synthetic clouds, none on the KITTI samples; plane normals agree to 1e-4 except for ill-conditioned
  * patches, where a float build departs from exact arithmetic by more than this library does).
- * One known difference: a patch whose FIRST seed set is empty -- possible only when its lowest height is not finite
- * (z = -inf; NaN heights are undefined in the reference itself) or num_lpr = 0 -- starts from the zero plane here and
- * from whatever plane the reference object fitted last.
+ * (NaN heights are undefined in the reference itself: it sorts bins with `a.z < b.z`.)
  * The order inside a list is not the reference's unless pwpp_set_output_order asks for it. */
 int pwpp_get_ground_indices(pwpp_handle *h, int frame, int32_t *out);
 int pwpp_get_nonground_indices(pwpp_handle *h, int frame, int32_t *out);
@@ -203,6 +201,11 @@ int pwpp_set_history(pwpp_handle *h, int stream, int which /*0 elevation, 1 flat
  * ROS launch file's setting) reports whatever plane was fitted last, also across frames (patchworkpp.cpp:49).  Zero for a
  * new stream; a checkpoint is pwpp_get_state + the histories + this. */
 int pwpp_get_plane_state(pwpp_handle *h, int index, float out[10]);
+/* Frames this handle had to finish with the serial fix-up kernel: a patch whose first fit set is empty consults the
+ * plane the reference object fitted last (the patch before it, or the frame before), which the parallel fit kernels
+ * only recognise; the host then runs k_fit_fixup + the GLE and list kernels for that frame.  It takes a lowest height
+ * of -inf, one beyond 1e15 m, or num_lpr = 0 -- no real scan; the count exists for tests. */
+int64_t pwpp_get_fixed_up_frames(pwpp_handle *h);
 int pwpp_set_plane_state(pwpp_handle *h, int stream, const float in[10]);
 
 /* ---- ingest ----------------------------------------------------------------- */

@@ -147,6 +147,7 @@ struct pwpp_handle {
     int64_t total_points = 0;
     int cols = 4, layout = 0;
     long long one_pass_batches = 0, one_pass_redone = 0;
+    long long fixed_up_frames = 0;   // frames finished by k_fit_fixup (a patch needed the plane fitted before it)
 
     // workspace
     DevBuf<PwppFrameDesc> d_frames;
@@ -500,10 +501,34 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
     }
 }
 
+// a view of the batch's workspaces that covers the frames [f0, f0 + nf): every per-frame array is indexed by the frame
+PwppBatch frame_range(const pwpp_handle *h, const PwppBatch &bt, int f0, int nf) {
+    const int B = h->dp.num_bins, NB = B + 2, NP = PWPP_NUM_PARTS(B);
+    PwppBatch v = bt;
+    v.frames += f0;
+    v.num_frames = nf;
+    v.no_clear = 1;
+    v.bin_count += (size_t)f0 * NB;
+    v.bin_off += (size_t)f0 * NB;
+    v.part_count += (size_t)f0 * NP;
+    v.part_off += (size_t)f0 * NP;
+    v.part_cursor += (size_t)f0 * NP;
+    v.dst_a += (size_t)f0 * NB;
+    v.dst_b += (size_t)f0 * NB;
+    v.cls_start += (size_t)f0 * PWPP_CLS_STRIDE;
+    v.cls_list += (size_t)f0 * B;
+    v.recs += (size_t)f0 * B;
+    v.centers += (size_t)f0 * B * 3;
+    v.normals += (size_t)f0 * B * 3;
+    v.results += f0;
+    v.results_host += f0;
+    return v;
+}
+
 // Launches the pipeline over the batch described by h->descs (buffers sized, inputs on the device).
 // one_pass: fixed bin segments (k_czm_bin_scatter); otherwise the exact two-pass binning.
 int launch_prepared(pwpp_handle *h, bool one_pass) {
-    const int B = h->dp.num_bins, NB = B + 2, NP = PWPP_NUM_PARTS(B);
+    const int NP = PWPP_NUM_PARTS(h->dp.num_bins);
     const int frames = h->frames;
     // where a frame's bins live in the bin-ordered buffers
     int64_t base = 0;
@@ -541,28 +566,7 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     // other (tools/two_handles.py: +7.5 % on 1024 KITTI frames).  Every per-frame array is indexed by the
     // frame, so the halves are two views of the same workspaces with shifted base pointers.
     if (h->overlap && !h->profiling && !ordered && frames >= 128 && bt.debug == 0) {
-        auto range = [&](int f0, int nf) {
-            PwppBatch v = bt;
-            const int B = h->dp.num_bins;
-            v.frames += f0;
-            v.num_frames = nf;
-            v.no_clear = 1;
-            v.bin_count += (size_t)f0 * NB;
-            v.bin_off += (size_t)f0 * NB;
-            v.part_count += (size_t)f0 * NP;
-            v.part_off += (size_t)f0 * NP;
-            v.part_cursor += (size_t)f0 * NP;
-            v.dst_a += (size_t)f0 * NB;
-            v.dst_b += (size_t)f0 * NB;
-            v.cls_start += (size_t)f0 * PWPP_CLS_STRIDE;
-            v.cls_list += (size_t)f0 * B;
-            v.recs += (size_t)f0 * B;
-            v.centers += (size_t)f0 * B * 3;
-            v.normals += (size_t)f0 * B * 3;
-            v.results += f0;
-            v.results_host += f0;
-            return v;
-        };
+        auto range = [&](int f0, int nf) { return frame_range(h, bt, f0, nf); };
         // R frame ranges of whole groups of eight frames (K1' deals frames to the 8 XCDs).  Every range is launched
         // with the fit plan of the WHOLE batch (the machine is shared, not split).
         int R = h->overlap_ranges < 2 ? 2 : h->overlap_ranges;
@@ -664,7 +668,7 @@ int finish_pending(pwpp_handle *h) {
     const bool was_one_pass = h->one_pass;
     if (h->one_pass) {  // did every bin fit its segment?  if not, redo the batch on the exact two-pass path
         bool over = false;
-        for (int f = 0; f < h->frames; ++f) over = over || h->h_results.p[f].overflow != 0;
+        for (int f = 0; f < h->frames; ++f) over = over || (h->h_results.p[f].overflow & 1) != 0;
         h->one_pass = false;
         if (over) {
             ++h->one_pass_redone;
@@ -681,6 +685,29 @@ int finish_pending(pwpp_handle *h) {
             h->pending = true;
             if ((rc = finish_pending(h))) return rc;
             return read_observed(h);  // the exact counts of the redo size the next table
+        }
+    }
+    // Frames with a patch whose first fit set was empty (pwpp_fit.hip: needs_previous_plane -- a lowest height of -inf or
+    // beyond 1e15 m, num_lpr = 0; never a real scan): K5 / K6 left them alone; k_fit_fixup fits those patches in the
+    // reference's order from the plane fitted before them, then K5 and K6 finish the frame.
+    {
+        bool any = false;
+        for (int f = 0; f < h->frames; ++f) any = any || (h->h_results.p[f].overflow & 2) != 0;
+        if (any) {
+            PwppBatch bt;
+            fill_batch(h, bt);
+            bt.cap_off = was_one_pass ? h->d_cap_off.p : nullptr;
+            bt.fixup_run = 1;
+            const bool ordered = h->output_order == PWPP_ORDER_REFERENCE;
+            for (int f = 0; f < h->frames; ++f) {
+                if (!(h->h_results.p[f].overflow & 2)) continue;
+                const PwppBatch v = frame_range(h, bt, f, 1);
+                const int lrc = pwpp_launch_pipeline(&v, h->stream, nullptr, nullptr, nullptr, nullptr, ordered ? h->d_ord_a.p : nullptr,
+                                                     ordered ? h->d_ord_b.p : nullptr, 2 | 4 | 8);
+                if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+                ++h->fixed_up_frames;
+            }
+            HIPCHK(hipStreamSynchronize(h->stream));
         }
     }
     h->have_results = true;
@@ -1308,6 +1335,12 @@ int pwpp_set_state(pwpp_handle *h, int stream, const pwpp_state *in) {
     for (int k = 0; k < 4; ++k) s.elev_len[k] = s.flat_len[k] = 0;
     HIPCHK(hipMemcpy(h->d_st_stream.p + stream, &s, sizeof(s), hipMemcpyHostToDevice));
     return PWPP_OK;
+}
+
+int64_t pwpp_get_fixed_up_frames(pwpp_handle *h) {
+    if (!h) return PWPP_E_ARG;
+    if (use_device(h) || finish_pending(h)) return PWPP_E_HIP;
+    return (int64_t)h->fixed_up_frames;
 }
 
 int pwpp_get_plane_state(pwpp_handle *h, int index, float out[10]) {

@@ -94,13 +94,17 @@ struct PwppPatchRec {  // one per (frame, bin); written by k_patch_fit, finished
     int32_t n_nonground;
     int32_t decision;
     int32_t valid;  // 0: no fit ran in this bin (empty bin let through by num_min_pts <= 0); bit 1: the last pass skipped the
-                    // high part (its points are non-ground and have no plist entries: k_emit takes them from sorted_idx)
+                    // high part (its points are non-ground and have no plist entries: k_emit takes them from sorted_idx);
+                    // bit 2 (alone): the patch's first fit set was empty, so it works with the plane the reference object
+                    // fitted LAST (the patch before it, or the frame before): nothing was fitted yet, k_fit_fixup does it
 };
 
 struct PwppFrameResult {
     int32_t n_ground, n_nonground, n_patches, n_rnr, n_oor, n_dropped;
     int32_t hist_state;  // (entries of the fullest A-GLE history after this frame << 1) | a push found its slab full
-    int32_t overflow;  // one-pass binning: some bin of this frame outgrew its segment (the batch is redone on the two-pass path)
+    int32_t overflow;  // bit 0: one-pass binning: some bin of this frame outgrew its segment (the batch is redone on the two-pass
+                       // path); bit 1: some patch of the frame needs the plane fitted before it (PwppPatchRec.valid bit 2): K5 and K6
+                       // leave the frame alone and the host runs k_fit_fixup + K5 + K6 for it when the batch lands
 };
 
 // everything a launch needs, by value in the kernarg segment
@@ -116,6 +120,7 @@ struct PwppBatch {
     int32_t debug;               // option "debug_flags": 4 = timing probes of the fit chain, 16 = exact binning only, 16384 / 32768 =
                                  // force the fall-back paths of the lowest-point selection (tests); results never depend on it
     int32_t no_clear;            // the caller already launched k_clear for these frames (overlap mode: two frame ranges, two streams)
+    int32_t fixup_run;           // this launch finishes frames whose patches needed the plane fitted before them (k_fit_fixup ran): K5 / K6 do not skip them
     const uint32_t *cap_off;     // one-pass binning: [2B+3] first slot of every PART's fixed segment inside a frame
                                  // (cap_off[2B+2] = slots per frame); null on the two-pass path
     PwppStateScalar *st_scalar;  // [num_states]

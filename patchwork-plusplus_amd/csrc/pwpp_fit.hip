@@ -247,6 +247,26 @@ __device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &
     rec->valid = hi_skipped ? 3 : 1;
 }
 
+// The reference object's plane members survive from patch to patch (and frame to frame): a patch whose FIRST fit set is
+// empty consults whatever plane was fitted last (ref :49 -- the near-zone verticality test :489 or the first R-GPF round
+// :525).  That is a serial dependence on the patch before, so the parallel kernels only RECOGNISE the case (it needs a
+// lowest height of -inf, or one so large that th_seeds is absorbed, or num_lpr = 0: never seen in a real scan) and
+// leave the patch untouched; K5 / K6 then leave the frame alone and the host runs k_fit_fixup for it (pwpp_capi.cpp).
+//   no plane fitted yet and the stage's set is empty: an R-VPF round (its plane's z decides :489), the R-VPF fit of a
+//   far-zone bin that was only evaluated because the R-GPF seeds were empty too, or the R-GPF seeds with no R-VPF
+//   fit to fall back on -- the next thing would be a distance test against the stale plane.
+__device__ __forceinline__ bool needs_previous_plane(const PwppDevParams &P, int kind, int zone, bool fitted) {
+    return !fitted && (kind == ST_VPF || kind == ST_LAZY || (kind == ST_SEED && !(P.enable_RVPF != 0 && zone != 0)));
+}
+__device__ __forceinline__ void mark_needs_previous_plane(const PwppBatch &Bt, int f, PwppPatchRec *rec, unsigned n) {
+    rec->n_points = (int)n;
+    rec->n_ground = 0;
+    rec->n_nonground = (int)n;
+    rec->decision = 0;
+    rec->valid = 4;
+    atomicOr((unsigned *)&Bt.results[f].overflow, 2u);
+}
+
 // A patch in the part-ordered planes (pwpp_dev.h): the FRAME's planes z, {x, y}, cloud index (the frame is a grid
 // dimension, so these are scalar registers and a load is base + 32-bit lane offset) and the slots of the bin's two
 // parts in them -- the points below the split height zs and the others (z >= zs, or NaN).
@@ -757,6 +777,7 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
     FxpOrg org = fxp_org(pc.ox, pc.oy, 0.0f, scale, P.fxp_zr);
     int kind = !alive ? ST_DONE : ((P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED);  // row-uniform
     int it = 0;
+    bool fitted = false;  // a plane of this patch's own exists
 
     for (int guard = 0; guard < 4 * P.num_iter + 8; ++guard) {
         if (!__any(kind != ST_DONE)) break;
@@ -821,7 +842,14 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
                 for (int k = 0; k < 6; ++k)
                     s2[k] = join_halves(Row<G>::sum_i64(m.s2[k] & 0xffffffffLL), Row<G>::sum_i64(m.s2[k] >> 32));
             }
-            if (kind != ST_DONE && cnt > 0) plane_from_totals(cnt, s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug, pl);  // empty: ref :49
+            if (kind != ST_DONE && cnt > 0) {  // empty: ref :49
+                plane_from_totals(cnt, s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug, pl);
+                fitted = true;
+            }
+        }
+        if (kind != ST_DONE && needs_previous_plane(P, kind, zone, fitted)) {
+            if (j == 0) mark_needs_previous_plane(Bt, f, Bt.recs + (size_t)f * P.num_bins + bin, n);
+            kind = ST_DONE;
         }
         // (the rows of a wave may be at different stages: everything wave-wide -- wave_max_u32 -- stays outside the per-stage branches)
         const bool vertical = kind == ST_VPF && (double)pl.nz < P.uprightness_thr;  // ref :489
@@ -954,6 +982,7 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
     float z0 = 0.0f;
     int kind = !alive ? ST_DONE : ((P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED);
     int it = 0;
+    bool fitted = false;      // a plane of this patch's own exists
     bool hi_skipped = false;  // the last points phase of this patch did not read the high part
     // Dual seed pass (big bins, G == 64): the R-VPF round and the R-GPF seed stage of a zone-0 patch
     // select seeds from the same working set with the same lowest-point representative and two
@@ -1136,6 +1165,11 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
 #pragma unroll
                 for (int k = 0; k < 6; ++k) s2[k] = G == 64 ? join_halves(tot[4 + k], tot[MW == 16 ? 10 + k : 4 + k]) : (__int128)tot[4 + k];
                 plane_from_totals(cnt, s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug, pl);
+                fitted = true;
+            }
+            if (needs_previous_plane(P, kind, zone, fitted)) {
+                mark_needs_previous_plane(Bt, f, Bt.recs + (size_t)f * P.num_bins + bin, n);
+                kind = ST_DONE;
             }
         }
 
@@ -1225,6 +1259,7 @@ struct FitShared {
     unsigned keff;
     unsigned cnt_g;
     unsigned cnt_ng;
+    long long last_n;  // points of the set reduce_and_fit saw last
 };
 
 // per-lane sums of the workgroup-per-patch kernel: it takes patches of any size, so the second moments are
@@ -1286,6 +1321,7 @@ __device__ void reduce_and_fit(FitShared &sh, const MomentsWide &m, int shift, f
             for (int q = 0; q < kWaves; ++q) t[k] += sh.part[q][k];
         }
         const long long n = t[0];
+        if (ln == 0) sh.last_n = n;
         if (n > 0) {
             __int128 s2[6];
 #pragma unroll
@@ -1580,6 +1616,7 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
     const bool v_is_hi = P.th_seeds_v >= P.th_seeds;
     bool stash_valid = false;
     long long stash_cnt = 0;
+    bool fitted = false;  // a plane of this patch's own exists
     PlaneFit pl_seed = pl;
     if (threadIdx.x == 0) {
         sh.cnt_g = 0;
@@ -1599,6 +1636,7 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
     for (int guard = 0; guard < 4 * P.num_iter + 8 && kind != ST_DONE; ++guard) {
         if (kind == ST_SEED && stash_valid) {  // ref :513-517 on the unchanged working set: solved above
             if (stash_cnt > 0) pl = pl_seed;   // an empty seed set leaves the R-VPF plane in place (ref :49)
+            fitted = fitted || stash_cnt > 0;  // (an R-VPF round came first: had it been empty the patch would have stopped there)
             stash_valid = false;
             kind = ST_ITER;                    // (zone 0: never ST_LAZY)
             continue;
@@ -1711,19 +1749,25 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         }
         __syncthreads();
         probe(4);
-        PlaneFit fitted = pl;
+        PlaneFit fitted_pl = pl;
         if (tot[0] > 0) {  // empty: ref :49
             const long long s1[3] = {tot[1], tot[2], tot[3]};
-            plane_from_totals_uniform(tot[0], s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug, fitted);  // (totals are the same in every lane of this wave)
+            plane_from_totals_uniform(tot[0], s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug, fitted_pl);  // (totals are the same in every lane of this wave)
         }
         if (dual_now) {
-            if (ln == 0 && (wv == 0 || wv == kWaves / 2)) sh.plane[wv ? 1 : 0] = fitted;
+            if (ln == 0 && (wv == 0 || wv == kWaves / 2)) sh.plane[wv ? 1 : 0] = fitted_pl;
             __syncthreads();
             pl = sh.plane[0];
             pl_seed = sh.plane[1];
             stash_valid = true;
         } else {
-            pl = fitted;
+            pl = fitted_pl;
+        }
+        fitted = fitted || cnt > 0;
+        if (needs_previous_plane(P, kind, zone, fitted)) {  // (workgroup-uniform)
+            if (threadIdx.x == 0) mark_needs_previous_plane(Bt, f, Bt.recs + (size_t)f * P.num_bins + bin, n);
+            kind = ST_DONE;
+            continue;
         }
         probe(5);
         if (kind == ST_VPF) {
@@ -1787,10 +1831,10 @@ __global__ __launch_bounds__(kBlock, 1) void k_fit_hybrid(PwppBatch Bt, int b_mi
         fit_srows_body<64>(Bt, 0, b_mid, blockIdx.y - nb_big);
 }
 
-// the whole fit chain of one patch of any size by one workgroup (k_fit_stream: what exceeds the plan's classes)
-__device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch &Bt, int f, unsigned slot) {
+// the whole fit chain of one patch of any size by one workgroup (k_fit_stream: what exceeds the plan's classes;
+// k_fit_fixup: a patch that starts from the plane fitted before it, `init`)
+__device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch &Bt, int f, const PatchCtx &pc, const PwppPlaneState *init) {
     const PwppDevParams &P = Bt.P;
-    const PatchCtx pc = patch_ctx(Bt, f, slot, true);
     const int bin = pc.bin, zone = pc.zone;
     const unsigned n = pc.n;
     PwppPatchRec *rec = Bt.recs + (size_t)f * P.num_bins + bin;
@@ -1803,14 +1847,17 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
     const double scale = (double)(1 << P.fxp_shift);
 
     if (threadIdx.x == 0) {
-        sh.normal[0] = sh.normal[1] = sh.normal[2] = 0.0f;
-        sh.mean[0] = sh.mean[1] = sh.mean[2] = 0.0f;
-        sh.sv[0] = sh.sv[1] = sh.sv[2] = 0.0f;
-        sh.d = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            sh.normal[k] = init ? init->normal[k] : 0.0f;
+            sh.mean[k] = init ? init->mean[k] : 0.0f;
+            sh.sv[k] = init ? init->sv[k] : 0.0f;
+        }
+        sh.d = init ? init->d : 0.0;
         sh.cnt_g = 0;
         sh.cnt_ng = 0;
     }
     __syncthreads();
+    bool fitted = init != nullptr;  // (with the plane fitted before this patch in hand nothing is missing)
 
     double lpr = 0.0;
     bool lpr_valid = false, z0_set = false;
@@ -1842,6 +1889,11 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
                 }
             }
             reduce_and_fit(sh, m, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug);
+            fitted = fitted || sh.last_n > 0;
+            if (!fitted && zone == 0) {  // the verticality test below would consult the plane fitted before this patch
+                if (threadIdx.x == 0) mark_needs_previous_plane(Bt, f, rec, n);
+                return;
+            }
             const float nx = sh.normal[0], ny = sh.normal[1], nz = sh.normal[2];
             const double d = sh.d;
             if (zone == 0 && (double)nz < P.uprightness_thr) {  // ref :489
@@ -1878,6 +1930,11 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
             }
         }
         reduce_and_fit(sh, m, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug);
+        fitted = fitted || sh.last_n > 0;
+    }
+    if (!fitted) {  // the first R-GPF round would measure distances to the plane fitted before this patch
+        if (threadIdx.x == 0) mark_needs_previous_plane(Bt, f, rec, n);
+        return;
     }
     const int ln = lane_id();
     for (int it = 0; it < P.num_iter; ++it) {
@@ -1950,10 +2007,72 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
     const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
     const unsigned slot = cs[b_lo] + blockIdx.y;
     if (slot >= cs[PWPP_NUM_BUCKETS]) return;
-    fit_stream_patch(sh, Bt, f, slot);
+    fit_stream_patch(sh, Bt, f, patch_ctx(Bt, f, slot, true), nullptr);
 }
 
+// k_fit_fixup: the patches of a frame that need the plane fitted before them (needs_previous_plane), in the reference's
+// order: one workgroup walks the frame's bins in traversal order with the object's plane members in hand -- the plane
+// of the stream's last frame at first (PwppPlaneState), then the final plane of every fitted patch it passes -- and
+// fits the marked ones from there.  Launched by the host for the frames whose flag is set when a batch lands (never,
+// for real scans); K5 and K6 follow for those frames.
+__global__ __launch_bounds__(kBlock) void k_fit_fixup(PwppBatch Bt) {
+    __shared__ FitShared sh;
+    __shared__ PwppPlaneState cur;
+    const int f = blockIdx.x;
+    const PwppDevParams &P = Bt.P;
+    const PwppFrameDesc fd = Bt.frames[f];
+    const int B = P.num_bins, NP = PWPP_NUM_PARTS(B);
+    if (threadIdx.x == 0) {
+        if (fd.state_in >= 0) {
+            cur = Bt.st_plane[fd.state_in];
+        } else {
+            for (int k = 0; k < 3; ++k) cur.mean[k] = cur.normal[k] = cur.sv[k] = 0.0f;
+            cur.d = 0.0;
+        }
+    }
+    __syncthreads();
+    for (int bin = 0; bin < B; ++bin) {  // (workgroup-uniform)
+        const uint2 cnt = *reinterpret_cast<const uint2 *>(Bt.part_count + (size_t)f * NP + PWPP_PART_LO(bin));
+        const unsigned n = cnt.x + cnt.y;
+        if ((uint64_t)n < P.min_pts || n == 0u) continue;  // not a patch / nothing to fit (the members stay as they are)
+        PwppPatchRec *rec = Bt.recs + (size_t)f * B + bin;
+        if (rec->valid == 4) {
+            PatchCtx pc;
+            pc.bin = bin;
+            pc.zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
+            const uint2 off = *reinterpret_cast<const uint2 *>(Bt.part_off + (size_t)f * NP + PWPP_PART_LO(bin));
+            pc.n_lo = cnt.x;
+            pc.n_hi = cnt.y;
+            pc.off_lo = off.x;
+            pc.off_hi = off.y;
+            pc.n = n;
+            const float2 o = Bt.bin_origin[bin];
+            pc.ox = o.x;
+            pc.oy = o.y;
+            fit_stream_patch(sh, Bt, f, pc, &cur);
+            __threadfence_block();
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {  // the members after this patch
+            for (int k = 0; k < 3; ++k) {
+                cur.mean[k] = rec->mean[k];
+                cur.normal[k] = rec->normal[k];
+                cur.sv[k] = rec->sv[k];
+            }
+            cur.d = rec->d;
+        }
+        __syncthreads();
+    }
+}
+
+
 }  // namespace
+
+extern "C" int pwpp_launch_fixup(const PwppBatch *batch, hipStream_t stream) {
+    if (batch->num_frames <= 0) return 0;
+    hipLaunchKernelGGL(k_fit_fixup, dim3(batch->num_frames), dim3(kBlock), 0, stream, *batch);
+    return (int)hipGetLastError();
+}
 
 // launches of K4; ev (optional) = 7 events recorded around up to six launches
 #define PWPP_DEFAULT_FIT_PLAN "W16:1023,W64.2:65535"

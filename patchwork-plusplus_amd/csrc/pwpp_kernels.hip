@@ -559,6 +559,12 @@ __global__ __launch_bounds__(kBlock) void k_czm_scatter(PwppBatch Bt) {
     }
 }
 
+// A frame with a patch that needs the plane fitted before it (PwppPatchRec.valid == 4, pwpp_fit.hip) is left alone by
+// K5 / K6 / K7 -- its stream's state must not advance on half-fitted patches -- until the host has run k_fit_fixup.  K5
+// notices while it fetches the patch records it needs anyway (no extra round trip in front of its latency chain) and
+// tells K6 / K7 through a value they read anyway: list offsets of ~0.
+constexpr unsigned kAwaitsFixup = 0xFFFFFFFFu;
+
 // ------------------------------------------------------------------------------------------
 // K5  GLE + A-GLE history + TGR + adaptive thresholds, one workgroup per frame.
 // k_gle_tgr_seq: the reference's sequential loop (ref :184-311) executed by lane 0 in the
@@ -631,6 +637,10 @@ __global__ __launch_bounds__(64) void k_gle_tgr_seq(PwppBatch Bt) {
     PwppPatchRec *recs = Bt.recs + (size_t)f * B;
     unsigned *dst_a = Bt.dst_a + (size_t)f * NB;
     unsigned *dst_b = Bt.dst_b + (size_t)f * NB;
+    if (!Bt.fixup_run && (Bt.results[f].overflow & 2)) {  // a patch awaits k_fit_fixup
+        for (int b = 0; b < NB; ++b) dst_a[b] = kAwaitsFixup;
+        return;
+    }
     float *centers = Bt.centers + (size_t)f * B * 3;
     float *normals = Bt.normals + (size_t)f * B * 3;
 
@@ -1001,7 +1011,27 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
             }
         for (; ci <= roi; ++ci) s_ring_first[ci] = B;  // fewer rings than rings of interest
     }
-    __syncthreads();
+    // Consecutive bins per thread: as few as cover the model (2 for the default 504 bins), so that a
+    // single frame keeps all four waves busy instead of one thread walking eight bins.  Everything a
+    // bin needs from global memory (its count, its patch record) is fetched once, up front and
+    // unconditionally: the kernel is a latency chain, every dependent round trip costs ~1 us.
+    const int per = (B + kBlock - 1) / kBlock;
+    const int b0 = threadIdx.x * per;
+    unsigned nn[kGlePer];
+    PwppPatchRec rr[kGlePer];
+    int awaits = 0;
+#pragma unroll
+    for (int j = 0; j < kGlePer; ++j) {
+        const int bin = b0 + j;
+        const bool have = j < per && bin < B;
+        nn[j] = have ? cnt[bin] : 0u;
+        rr[j] = recs[have ? bin : 0];
+        if (have && nn[j] > 0u && (uint64_t)nn[j] >= P.min_pts && rr[j].valid == 4) awaits = 1;
+    }
+    if (__syncthreads_or(awaits && !Bt.fixup_run)) {  // a patch awaits k_fit_fixup: hands off (workgroup-uniform)
+        for (int b = threadIdx.x; b < NB; b += kBlock) dst_a[b] = kAwaitsFixup;
+        return;
+    }
     if (fd.state_in >= 0 && fd.state_in != fd.state_out) {  // carry the histories over
         const double *hist_in = Bt.st_hist + (size_t)fd.state_in * 8 * P.hist_cap;
         for (int w = 0; w < 8; ++w) {
@@ -1012,24 +1042,9 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     const int near_end = s_ring_first[roi];  // bins [0, near_end) are "near" (concentric_idx < roi)
 
     // ---- pass 1: per-bin GLE (ref :217-282) ------------------------------------------------
-    // Consecutive bins per thread: as few as cover the model (2 for the default 504 bins), so that a
-    // single frame keeps all four waves busy instead of one thread walking eight bins.  Everything a
-    // bin needs from global memory (its count, its patch record) is fetched once, up front and
-    // unconditionally: the kernel is a latency chain, every dependent round trip costs ~1 us.
-    const int per = (B + kBlock - 1) / kBlock;
-    const int b0 = threadIdx.x * per;
     unsigned a_patch = 0, a_push = 0;
     uint8_t dec[kGlePer];
     int ci_of[kGlePer];
-    unsigned nn[kGlePer];
-    PwppPatchRec rr[kGlePer];
-#pragma unroll
-    for (int j = 0; j < kGlePer; ++j) {
-        const int bin = b0 + j;
-        const bool have = j < per && bin < B;
-        nn[j] = have ? cnt[bin] : 0u;
-        rr[j] = recs[have ? bin : 0];
-    }
 #pragma unroll
     for (int j = 0; j < kGlePer; ++j) {
         const int bin = b0 + j;
@@ -1456,6 +1471,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt, bool keep_cat
     const unsigned off = Bt.bin_off[(size_t)f * NB + seg];
     int *out = Bt.out_idx + fd.base;
     const unsigned da = Bt.dst_a[(size_t)f * NB + seg];
+    if (da == kAwaitsFixup) return;  // K5 left the frame alone: the host sees the flag in the mirror and finishes it (k_fit_fixup)
     const bool whole = seg >= B || (uint64_t)n < P.min_pts;
     // the bin's high part (pwpp_dev.h): `n_lo` points at `off`, the others at `off_hi`
     // (a pseudo-bin is one part: its own count / offset stand in, no branch in front of the loads)
@@ -1633,6 +1649,7 @@ __global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned
     const int B = P.num_bins, NB = B + 2;
     const unsigned n = Bt.bin_count[(size_t)f * NB + seg];
     if (n < 1) return;
+    if (Bt.dst_a[(size_t)f * NB + seg] == kAwaitsFixup) return;  // (the frame awaits k_fit_fixup)
     const PwppFrameDesc fd = Bt.frames[f];
     int *out = Bt.out_idx + fd.base;
     const bool whole = seg >= B || (uint64_t)n < P.min_pts;
@@ -1725,6 +1742,7 @@ extern "C" int pwpp_launch_gather_xyz(const PwppFrameDesc *fd, const int *idx, i
 // ------------------------------------------------------------------------------------------
 extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
                                hipEvent_t aux_fork, hipEvent_t aux_join);
+extern "C" int pwpp_launch_fixup(const PwppBatch *batch, hipStream_t stream);
 
 // K0: the per-launch zeroing (histogram / cursor slabs and the frame counters) in ONE dispatch; two
 // hipMemsetAsync calls were three fill kernels of the runtime, ~6 us apart on the queue
@@ -1769,7 +1787,8 @@ extern "C" int pwpp_launch_histogram(const PwppBatch *batch, hipStream_t stream)
 }
 
 // stages: bit 0 = binning (K0-K3), bit 1 = plane fits + K5, bit 2 = index lists (K6, K7); the overlap schedule of
-// pwpp_capi.cpp launches the stages of a frame range on different streams
+// pwpp_capi.cpp launches the stages of a frame range on different streams.  Bit 3 (with bit 1): k_fit_fixup instead of the
+// fit kernels -- the host finishing a frame whose patches needed the plane fitted before them (batch->fixup_run set).
 extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev /* PWPP_NUM_KERNELS + 1 events or null */,
                                     hipStream_t aux, hipEvent_t aux_fork, hipEvent_t aux_join,
                                     unsigned long long *order_a /* reference-order mode: two scratch arrays, else null */,
@@ -1804,7 +1823,8 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
         }
     }
     if (stages & 2) {
-        const int frc = pwpp_launch_fit(batch, stream, ev ? ev + 3 : nullptr, aux, aux_fork, aux_join);  // records ev[3..9]
+        const int frc = (stages & 8) ? pwpp_launch_fixup(batch, stream)
+                                     : pwpp_launch_fit(batch, stream, ev ? ev + 3 : nullptr, aux, aux_fork, aux_join);  // records ev[3..9]
         if (frc) return frc;
         if (B.P.min_pts == 0)
             hipLaunchKernelGGL(k_gle_tgr_seq, dim3(F), dim3(64), 0, stream, B);  // empty bins inherit planes: serial

@@ -92,6 +92,8 @@ def load():
         L.pwpp_get_history.argtypes = [vp, ci, ci, ci, vp, ci]
         L.pwpp_set_state.argtypes = [vp, ci, ctypes.POINTER(State)]
         L.pwpp_set_history.argtypes = [vp, ci, ci, ci, vp, ci]
+        L.pwpp_get_fixed_up_frames.argtypes = [vp]
+        L.pwpp_get_fixed_up_frames.restype = ctypes.c_int64
         L.pwpp_get_plane_state.argtypes = [vp, ci, vp]
         L.pwpp_set_plane_state.argtypes = [vp, ci, vp]
         L.pwpp_get_device_view.argtypes = [vp, ctypes.POINTER(DeviceView)]
@@ -312,6 +314,10 @@ class Handle:
                 self.set_history(stream, w, r, ck["hist"][w][r])
         if "plane" in ck:
             self.set_plane_state(stream, ck["plane"])
+
+    def fixed_up_frames(self):
+        """Frames finished by the serial fix-up kernel so far (pwpp_get_fixed_up_frames)."""
+        return int(self._L.pwpp_get_fixed_up_frames(self._h))
 
     def plane_state(self, index=0):
         """{mean[3], normal[3], singular values[3], d} of the plane the stream's last frame fitted last (pwpp_get_plane_state)."""

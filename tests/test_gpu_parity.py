@@ -448,7 +448,7 @@ def test_split_bins_in_reference_order_and_one_pass_batches(kitti, oracle):
 def test_randomised_differential_cases(oracle):
     """tools/fuzz_parity.py: random parameter sets, random clouds with walls / ramps / huge and infinite heights /
     duplicates, random bin splits and fit plans, fresh batches, stateful sequences and lock-step streams -- every case
-    bit-identical to the oracle (400 more seeds ran clean when this was written; a failing seed reproduces with
+    bit-identical to the oracle (1200 more seeds ran clean when this was written; a failing seed reproduces with
     `python tools/fuzz_parity.py 1 <seed>`)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
@@ -1108,6 +1108,55 @@ def test_plane_members_carry_over_between_frames(kitti, oracle):
             hs.estimate_ground_batch(frames, mode=pwpp_hip.MODE_STREAMS)
             for i, c in enumerate(frames):
                 assert_frame_equal(hs, i, ests[i].run(c), c.shape[0])
+
+
+def test_patches_that_start_from_the_plane_fitted_before_them(kitti, oracle):
+    """A patch whose first fit set is empty consults whatever plane the reference object fitted last (patchworkpp.cpp:49:
+    the members survive from patch to patch and frame to frame).  It takes a lowest height of -inf, a lone height so large
+    that th_seeds is absorbed (1e30 m in a one-point patch), or num_lpr = 0 -- the parallel fit kernels recognise the
+    case, K5 / K6 leave the frame alone and the host finishes it with the serial k_fit_fixup.  Fresh batches under several
+    plans, a stateful sequence (the first dirty patch of a frame starts from the last plane of the frame before) and
+    lock-step streams, against the oracle."""
+    rng = np.random.default_rng(5)
+
+    def spoil(c, k):
+        c = c.copy()
+        pick = rng.choice(c.shape[0], k, replace=False)
+        c[pick, 2] = -np.inf                      # lowest height of its bin, wherever it falls
+        lone = np.array([[70.0, 30.0 + i, 1e30, 0.5] for i in range(3)] + [[3.5, -1.0, 3e38, 0.5]], np.float32)
+        return np.ascontiguousarray(np.concatenate([c, lone[:, :c.shape[1]]]))
+
+    syn = pwpp_synth.add_edge_cases(pwpp_synth.make_cloud(77, beams=32, azimuth_steps=1200), 77)
+    frames = [spoil(kitti[0], 40), spoil(syn, 25), kitti[1], spoil(kitti[5], 3)]
+    for variant in (dict(), dict(num_min_pts=1), dict(num_min_pts=0), dict(num_lpr=0), dict(enable_RVPF=0, num_min_pts=1)):
+        p = apply_variant(pwpp_hip.default_params(), variant)
+        op = to_oracle_params(p)
+        refs = [ol.Estimator(oracle, op, arith=ol.ARITH_FXP).run(c) for c in frames]
+        for plan in ("", "W16:1023,W64.2:65535", "S16:255,S64:65535", "B64:65535", "S16:100"):
+            h = pwpp_hip.Handle(p)
+            if plan:
+                h.set_option("fit_plan", plan)
+            h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+            for i, c in enumerate(frames):
+                assert_frame_equal(h, i, refs[i], c.shape[0])
+            assert h.fixed_up_frames() >= 1
+        # one stream, frame after frame; then two streams in lock step
+        est = ol.Estimator(oracle, op, arith=ol.ARITH_FXP)
+        h = pwpp_hip.Handle(p)
+        for c in frames + frames[:2]:
+            h.estimate_ground(c)
+            assert_frame_equal(h, 0, est.run(c), c.shape[0], state_index=0)
+        hs = pwpp_hip.Handle(p)
+        hs.set_num_streams(2)
+        ests = [ol.Estimator(oracle, op, arith=ol.ARITH_FXP) for _ in range(2)]
+        for step in range(3):
+            pair = [frames[step], frames[(step + 2) % 4]]
+            hs.estimate_ground_batch(pair, mode=pwpp_hip.MODE_STREAMS)
+            for i, c in enumerate(pair):
+                assert_frame_equal(hs, i, ests[i].run(c), c.shape[0])
+    clean = pwpp_hip.Handle()
+    clean.estimate_ground_batch(kitti, mode=pwpp_hip.MODE_FRESH)
+    assert clean.fixed_up_frames() == 0  # real scans never take the path
 
 
 def test_dense_batch_one_pass_36_sectors(oracle):

@@ -68,7 +68,7 @@ def random_params(rng):
     return p
 
 
-ODD_HEIGHTS = True  # (switched off per case when num_min_pts <= 1: see the comment in random_cloud)
+ODD_HEIGHTS = True
 
 
 def random_cloud(rng, sensor_height):
@@ -98,11 +98,9 @@ def random_cloud(rng, sensor_height):
     if rng.random() < 0.4 and ODD_HEIGHTS and not os.environ.get("FUZZ_NO_ODD"):  # odd heights and duplicates
         k = int(rng.integers(1, 30))
         o = pts[rng.integers(0, len(pts), k)].copy()
-        # (no -inf: a patch whose LOWEST height is -inf has an empty first seed set, and the reference then fits with
-        # whatever plane its object computed last -- the one documented difference, DESIGN.md section 5.  The same
-        # happens when the lowest height is so large that adding th_seeds does not change it -- a one-point patch at
-        # 1e30 m, possible with num_min_pts <= 1 -- so those parameter sets get no odd heights.)
-        o[:, 2] = rng.choice(np.array([np.inf, 1e30, -1e30, 0.0, -0.0, 100.0, -100.0, 3e38, -3e38], np.float32), k)
+        # (-inf as the lowest height of a bin, or a lone 1e30 with num_min_pts <= 1, leaves a patch's first seed set empty:
+        # it then starts from the plane the reference object fitted last -- the serial fix-up path, pwpp_fit.hip)
+        o[:, 2] = rng.choice(np.array([np.inf, -np.inf, 1e30, -1e30, 0.0, -0.0, 100.0, -100.0, 3e38, -3e38], np.float32), k)
         extra.append(o)
         extra.append(pts[rng.integers(0, len(pts), int(rng.integers(1, 200)))].copy())
     if rng.random() < 0.3:
@@ -123,7 +121,7 @@ def one_case(seed, oracle):
     rng = np.random.default_rng(seed)
     p = random_params(rng)
     global ODD_HEIGHTS
-    ODD_HEIGHTS = p.num_min_pts > 1
+    ODD_HEIGHTS = True
     h = pwpp_hip.Handle(p)
     plan = PLANS[int(rng.integers(0, len(PLANS)))]
     if plan:
