@@ -496,7 +496,12 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
             const uint32_t both = b < 2 * (size_t)B ? h->observed[b] + h->observed[b + 1] : (h->observed[b] > h->observed[b + 1] ? h->observed[b] : h->observed[b + 1]);
             biggest = both > biggest ? both : biggest;
         }
-        const int parts = (int)(biggest / 8192u) + 1;
+        int parts = (int)(biggest / 8192u) + 1;
+        // a few frames: the kernel is as long as the copy of its longest list by ONE wave (a 4 900-point patch: ten rounds of
+        // 512 entries, ~1 us each) -- eight waves per bin cut that chain (single frame: k_emit 13.2 -> see DESIGN.md), where a
+        // big batch would only pay for the empty waves (0.24 -> 0.30 ms with two per bin)
+        if (h->frames <= 8) parts = 8;
+        else if (h->frames <= 64 && parts < 4) parts = 4;
         bt.emit_parts = parts > 8 ? 8 : parts;
     }
 }

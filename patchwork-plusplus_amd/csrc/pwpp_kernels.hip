@@ -405,6 +405,9 @@ __global__ __launch_bounds__(BLOCK, 8) void k_czm_bin_scatter(PwppBatch Bt, int 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     __shared__ unsigned s_part[kBlock];
+    // the frame's part counts and offsets stay in LDS for the second half of the kernel (reading back what other
+    // threads just wrote to global memory is a round trip of its own, and a single frame waits for this chain)
+    __shared__ unsigned s_pc[PWPP_NUM_PARTS(PWPP_MAX_BINS)], s_po[PWPP_NUM_PARTS(PWPP_MAX_BINS)];
     const int f = blockIdx.x;
     const int B = Bt.P.num_bins, NB = B + 2, NP = PWPP_NUM_PARTS(B);
     unsigned *pcnt = Bt.part_count + (size_t)f * NP;
@@ -412,22 +415,30 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     if (Bt.cap_off) {  // one-pass binning: fixed segments; a part never reports more points than its segment holds
         for (int p = threadIdx.x; p < NP; p += kBlock) {
             const unsigned seg = Bt.cap_off[p], cap = Bt.cap_off[p + 1] - seg;
+            unsigned c = pcnt[p];
             poff[p] = seg;
-            if (pcnt[p] > cap) {
+            if (c > cap) {
+                c = cap;
                 pcnt[p] = cap;
                 Bt.results[f].overflow = 1;
             }
+            s_pc[p] = c;
+            s_po[p] = seg;
         }
     } else {
+        // as few consecutive parts per thread as cover the model (4 for the default 1010 parts): all four waves busy
         constexpr int kPer = (PWPP_NUM_PARTS(PWPP_MAX_BINS) + kBlock - 1) / kBlock;
+        const int per = (NP + kBlock - 1) / kBlock;
         unsigned local[kPer];
         unsigned sum = 0;
-        const int p0 = threadIdx.x * kPer;
+        const int p0 = threadIdx.x * per;
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
             const int p = p0 + j;
-            local[j] = p < NP ? ((pcnt[p] + 3u) & ~3u) : 0u;  // every part starts at a multiple of four slots: the fit kernels
-            sum += local[j];                                  // fetch four points (16 / 32 bytes) per lane and load
+            const unsigned c = (j < per && p < NP) ? pcnt[p] : 0u;
+            if (j < per && p < NP) s_pc[p] = c;
+            local[j] = (c + 3u) & ~3u;  // every part starts at a multiple of four slots: the fit kernels
+            sum += local[j];            // fetch four points (16 / 32 bytes) per lane and load
         }
         // inclusive scan inside the wave (DPP), then the four wave totals through LDS: one barrier
         // instead of the sixteen of a Hillis-Steele scan over 256 partials (a single frame waits for this)
@@ -440,30 +451,31 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
             const int p = p0 + j;
-            if (p < NP) poff[p] = run;
+            if (j < per && p < NP) {
+                poff[p] = run;
+                s_po[p] = run;
+            }
             run += local[j];
         }
     }
-    __syncthreads();  // (the part counts / offsets written above are read by other threads below)
+    __syncthreads();
     // what the host sizes the one-pass segments of the NEXT batches from (an overflowed part reports its clamped
     // count here; the exact redo that follows reports the true one)
     for (int p = threadIdx.x; p < NP; p += kBlock)
-        if (pcnt[p] > Bt.bin_max[p]) atomicMax(&Bt.bin_max[p], pcnt[p]);
+        if (s_pc[p] > Bt.bin_max[p]) atomicMax(&Bt.bin_max[p], s_pc[p]);
     // the bins: a bin's points = its two parts, its slots begin where its low part begins
     unsigned *cnt = Bt.bin_count + (size_t)f * NB;
     unsigned *off = Bt.bin_off + (size_t)f * NB;
+    __shared__ unsigned s_bc[PWPP_MAX_BINS + 2];
     for (int b = threadIdx.x; b < NB; b += kBlock) {
-        if (b < B) {
-            cnt[b] = pcnt[PWPP_PART_LO(b)] + pcnt[PWPP_PART_HI(b)];
-            off[b] = poff[PWPP_PART_LO(b)];
-        } else {
-            cnt[b] = pcnt[B + b];
-            off[b] = poff[B + b];
-        }
+        const unsigned c = b < B ? s_pc[PWPP_PART_LO(b)] + s_pc[PWPP_PART_HI(b)] : s_pc[B + b];
+        cnt[b] = c;
+        s_bc[b] = c;
+        off[b] = b < B ? s_po[PWPP_PART_LO(b)] : s_po[B + b];
     }
     if (threadIdx.x == 0) {
-        Bt.results[f].n_rnr = (int)pcnt[2 * B];
-        Bt.results[f].n_oor = (int)pcnt[2 * B + 1];
+        Bt.results[f].n_rnr = (int)s_pc[2 * B];
+        Bt.results[f].n_oor = (int)s_pc[2 * B + 1];
     }
     __syncthreads();
     // patches of this frame sorted by size bucket (work lists of the K4 kernels)
@@ -474,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     }
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += kBlock) {
-        const unsigned n = cnt[b];
+        const unsigned n = s_bc[b];
         if ((uint64_t)n < Bt.P.min_pts) continue;  // small bin (ref :191-195)
         PwppPatchRec *rec = Bt.recs + (size_t)f * B + b;
         rec->valid = 0;
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     __syncthreads();
     for (int c = threadIdx.x; c <= PWPP_NUM_BUCKETS; c += kBlock) Bt.cls_start[(size_t)f * PWPP_CLS_STRIDE + c] = s_start[c];
     for (int b = threadIdx.x; b < B; b += kBlock) {
-        const unsigned n = cnt[b];
+        const unsigned n = s_bc[b];
         if ((uint64_t)n < Bt.P.min_pts || n == 0) continue;
         const int c = pwpp_size_bucket(n);
         Bt.cls_list[(size_t)f * B + s_start[c] + atomicAdd(&s_cur[c], 1u)] = (uint16_t)b;
@@ -1465,18 +1477,24 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt, bool keep_cat
     if (seg == 0 && blockIdx.z == 0 && threadIdx.x == 0) Bt.results_host[f] = Bt.results[f];
     const PwppDevParams &P = Bt.P;
     const int B = P.num_bins, NB = B + 2;
-    const unsigned n = Bt.bin_count[(size_t)f * NB + seg];
-    if (n == 0) return;
+    // Everything the wave needs to know about its bin, fetched at once and unconditionally (nine independent loads, one
+    // round trip: a single frame waits for this kernel's chain, and a load behind a branch is a round trip of its own).
+    // A pseudo-bin is one part -- its own count / offset stand in -- and has no patch record: that of bin 0 is read and ignored.
     const PwppFrameDesc fd = Bt.frames[f];
+    const unsigned n = Bt.bin_count[(size_t)f * NB + seg];
     const unsigned off = Bt.bin_off[(size_t)f * NB + seg];
-    int *out = Bt.out_idx + fd.base;
     const unsigned da = Bt.dst_a[(size_t)f * NB + seg];
-    if (da == kAwaitsFixup) return;  // K5 left the frame alone: the host sees the flag in the mirror and finishes it (k_fit_fixup)
-    const bool whole = seg >= B || (uint64_t)n < P.min_pts;
-    // the bin's high part (pwpp_dev.h): `n_lo` points at `off`, the others at `off_hi`
-    // (a pseudo-bin is one part: its own count / offset stand in, no branch in front of the loads)
+    const unsigned db = Bt.dst_b[(size_t)f * NB + seg];
     const unsigned n_lo = Bt.part_count[(size_t)f * PWPP_NUM_PARTS(B) + (seg < B ? PWPP_PART_LO(seg) : B + seg)];
     const unsigned off_hi = Bt.part_off[(size_t)f * PWPP_NUM_PARTS(B) + (seg < B ? PWPP_PART_HI(seg) : B + seg)];
+    const PwppPatchRec *rec = Bt.recs + (size_t)f * B + (seg < B ? seg : 0);
+    const unsigned ng = (unsigned)rec->n_ground;
+    const int rec_valid = rec->valid;
+    if (n == 0) return;
+    if (da == kAwaitsFixup) return;  // K5 left the frame alone: the host sees the flag in the mirror and finishes it (k_fit_fixup)
+    int *out = Bt.out_idx + fd.base;
+    const bool whole = seg >= B || (uint64_t)n < P.min_pts;
+    // the bin's high part (pwpp_dev.h): `n_lo` points at `off`, the others at `off_hi`
     const int *idx_lo = Bt.sorted_idx + fd.sbase + off, *idx_hi = Bt.sorted_idx + fd.sbase + off_hi;
     // blockIdx.z = part of the list this wave copies (long lists -- dense clouds have bins of 10^4 points -- are
     // dealt out in blocks of 512 entries to gridDim.z waves; eight loads in flight per lane)
@@ -1500,11 +1518,8 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt, bool keep_cat
     // back.  If that pass skipped the high part (rec.valid bit 1), the n - n_lo entries in between were never written:
     // they are the high part's points, all of them non-ground, taken from the part itself.
     const int *src = Bt.plist + fd.sbase + off;
-    const PwppPatchRec *rec = Bt.recs + (size_t)f * B + seg;
-    const unsigned ng = (unsigned)rec->n_ground;
-    const unsigned n_gap = (rec->valid & 2) ? n - n_lo : 0u;
+    const unsigned n_gap = (rec_valid & 2) ? n - n_lo : 0u;
     const float *z_hi = Bt.sorted_z + fd.sbase + off_hi;
-    const unsigned db = Bt.dst_b[(size_t)f * NB + seg];
     for (unsigned i0 = part * (kU * kEmitBlock) + threadIdx.x; i0 < n; i0 += parts * (kU * kEmitBlock)) {
         int v[kU];
 #pragma unroll
