@@ -132,27 +132,42 @@ def one_case(seed, oracle):
         h.set_option("hi_split_zones", 0)
     if os.environ.get("FUZZ_PLAN") is not None:
         h.set_option("fit_plan", os.environ["FUZZ_PLAN"])
-    opm = rng.random() < 0.2
+    opm = rng.random() < 0.25
     if opm:
         h.set_option("one_pass_min_frames", 1)
+        if rng.random() < 0.5:
+            h.set_option("one_pass_scale", float(rng.choice([0.02, 0.2, 1.0])))  # segments far too small: overflow, exact redo
+    ordered = rng.random() < 0.2   # the reference's own order inside the lists (ties among equal heights aside)
+    h.set_output_order(ordered)
+    fortran = rng.random() < 0.2   # column-major matrices (Eigen's storage)
     mode = rng.random()
     global LAST
-    LAST = "plan '%s' one_pass_min_frames=1: %s mode %.2f" % (plan, opm, mode)
+    LAST = "plan '%s' one_pass_min_frames=1: %s ordered %s fortran %s mode %.2f" % (plan, opm, ordered, fortran, mode)
+
+    def check(i, ref, pts, **kw):
+        assert_frame_equal(h, i, ref, pts.shape[0], **kw)
+        if ordered:
+            z = pts[:, 2]
+            for mine, theirs in ((h.ground_indices(i), ref.ground_idx), (h.nonground_indices(i), ref.nonground_idx)):
+                assert np.array_equal(z[mine], z[np.asarray(theirs)], equal_nan=True), "the z sequence differs from the reference's"
+
+    def lay(c):
+        return np.asfortranarray(c) if fortran else c
     if mode < 0.45:  # a fresh batch
         frames = [random_cloud(rng, p.sensor_height) for _ in range(int(rng.integers(1, 7)))]
         if len({f.shape[1] for f in frames}) > 1:
             frames = [np.ascontiguousarray(f[:, :3]) for f in frames]
-        h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+        h.estimate_ground_batch([lay(f) for f in frames], mode=pwpp_hip.MODE_FRESH)
         for i, pts in enumerate(frames):
-            assert_frame_equal(h, i, ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(pts), pts.shape[0])
+            check(i, ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(pts), pts)
         return "batch of %d" % len(frames)
     if mode < 0.8:  # one stateful stream, frame after frame
         est = ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP)
         n = int(rng.integers(2, 6))
         for _ in range(n):
             pts = random_cloud(rng, p.sensor_height)
-            h.estimate_ground(pts)
-            assert_frame_equal(h, 0, est.run(pts), pts.shape[0], state_index=0)
+            h.estimate_ground(lay(pts))
+            check(0, est.run(pts), pts, state_index=0)
         return "sequence of %d" % n
     streams = int(rng.integers(2, 5))  # several streams in lock step
     h.set_num_streams(streams)
@@ -162,9 +177,9 @@ def one_case(seed, oracle):
         frames = [random_cloud(rng, p.sensor_height) for _ in range(streams)]
         if cols == 3 or len({f.shape[1] for f in frames}) > 1:  # (one column count per call)
             frames = [np.ascontiguousarray(f[:, :3]) for f in frames]
-        h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_STREAMS)
+        h.estimate_ground_batch([lay(f) for f in frames], mode=pwpp_hip.MODE_STREAMS)
         for i, pts in enumerate(frames):
-            assert_frame_equal(h, i, ests[i].run(pts), pts.shape[0])
+            check(i, ests[i].run(pts), pts)
     return "%d streams" % streams
 
 
