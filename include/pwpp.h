@@ -190,7 +190,8 @@ double pwpp_get_time_us(pwpp_handle *h);
 /* state after the last call; PWPP_MODE_FRESH: `index` is the frame, PWPP_MODE_STREAMS: the stream */
 int pwpp_get_state(pwpp_handle *h, int index, pwpp_state *out);
 int pwpp_get_history(pwpp_handle *h, int index, int which /*0 elevation, 1 flatness*/, int ring, double *out, int capacity);
-/* overwrite the scalars of a stream state; its histories are cleared (elevation_len / flatness_len of `in` are ignored) */
+/* overwrite the scalars of a stream state; its histories are cleared (elevation_len / flatness_len of `in` are ignored),
+ * its plane members (pwpp_set_plane_state) are left as they are */
 int pwpp_set_state(pwpp_handle *h, int stream, const pwpp_state *in);
 /* ... and put a history back: after pwpp_set_state + eight pwpp_set_history calls with what pwpp_get_state /
  * pwpp_get_history returned, a stream continues exactly where the checkpointed one stood. */

@@ -18,9 +18,13 @@
 //   k_fit_hybrid            the single-frame kernel: k_fit_brows' body for the big patches, k_fit_srows<64>'s
 //                           for the small ones (four per workgroup), one launch, one workgroup per CU
 //   k_fit_stream            whatever exceeds the plan: workgroup per patch, 128-bit lane sums
+//   k_fit_fixup             (run by the host for marked frames only) the patches whose first fit set is empty, in
+//                           the reference's order: they start from the plane the object fitted last
 //
 // The bin-ordered records are planes (pwpp_dev.h): the lowest-point pass streams z alone (4 B per
 // point), every other pass z and {x, y} (12 B), the pass that writes the split also the cloud index.
+// A near-zone bin is stored in two parts, below and above a split height: every pass skips the high part
+// when it can prove that none of its points can enter (stage_needs_hi).
 // DESIGN.md section 3 has the measurements that led here (and the variants that were dropped: points
 // parked in LDS, the chain cut into phase kernels).
 //

@@ -8,10 +8,11 @@
 //   K1' k_czm_bin_scatter  RNR + CZM code per point, straight into the bin's FIXED segment   (ref :377-400, :578-622)
 //       (or K1 k_czm_bin + K3 k_czm_scatter: histogram, then scatter -- the exact two-pass path
 //        for <= 4 frames and for the redo after a segment overflow)
-//   K2  k_czm_scan         bin offsets, patches sorted into size buckets
+//   K2  k_czm_scan         part / bin offsets (a near-zone bin = a low and a high part, pwpp_dev.h), patches sorted into size buckets
 //   K4  k_fit_*            per patch: LPR seeds, R-VPF, R-GPF, final plane       (ref :77-149, :47-75, :467-554)
 //                          one or two launches by patch size, see pwpp_fit.hip
-//   K5  k_gle_tgr          per frame: GLE ladder, A-GLE history, TGR, thresholds (ref :211-309, :338-375, :402-464)
+//   K5  k_gle_tgr          per frame: GLE ladder, A-GLE history, TGR, thresholds (ref :211-309, :338-375, :402-464);
+//                          the object's plane members after the frame (PwppPlaneState)
 //   K6  k_emit             ground / non-ground index lists                       (ref :28-31, :18-26);
 //                          mirrors the frame counters into pinned host memory
 //   K7  k_order_sublists   optional: the reference's order inside every part of the lists
