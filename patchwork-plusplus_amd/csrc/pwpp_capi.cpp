@@ -1342,6 +1342,24 @@ int pwpp_set_state(pwpp_handle *h, int stream, const pwpp_state *in) {
     return PWPP_OK;
 }
 
+int pwpp_get_bin_boxes(const pwpp_params *p, float *out_boxes, int capacity_bins) {
+    if (!p) return fail(PWPP_E_ARG, "null params");
+    PwppDevParams dp;
+    const int rc = build_dev_params(*p, dp);
+    if (rc < 0) return rc;
+    if (!out_boxes) return dp.num_bins;
+    if (capacity_bins < dp.num_bins) return fail(PWPP_E_ARG, "room for %d bins, %d needed", capacity_bins, dp.num_bins);
+    std::vector<float4> boxes;
+    bin_boxes(dp, boxes);
+    for (int b = 0; b < dp.num_bins; ++b) {
+        out_boxes[4 * b] = boxes[(size_t)b].x;
+        out_boxes[4 * b + 1] = boxes[(size_t)b].y;
+        out_boxes[4 * b + 2] = boxes[(size_t)b].z;
+        out_boxes[4 * b + 3] = boxes[(size_t)b].w;
+    }
+    return dp.num_bins;
+}
+
 int64_t pwpp_get_fixed_up_frames(pwpp_handle *h) {
     if (!h) return PWPP_E_ARG;
     if (use_device(h) || finish_pending(h)) return PWPP_E_HIP;

@@ -131,3 +131,81 @@ def test_c_abi_from_plain_c99():
         return
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "no CPU path" in r.stderr
+
+
+def _numpy_bins(pts, p):
+    """pc2czm (reference patchworkpp.cpp:578-622) in numpy doubles: the bin of every point, -1 outside (min_range, max_range]."""
+    import numpy as np
+    x, y = pts[:, 0].astype(np.float64), pts[:, 1].astype(np.float64)
+    r = np.sqrt(x * x + y * y)
+    th = np.arctan2(y, x)
+    th = np.where(th > 0, th, th + 2 * np.pi)
+    mn, mx = p.min_range, p.max_range
+    mr = [mn, (7 * mn + mx) / 8, (3 * mn + mx) / 4, (mn + mx) / 2, mx]
+    rings, sect = list(p.num_rings_each_zone), list(p.num_sectors_each_zone)
+    base = np.cumsum([0] + [a * b for a, b in zip(rings, sect)])
+    ok = (r > mn) & (r <= mx)
+    k = np.digitize(r, mr[1:4])
+    code = np.full(len(r), -1)
+    for z in range(4):
+        m = ok & (k == z)
+        ring = np.minimum(((r[m] - mr[z]) / ((mr[z + 1] - mr[z]) / rings[z])).astype(int), rings[z] - 1)
+        sec = np.minimum((th[m] / (2 * np.pi / sect[z])).astype(int), sect[z] - 1)
+        code[m] = base[z] + ring * sect[z] + sec
+    return code
+
+
+def test_bin_boxes_contain_every_point_the_reference_bins_there(lib):
+    """The fit kernels skip the high part of a bin when no point of the box [bin box] x [split height, inf) can lie below
+    the plane (pwpp_fit.hip, stage_needs_hi): that is only exact if every point the reference bins into b lies inside
+    box b.  Host logic, no GPU: random clouds plus points on every boundary the binning has (ring and sector edges nudged
+    by a few float ulps, the axes, the diagonals, min / max range), for CZM shapes from one sector per ring to 128."""
+    import numpy as np
+    lib.pwpp_get_bin_boxes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    rng = np.random.default_rng(3)
+    shapes = [((16, 32, 54, 32), (2, 4, 4, 4), 2.7, 80.0), ((36, 36, 36, 36), (2, 4, 4, 4), 2.7, 80.0),
+              ((1, 1, 1, 1), (1, 1, 1, 1), 2.7, 80.0), ((2, 3, 5, 7), (1, 2, 3, 1), 0.3, 200.0),
+              ((128, 128, 128, 128), (4, 4, 4, 4), 1.0, 50.0), ((4, 8, 16, 4), (5, 1, 2, 3), 5.0, 20.0)]
+    for sect, rings, mn, mx in shapes:
+        p = pwpp_hip.default_params()
+        p.min_range, p.max_range = mn, mx
+        for k in range(4):
+            p.num_sectors_each_zone[k] = sect[k]
+            p.num_rings_each_zone[k] = rings[k]
+        nb = lib.pwpp_get_bin_boxes(ctypes.byref(p), None, 0)
+        assert nb == sum(a * b for a, b in zip(sect, rings))
+        boxes = np.zeros((nb, 4), np.float32)
+        assert lib.pwpp_get_bin_boxes(ctypes.byref(p), boxes.ctypes.data_as(ctypes.c_void_p), nb) == nb
+        mr = [mn, (7 * mn + mx) / 8, (3 * mn + mx) / 4, (mn + mx) / 2, mx]
+        radii, angles = [mn, mx], [0.0]
+        for z in range(4):
+            radii += [mr[z] + i * (mr[z + 1] - mr[z]) / rings[z] for i in range(rings[z] + 1)]
+            angles += [i * 2 * np.pi / sect[z] for i in range(sect[z] + 1)]
+        angles += [q * np.pi / 4 for q in range(9)]
+        pts = []
+        for r in radii:
+            for dr in (-3e-7, -1e-7, 0.0, 1e-7, 3e-7):
+                rr = r * (1 + dr)
+                a = rng.uniform(0, 2 * np.pi, 40)
+                pts.append(np.stack([rr * np.cos(a), rr * np.sin(a)], 1))
+                aa = np.array(angles)
+                pts.append(np.stack([rr * np.cos(aa), rr * np.sin(aa)], 1))
+        for a in angles:
+            for da in (-3e-7, -1e-7, 0.0, 1e-7, 3e-7):
+                rr = rng.uniform(mn, mx, 25)
+                pts.append(np.stack([rr * np.cos(a + da), rr * np.sin(a + da)], 1))
+        rr, a = rng.uniform(0.5 * mn, 1.05 * mx, 20000), rng.uniform(0, 2 * np.pi, 20000)
+        pts.append(np.stack([rr * np.cos(a), rr * np.sin(a)], 1))
+        for ux, uy in ((1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, 1), (1, -1), (-1, -1)):  # exact axes and diagonals
+            rr = rng.uniform(mn, mx, 50).astype(np.float32)
+            pts.append(np.stack([rr * ux / np.hypot(ux, uy), rr * uy / np.hypot(ux, uy)], 1))
+        xy = np.concatenate(pts).astype(np.float32)
+        code = _numpy_bins(xy, p)
+        m = code >= 0
+        b = boxes[code[m]]
+        assert (xy[m, 0] >= b[:, 0]).all() and (xy[m, 0] <= b[:, 1]).all() and (xy[m, 1] >= b[:, 2]).all() and (xy[m, 1] <= b[:, 3]).all()
+        # ... and the boxes are not absurdly generous: each is inside the circle of radius max_range (+ its margin)
+        assert np.abs(boxes).max() <= mx * 1.0002 + 0.002
+        # (a bin of a quarter turn or less is a proper sector: its box is smaller than the full disc's)
+        if min(sect) >= 4:
+            assert ((boxes[:, 1] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 2])).max() < (2 * mx) ** 2 * 0.5
