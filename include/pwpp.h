@@ -207,6 +207,10 @@ int pwpp_get_plane_state(pwpp_handle *h, int index, float out[10]);
  * only recognise; the host then runs k_fit_fixup + the GLE and list kernels for that frame.  It takes a lowest height
  * of -inf, one beyond 1e15 m, or num_lpr = 0 -- no real scan; the count exists for tests. */
 int64_t pwpp_get_fixed_up_frames(pwpp_handle *h);
+/* Host only (no device needed): shift and per-bin origins {ox, oy} of the fixed-point plane-fit sums a handle created with
+ * these parameters would use (= pwpp_get_fxp_shift / pwpp_get_fxp_origins of that handle).  The CPU tests compare them with
+ * the restatement's for many CZM shapes.  Returns the number of bins; shift / out_xy may be NULL. */
+int pwpp_get_fxp_geometry(const pwpp_params *p, int *shift, float *out_xy, int capacity_bins);
 /* Host only (no device needed): the axis-aligned box {xmin, xmax, ymin, ymax} the library assumes around every CZM bin of
  * a parameter set, bins in traversal order (zone, ring, sector).  The fit kernels prove with it that no point of a bin's
  * high part can lie below a plane, so every point the reference bins into b must lie inside box b:

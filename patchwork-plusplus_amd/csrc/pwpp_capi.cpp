@@ -1342,6 +1342,25 @@ int pwpp_set_state(pwpp_handle *h, int stream, const pwpp_state *in) {
     return PWPP_OK;
 }
 
+int pwpp_get_fxp_geometry(const pwpp_params *p, int *shift, float *out_xy, int capacity_bins) {
+    if (!p) return fail(PWPP_E_ARG, "null params");
+    PwppDevParams dp;
+    const int rc = build_dev_params(*p, dp);
+    if (rc < 0) return rc;
+    std::vector<float2> origin;
+    int s = 0;
+    fxp_geometry(dp, origin, s);
+    if (shift) *shift = s;
+    if (out_xy) {
+        if (capacity_bins < dp.num_bins) return fail(PWPP_E_ARG, "room for %d bins, %d needed", capacity_bins, dp.num_bins);
+        for (int b = 0; b < dp.num_bins; ++b) {
+            out_xy[2 * b] = origin[(size_t)b].x;
+            out_xy[2 * b + 1] = origin[(size_t)b].y;
+        }
+    }
+    return dp.num_bins;
+}
+
 int pwpp_get_bin_boxes(const pwpp_params *p, float *out_boxes, int capacity_bins) {
     if (!p) return fail(PWPP_E_ARG, "null params");
     PwppDevParams dp;

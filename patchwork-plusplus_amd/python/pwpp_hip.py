@@ -93,6 +93,7 @@ def load():
         L.pwpp_set_state.argtypes = [vp, ci, ctypes.POINTER(State)]
         L.pwpp_set_history.argtypes = [vp, ci, ci, ci, vp, ci]
         L.pwpp_get_bin_boxes.argtypes = [vp, vp, ci]
+        L.pwpp_get_fxp_geometry.argtypes = [vp, vp, vp, ci]
         L.pwpp_get_fixed_up_frames.argtypes = [vp]
         L.pwpp_get_fixed_up_frames.restype = ctypes.c_int64
         L.pwpp_get_plane_state.argtypes = [vp, ci, vp]

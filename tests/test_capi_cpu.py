@@ -209,3 +209,32 @@ def test_bin_boxes_contain_every_point_the_reference_bins_there(lib):
         # (a bin of a quarter turn or less is a proper sector: its box is smaller than the full disc's)
         if min(sect) >= 4:
             assert ((boxes[:, 1] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 2])).max() < (2 * mx) ** 2 * 0.5
+
+
+def test_fixed_point_geometry_matches_the_restatement(lib, oracle_built):
+    """Shift and per-bin origins of the plane-fit sums are computed on the host in pwpp_create and,
+    independently, by the CPU restatement: they must agree for every CZM shape and range -- host logic, no GPU."""
+    import numpy as np
+    lib.pwpp_get_fxp_geometry.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    ora = oracle_built.restatement()
+    rng = np.random.default_rng(11)
+    shapes = [((16, 32, 54, 32), (2, 4, 4, 4), 2.7, 80.0), ((1, 1, 1, 1), (1, 1, 1, 1), 2.7, 80.0), ((3, 3, 3, 3), (2, 2, 2, 2), 2.7, 80.0),
+              ((128, 128, 128, 128), (4, 4, 4, 4), 1.0, 50.0), ((16, 32, 54, 32), (2, 4, 4, 4), 2.7, 500.0), ((4, 4, 4, 4), (1, 1, 1, 1), 0.3, 8000.0)]
+    for _ in range(20):
+        shapes.append((tuple(int(v) for v in rng.choice([1, 2, 3, 4, 5, 8, 16, 36, 54, 64], 4)), tuple(int(v) for v in rng.integers(1, 7, 4)),
+                       float(rng.uniform(0.1, 5.0)), float(rng.uniform(10.0, 3000.0))))
+    for sect, rings, mn, mx in shapes:
+        p = pwpp_hip.default_params()
+        p.min_range, p.max_range = mn, mx
+        op = ora.default_params()
+        op.min_range, op.max_range = mn, mx
+        for k in range(4):
+            p.num_sectors_each_zone[k] = op.num_sectors_each_zone[k] = sect[k]
+            p.num_rings_each_zone[k] = op.num_rings_each_zone[k] = rings[k]
+        nb = sum(a * b for a, b in zip(sect, rings))
+        shift = ctypes.c_int(-1)
+        xy = np.zeros((nb, 2), np.float32)
+        assert lib.pwpp_get_fxp_geometry(ctypes.byref(p), ctypes.byref(shift), xy.ctypes.data_as(ctypes.c_void_p), nb) == nb
+        sh, zr, ox, oy = ol.Estimator(ora, op, arith=ol.ARITH_FXP).fxp_geometry()
+        assert shift.value == sh and zr == 2.0 ** (26 - sh), (sect, rings, mn, mx)
+        assert np.array_equal(xy[:, 0], ox) and np.array_equal(xy[:, 1], oy), (sect, rings, mn, mx)
