@@ -137,3 +137,46 @@ def test_hip_path_against_the_exact_arbiter_and_the_float_reference(oracle_built
             json.dump(dict(worst=worst, cases=report), f, indent=1, default=float)
     assert not fails, fails
     assert worst["dn_well"] < 1e-4  # every well-conditioned patch (cond < 100): far inside the 1e-4 of BASELINE.json
+
+
+def test_contract_is_no_further_from_exact_arithmetic_than_float_sums_on_adversarial_clouds(oracle_built):
+    """CPU only (tools/fuzz_arbiter.py, 24 seeds = 48 frames of its adversarial clouds): walls, ramps, heavy undulation and
+    reflected noise produce degenerate INTERMEDIATE fits -- a handful of collinear seeds whose plane is vertical with
+    n_z = +-1e-6 -- and the reference orients a normal by the sign of n_z (patchworkpp.cpp:68), so the next one-sided round
+    takes one side of the plane or the other: every arithmetic parts ways with every other there.
+    What must hold: the fixed-point contract differs from the exact arbiter in no more frames than the reference's float
+    sums do (give or take the small-sample noise), and on most frames none of the three differs at all."""
+    import importlib.util
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(__file__), "..", "tools")
+    sys.path.insert(0, tools)
+    os.environ["FUZZ_NO_ODD"] = "1"
+    try:
+        spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(tools, "fuzz_parity.py"))
+        fz = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(fz)
+    finally:
+        os.environ.pop("FUZZ_NO_ODD", None)
+    lib = oracle_built.restatement()
+    frames = fxp_frames = f32_frames = 0
+    os.environ["FUZZ_NO_ODD"] = "1"
+    try:
+        for seed in range(1, 25):
+            rng = np.random.default_rng(seed)
+            p = fz.random_params(rng)
+            p.num_min_pts = max(p.num_min_pts, 5)
+            p.num_lpr = max(p.num_lpr, 5)
+            op = fz.to_oracle_params(p)
+            for _ in range(2):
+                pts = fz.random_cloud(rng, p.sensor_height)
+                ex = ol.Estimator(lib, op, arith=ol.ARITH_EXACT_F64).run(pts)
+                fx = ol.Estimator(lib, op, arith=ol.ARITH_FXP).run(pts)
+                f3 = ol.Estimator(lib, op, arith=ol.ARITH_EIGEN_F32).run(pts)
+                frames += 1
+                fxp_frames += len(np.setxor1d(fx.ground_idx, ex.ground_idx)) > 0
+                f32_frames += len(np.setxor1d(f3.ground_idx, ex.ground_idx)) > 0
+    finally:
+        os.environ.pop("FUZZ_NO_ODD", None)
+    assert fxp_frames <= f32_frames + 3, (frames, fxp_frames, f32_frames)
+    assert fxp_frames <= frames // 4 and f32_frames <= frames // 4, (frames, fxp_frames, f32_frames)
