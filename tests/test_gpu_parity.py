@@ -448,7 +448,7 @@ def test_split_bins_in_reference_order_and_one_pass_batches(kitti, oracle):
 def test_randomised_differential_cases(oracle):
     """tools/fuzz_parity.py: random parameter sets, random clouds with walls / ramps / huge and infinite heights /
     duplicates, random bin splits and fit plans, fresh batches, stateful sequences and lock-step streams -- every case
-    bit-identical to the oracle (2 800 more seeds ran clean when this was written; a failing seed reproduces with
+    bit-identical to the oracle (3 200 more seeds ran clean when this was written; a failing seed reproduces with
     `python tools/fuzz_parity.py 1 <seed>`)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
