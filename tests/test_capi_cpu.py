@@ -238,3 +238,40 @@ def test_fixed_point_geometry_matches_the_restatement(lib, oracle_built):
         sh, zr, ox, oy = ol.Estimator(ora, op, arith=ol.ARITH_FXP).fxp_geometry()
         assert shift.value == sh and zr == 2.0 ** (26 - sh), (sect, rings, mn, mx)
         assert np.array_equal(xy[:, 0], ox) and np.array_equal(xy[:, 1], oy), (sect, rings, mn, mx)
+
+
+def test_plane_distance_is_monotone_in_every_coordinate():
+    """The exact skip of a bin's high part (pwpp_fit.hip, stage_needs_hi) evaluates the reference's distance expression
+    (patchworkpp.cpp:551-554: three float products, two float adds, one double add -- no FMA contraction) at ONE corner of
+    the box [xmin, xmax] x [ymin, ymax] x [zs, inf) and concludes that every point of the box is at least as far.  That holds
+    because every correctly rounded operation is monotone in each operand: checked here in the same float32 / float64
+    arithmetic on millions of (plane, box, point) triples, including planes of wildly different scales, tiny boxes (points
+    a few ulps apart), huge coordinates and zero components."""
+    import numpy as np
+    rng = np.random.default_rng(2)
+
+    def dist(nx, ny, nz, d, x, y, z):
+        f = np.float32
+        return ((f(nx) * f(x) + f(ny) * f(y)).astype(f) + f(nz) * f(z)).astype(f).astype(np.float64) + np.float64(d)
+
+    with np.errstate(over="ignore", invalid="ignore"):
+        for scale, width in ((1.0, 10.0), (1.0, 1e-5), (100.0, 50.0), (1e-3, 1.0), (1e6, 1e3), (1.0, 0.0)):
+            n = 400000
+            nrm = rng.normal(size=(n, 3)).astype(np.float32)
+            nrm[:, 2] = np.abs(nrm[:, 2])                       # the reference flips the normal to n_z >= 0 (:68)
+            nrm[rng.random(n) < 0.1, 0] = 0.0
+            nrm[rng.random(n) < 0.1, 2] = 0.0
+            d = (rng.normal(size=n) * scale).astype(np.float32).astype(np.float64)
+            lo = (rng.normal(size=(n, 3)) * scale).astype(np.float32)
+            hi = (lo.astype(np.float64) + np.abs(rng.normal(size=(n, 3))) * width).astype(np.float32)
+            hi = np.maximum(hi, lo)
+            t = rng.random((n, 3)).astype(np.float32)
+            pt = np.clip((lo + (hi - lo) * t).astype(np.float32), lo, hi)
+            pt[:, 2] = np.maximum(pt[:, 2], lo[:, 2])          # z only bounded below (box open to +inf)
+            pt[rng.random(n) < 0.2, 2] += np.float32(abs(scale) * 3)
+            cx = np.where(nrm[:, 0] >= 0, lo[:, 0], hi[:, 0])
+            cy = np.where(nrm[:, 1] >= 0, lo[:, 1], hi[:, 1])
+            corner = dist(nrm[:, 0], nrm[:, 1], nrm[:, 2], d, cx, cy, lo[:, 2])
+            point = dist(nrm[:, 0], nrm[:, 1], nrm[:, 2], d, pt[:, 0], pt[:, 1], pt[:, 2])
+            ok = np.isfinite(corner) & np.isfinite(point)
+            assert (point[ok] >= corner[ok]).all(), (scale, width)
