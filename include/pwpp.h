@@ -160,13 +160,21 @@ int pwpp_set_num_streams(pwpp_handle *h, int streams); /* (re)creates `streams` 
 /* sizes of getGround()/getNonground()/getCenters(), reference patchworkpp.h:157-163 */
 int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32_t *n_nonground, int32_t *n_patches);
 /* getGroundIndices()/getNongroundIndices(), reference patchworkpp.h:159-160, patchworkpp.cpp:18-26.
- * The index SETS are those of the reference's control flow evaluated with the plane-fit sums of
- * patchworkpp.cpp:56-60 in exact arithmetic: bit-identical to the CPU restatement of that
- * contract (oracle/), and on every cloud of the test suite identical to the "exact-f64" build of the
- * reference.  A float build of the reference (Eigen) adds those sums up in float; its own rounding then
- * moves a point that lies within ~1e-4 m of a threshold now and then (measured: 0-2 of 480 000 indices on
- * dense synthetic clouds, none on the KITTI samples; plane normals agree to 1e-4 except for ill-conditioned
- * patches, where a float build departs from exact arithmetic by more than this library does).
+ * The index SETS are those of the reference's control flow with the plane-fit sums of patchworkpp.cpp:56-60
+ * evaluated (contract v3)
+ *   - for a fit set of 1, 2 or 3 points: in the reference's own float arithmetic, which is determinate there (Eigen
+ *     reduces fewer elements than one SIMD packet sequentially; two terms commute) -- points in the order of the
+ *     reference's z-sorted bin, equal heights in cloud order.  All three builds of the reference under oracle/_ref agree
+ *     on such sets and this library agrees with them: identical ground sets under the ROS launch file's parameters,
+ *     num_min_pts 0-3, num_lpr 1-3 on the KITTI samples (tests/test_tiny_fits.py, CPU and GPU);
+ *   - for 4 points and more: in exact arithmetic (integer moments on a 2^-21 m grid around per-bin / per-patch origins,
+ *     z clamped to z0 +- 2^(26-s) m = 32 m with the default CZM -- see pwpp_get_fxp_geometry), because Eigen's float
+ *     summation order there depends on the vector width it was built for.  Bit-identical to the CPU restatement of the
+ *     contract (oracle/); identical to the "exact-f64" build of the reference on every scan of the test suite.  A float
+ *     build of the reference adds those sums up in float; its own rounding then moves a point that lies within ~1e-4 m
+ *     of a threshold now and then (measured: 0-2 of 480 000 indices on dense synthetic clouds, none on the KITTI
+ *     samples; plane normals agree to 1e-4 except for ill-conditioned patches, where a float build departs from exact
+ *     arithmetic by more than this library does).
  * (NaN heights are undefined in the reference itself: it sorts bins with `a.z < b.z`.)
  * The order inside a list is not the reference's unless pwpp_set_output_order asks for it. */
 int pwpp_get_ground_indices(pwpp_handle *h, int frame, int32_t *out);

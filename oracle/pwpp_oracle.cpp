@@ -19,8 +19,10 @@
 // Arithmetic flavours for the plane fit (the only place where the reference defers to
 // Eigen); everything else follows the reference's own float/double expressions:
 //   PWO_ARITH_EIGEN_F32  float accumulators in storage order (plain reading of Eigen)
-//   PWO_ARITH_FXP        fixed-point, order-independent contract;
-//                        this is the flavour the HIP kernels must match bit for bit.
+//   PWO_ARITH_FXP        the product's contract v3: fit sets of 1-3 points in the
+//                        reference's own float arithmetic (determinate there), larger ones in
+//                        order-independent fixed point; this is the flavour the HIP kernels
+//                        must match bit for bit.
 //   PWO_ARITH_EXACT_F64  reference-neutral arbiter: what :56-60 give in (near-)exact
 //                        arithmetic -- double accumulation of the unquantised floats, one
 //                        rounding to float per output.  Neither the product nor the
@@ -576,6 +578,30 @@ private:
                     cov[a * 3 + b] = sum4([&](int i) {
                                          return (coord(g[(size_t)i], a) - mean[a]) * (coord(g[(size_t)i], b) - mean[b]);
                                      }) / den;
+        } else if (n <= 3) {
+            // contract v3: a fit set of one, two or three points.  The reference's float sums are DETERMINATE there --
+            // Eigen reduces fewer elements than one packet sequentially, in storage order (redux of a column, and the
+            // coefficient-based lazy product it takes for 3 x n times n x 3 with n this small), and two terms commute --
+            // so the contract follows the reference's own float arithmetic (:56-60) instead of the grid: mean = float
+            // sum / n, centred rows, products summed in float, / (n - 1).  Order: the reference's z-sorted bin (:199);
+            // equal heights (std::sort leaves them to libstdc++) in cloud order.
+            Pt q[3];
+            for (int i = 0; i < n; ++i) q[i] = g[(size_t)i];
+            for (int i = 1; i < n; ++i)
+                for (int j = i; j > 0 && (q[j].z < q[j - 1].z || (!(q[j - 1].z < q[j].z) && q[j].idx < q[j - 1].idx)); --j)
+                    std::swap(q[j], q[j - 1]);
+            for (int j = 0; j < 3; ++j) {
+                float acc = 0.0f;
+                for (int i = 0; i < n; ++i) acc += coord(q[i], j);
+                mean[j] = acc / (float)n;
+            }
+            const float den = (float)(double)(n - 1);
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    float acc = 0.0f;
+                    for (int i = 0; i < n; ++i) acc += (coord(q[i], a) - mean[a]) * (coord(q[i], b) - mean[b]);
+                    cov[a * 3 + b] = acc / den;
+                }
         } else {
             // the fixed-point contract (top of this file): exact integer moments around the bin's origin
             const double org[3] = {(double)fxp.ox[(size_t)cur_bin], (double)fxp.oy[(size_t)cur_bin], z0};

@@ -354,38 +354,88 @@ __device__ __forceinline__ float moment_output(int o, long long n, const long lo
     return (float)((i128_to_double(num) / den) * (inv * inv));
 }
 
-__device__ __forceinline__ void plane_from_totals(long long n, const long long s1[3], const __int128 s2[6], int shift,
-                                                  float ox, float oy, float z0, int debug, PlaneFit &out) {
+// the moments -> (mean, covariance) step alone: mean[3] and the six distinct covariance entries (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+__device__ __forceinline__ void mean_cov_from_totals(long long n, const long long s1[3], const __int128 s2[6], int shift,
+                                                     float ox, float oy, float z0, float mean[3], float c6[6]) {
     const double org[3] = {(double)ox, (double)oy, (double)z0};
-    float mean[3], cov[9];
 #pragma unroll
     for (int a = 0; a < 3; ++a) mean[a] = moment_output(a, n, s1, s2, shift, org);
-    const int map[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
-    float c6[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) c6[k] = moment_output(3 + k, n, s1, s2, shift, org);
+}
+__device__ __forceinline__ void plane_from_mean_c6(const float mean[3], const float c6[6], int debug, PlaneFit &out) {
+    const int map[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+    float cov[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) cov[k] = c6[map[k]];
     plane_from_cov(mean, cov, debug, out);
+}
+__device__ __forceinline__ void plane_from_totals(long long n, const long long s1[3], const __int128 s2[6], int shift,
+                                                  float ox, float oy, float z0, int debug, PlaneFit &out) {
+    float mean[3], c6[6];
+    mean_cov_from_totals(n, s1, s2, shift, ox, oy, z0, mean, c6);
+    plane_from_mean_c6(mean, c6, debug, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// Contract v3: a fit set of ONE, TWO or THREE points.  There the reference's float sums (ref :56-60) are determinate --
+// Eigen reduces fewer elements than one SIMD packet sequentially in storage order (the column redux of colwise().mean()
+// and the coefficient-based product it takes for 3 x n times n x 3 with n this small), and two terms commute -- so these
+// sets follow the reference's own float arithmetic instead of the fixed-point grid: mean = float sum / n, centred rows,
+// products summed in float, / (n - 1).  Order: the reference's z-sorted bin (ref :199), equal heights in cloud order
+// (the kernels hand the points over sorted).  The covariance of a float sum is symmetric term by term (a * b == b * a),
+// so six entries suffice.  Restated for the checker in oracle/pwpp_oracle.cpp (estimate_plane, n <= 3).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mean_cov_tiny(int n, const float px[3], const float py[3], const float pz[3], float mean[3], float c6[6]) {
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i < n) {
+            ax += px[i];
+            ay += py[i];
+            az += pz[i];
+        }
+    }
+    const float fn = (float)n;
+    mean[0] = ax / fn;
+    mean[1] = ay / fn;
+    mean[2] = az / fn;
+    float acc[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i < n) {
+            const float cx = px[i] - mean[0], cy = py[i] - mean[1], cz = pz[i] - mean[2];
+            acc[0] += cx * cx;
+            acc[1] += cx * cy;
+            acc[2] += cx * cz;
+            acc[3] += cy * cy;
+            acc[4] += cy * cz;
+            acc[5] += cz * cz;
+        }
+    }
+    const float den = (float)(n - 1);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c6[k] = acc[k] / den;
 }
 
 // The same when every lane of the wave holds the SAME totals (the four-waves-per-patch kernel): the nine outputs --
 // nine IEEE double divisions and six 128-bit products, a third of the solve's instructions -- are computed by nine
 // lanes side by side and handed round with v_readlane; only the Jacobi iteration stays serial.
-__device__ __forceinline__ void plane_from_totals_uniform(long long n, const long long s1[3], const __int128 s2[6], int shift,
-                                                          float ox, float oy, float z0, int debug, PlaneFit &out) {
+__device__ __forceinline__ void mean_cov_from_totals_uniform(long long n, const long long s1[3], const __int128 s2[6], int shift,
+                                                             float ox, float oy, float z0, float mean[3], float c6[6]) {
     const double org[3] = {(double)ox, (double)oy, (double)z0};
     const int o = lane_id() & 15;
     const float mine = moment_output(o < 9 ? o : 0, n, s1, s2, shift, org);
-    float mean[3], c6[6], cov[9];
 #pragma unroll
     for (int a = 0; a < 3; ++a) mean[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), a));
 #pragma unroll
     for (int k = 0; k < 6; ++k) c6[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), 3 + k));
-    const int map[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
-#pragma unroll
-    for (int k = 0; k < 9; ++k) cov[k] = c6[map[k]];
-    plane_from_cov(mean, cov, debug, out);
+}
+__device__ __forceinline__ void plane_from_totals_uniform(long long n, const long long s1[3], const __int128 s2[6], int shift,
+                                                          float ox, float oy, float z0, int debug, PlaneFit &out) {
+    float mean[3], c6[6];
+    mean_cov_from_totals_uniform(n, s1, s2, shift, ox, oy, z0, mean, c6);
+    plane_from_mean_c6(mean, c6, debug, out);
 }
 
 // The height that separates the two parts of a frame's bins (pwpp_dev.h): k_czm_bin / k_czm_bin_scatter compare every z

@@ -211,6 +211,8 @@ struct Row {
     }
 };
 
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~Row<64>::min_u32(~v); }
+
 // compare-exchange of two keys, ascending
 __device__ __forceinline__ void ce(unsigned &a, unsigned &b) {
     const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
@@ -478,6 +480,63 @@ __device__ __forceinline__ unsigned lane_strip(const ChunkPts &cp, unsigned act,
     return hit;
 }
 
+// Contract v3 (pwpp_common.hpp, mean_cov_tiny): a fit set of one, two or three points follows the reference's own float
+// arithmetic, which needs the POINTS, not their moments.  The pass that found so few members is repeated here for the
+// row's patch with the same test on the same data (both parts: skipping the high part is only ever an optimisation),
+// every member is handed to all lanes of the row, which keep them sorted by (z, cloud index) -- the order of the
+// reference's z-sorted bin (ref :199; equal heights, which std::sort leaves to libstdc++, in cloud order) -- and
+// evaluate mean and covariance side by side.  Rare (num_min_pts < 4, or a patch whose seeds / ground set dwindle to
+// a few points), so nothing here is tuned; `on` is row-uniform, the loops are wave-uniform.
+template <int G>
+__device__ void tiny_fit_row(const PatchRef &pts, bool on, int kind, double thr_seed, double th_dist, float nx, float ny, float nz, double d,
+                             float mean[3], float c6[6]) {
+    const unsigned j = (unsigned)lane_id() & (G - 1);
+    const bool iter = kind == ST_ITER;
+    const float tx = iter ? nx : 0.0f, ty = iter ? ny : 0.0f, tz = iter ? nz : 1.0f;  // (the one test of lane_stage_accum)
+    const double td = iter ? d : 0.0;
+    const double thr = iter ? th_dist : thr_seed;
+    unsigned long long key[3] = {~0ull, ~0ull, ~0ull};
+    float qx[3] = {0.0f, 0.0f, 0.0f}, qy[3] = {0.0f, 0.0f, 0.0f}, qz[3] = {0.0f, 0.0f, 0.0f};
+    int cnt = 0;
+    const unsigned n = on ? pts.n_lo + pts.n_hi : 0u;
+    const unsigned nmax = wave_max_u32(n);
+    for (unsigned i0 = 0; i0 < nmax; i0 += G) {  // one point per lane and step: few registers, so that the kernels around it keep theirs
+        const unsigned i = i0 + j;
+        const bool in = i < n;
+        const unsigned sl = in ? patch_slot(pts, i) : pts.off_lo;
+        const float pz = pts.z[sl];
+        const float2 pxy = pts.xy[sl];
+        const int pidx = pts.idx[sl];
+        const bool inc = in && !z_stripped(pz) && (plane_dist(tx, ty, tz, td, pxy.x, pxy.y, pz) < thr);
+        unsigned long long mm = Row<G>::ballot(inc);
+        while (__any(mm != 0ull)) {  // (wave-uniform: the shuffles below need every lane)
+            const int src = Row<G>::first_lane() + (mm ? __ffsll((long long)mm) - 1 : (int)j);
+            float ex = __shfl(pxy.x, src, 64), ey = __shfl(pxy.y, src, 64), ez = __shfl(pz, src, 64);
+            const int ei = __shfl(pidx, src, 64);
+            if (mm) {
+                unsigned long long nk = ((unsigned long long)z_key(ez == 0.0f ? 0.0f : ez) << 32) | (unsigned)ei;  // (-0 and +0 compare equal: cloud order)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {  // sorted insertion; a fourth member (there is none) would fall off the end
+                    const bool sw = nk < key[q];
+                    const unsigned long long tk = key[q];
+                    const float t0 = qx[q], t1 = qy[q], t2 = qz[q];
+                    key[q] = sw ? nk : tk;
+                    qx[q] = sw ? ex : t0;
+                    qy[q] = sw ? ey : t1;
+                    qz[q] = sw ? ez : t2;
+                    nk = sw ? tk : nk;
+                    ex = sw ? t0 : ex;
+                    ey = sw ? t1 : ey;
+                    ez = sw ? t2 : ez;
+                }
+                ++cnt;
+                mm &= mm - 1ull;
+            }
+        }
+    }
+    mean_cov_tiny(cnt < 3 ? cnt : 3, qx, qy, qz, mean, c6);
+}
+
 // the sixteen values Row<64>::reduce16_scatter adds up for a patch: n, S1[3], lower and upper halves of S2[6]
 __device__ __forceinline__ void moments_to_16(const Moments &mm, long long (&v)[16]) {
     v[0] = mm.n;
@@ -492,7 +551,6 @@ __device__ __forceinline__ void moments_to_16(const Moments &mm, long long (&v)[
 }
 __device__ __forceinline__ __int128 join_halves(long long lo, long long hi) { return ((__int128)hi << 32) + (__int128)lo; }
 
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~Row<64>::min_u32(~v); }
 
 // LPR (ref :84-103) of streamed rows, normally in ONE pass over the points: every lane keeps its
 // four smallest eligible keys and the smallest key it had to drop.  The keff smallest of the
@@ -846,8 +904,21 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
                 for (int k = 0; k < 6; ++k)
                     s2[k] = join_halves(Row<G>::sum_i64(m.s2[k] & 0xffffffffLL), Row<G>::sum_i64(m.s2[k] >> 32));
             }
-            if (kind != ST_DONE && cnt > 0) {  // empty: ref :49
-                plane_from_totals(cnt, s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug, pl);
+            const bool fit = kind != ST_DONE && cnt > 0;  // empty: ref :49
+            const bool tiny = fit && cnt <= 3;            // contract v3: the reference's float arithmetic (row-uniform)
+            float mt[3], ct[6];
+            if (__any(tiny)) tiny_fit_row<G>(pts, tiny, kind, thr_seed, P.th_dist, pl.nx, pl.ny, pl.nz, pl.d, mt, ct);
+            if (fit) {
+                float mean[3], c6[6];
+                if (tiny) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) mean[k] = mt[k];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) c6[k] = ct[k];
+                } else {
+                    mean_cov_from_totals(cnt, s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, mean, c6);
+                }
+                plane_from_mean_c6(mean, c6, Bt.debug, pl);
                 fitted = true;
             }
         }
@@ -1149,26 +1220,70 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
 
         // ---- D. solve phase: lane p fits patch p (ref :47-75)
         long long cnt = 0;
+        bool tiny = false;  // contract v3: a fit set of 1-3 points follows the reference's float arithmetic (tiny_fit_row)
         if (kind != ST_DONE) {
-            long long tot[MW];
-#pragma unroll
-            for (int k = 0; k < MW; ++k) tot[k] = from_stash ? sh.mom2[DUAL ? ln : 0][k] : sh.mom[ln][k];
-            if (dual_now) {  // mom = below the smaller threshold (A), mom2 = the band (B)
-#pragma unroll
-                for (int k = 0; k < MW; ++k) {
-                    const long long a = tot[k], ab = a + sh.mom2[DUAL ? ln : 0][k];
-                    tot[k] = v_is_hi ? ab : a;            // this round: the R-VPF seeds (th_seeds_v)
-                    sh.mom2[DUAL ? ln : 0][k] = v_is_hi ? a : ab;    // stash: the R-GPF seeds (th_seeds)
+            const long long a0 = sh.mom[ln][0], b0 = DUAL ? sh.mom2[DUAL ? ln : 0][0] : 0;
+            cnt = from_stash ? b0 : (dual_now ? (v_is_hi ? a0 + b0 : a0) : a0);
+            tiny = cnt >= 1 && cnt <= 3;
+        }
+        const unsigned long long t_mask = __ballot(tiny);
+        if (t_mask) {  // the rows gather the points of those patches again (the stage of phase B is still published)
+            for (int sb = 0; sb < NSB; ++sb) {
+                if (((t_mask >> (R * sb)) & ((1ull << R) - 1ull)) == 0ull) continue;
+                const int q = R * sb + row;
+                const bool trow = (t_mask >> q) & 1ull;
+                const W64Patch<DUAL> pp = sh.p[q];
+                double thr = pp.thr_seed;
+                if constexpr (DUAL) {
+                    if ((pp.flags & 4) && v_is_hi) thr = pp.thr_band[0];  // dual pass: this round's set is the R-VPF one
                 }
-                stash_valid = true;
-            }
-            cnt = tot[0];
-            if (cnt > 0) {  // empty set: the previous plane stays (ref :49)
-                const long long s1[3] = {tot[1], tot[2], tot[3]};
-                __int128 s2[6];
+                const PatchRef pts = patch_ref(Bt, fd, pp.off_lo, pp.n_lo, pp.off_hi, pp.n_hi);
+                float mt[3], ct[6];
+                tiny_fit_row<G>(pts, trow, pp.kind, thr, P.th_dist, pp.nx, pp.ny, pp.nz, pp.d, mt, ct);
+                if (trow && j == 0) {  // mean and covariance take the place of the patch's moments 1..5 (the count stays)
+                    float *dst = reinterpret_cast<float *>(&sh.mom[q][1]);
 #pragma unroll
-                for (int k = 0; k < 6; ++k) s2[k] = G == 64 ? join_halves(tot[4 + k], tot[MW == 16 ? 10 + k : 4 + k]) : (__int128)tot[4 + k];
-                plane_from_totals(cnt, s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug, pl);
+                    for (int k = 0; k < 3; ++k) dst[k] = mt[k];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) dst[3 + k] = ct[k];
+                }
+            }
+            wave_lds_sync();
+        }
+        if (kind != ST_DONE) {
+            float mean[3], c6[6];
+            if (tiny) {
+                const float *src = reinterpret_cast<const float *>(&sh.mom[ln][1]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) mean[k] = src[k];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) c6[k] = src[3 + k];
+                if (dual_now) stash_valid = false;  // (its moments are gone: the R-GPF seed stage streams the patch itself)
+            } else {
+                long long tot[MW];
+#pragma unroll
+                for (int k = 0; k < MW; ++k) tot[k] = from_stash ? sh.mom2[DUAL ? ln : 0][k] : sh.mom[ln][k];
+                if (dual_now) {  // mom = below the smaller threshold (A), mom2 = the band (B)
+                    long long stash_cnt = 0;
+#pragma unroll
+                    for (int k = 0; k < MW; ++k) {
+                        const long long a = tot[k], ab = a + sh.mom2[DUAL ? ln : 0][k];
+                        tot[k] = v_is_hi ? ab : a;            // this round: the R-VPF seeds (th_seeds_v)
+                        sh.mom2[DUAL ? ln : 0][k] = v_is_hi ? a : ab;    // stash: the R-GPF seeds (th_seeds)
+                        if (k == 0) stash_cnt = v_is_hi ? a : ab;
+                    }
+                    stash_valid = !(stash_cnt >= 1 && stash_cnt <= 3);  // (1-3 seeds: that stage gathers the points, it needs its own pass)
+                }
+                if (cnt > 0) {
+                    const long long s1[3] = {tot[1], tot[2], tot[3]};
+                    __int128 s2[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) s2[k] = G == 64 ? join_halves(tot[4 + k], tot[MW == 16 ? 10 + k : 4 + k]) : (__int128)tot[4 + k];
+                    mean_cov_from_totals(cnt, s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, mean, c6);
+                }
+            }
+            if (cnt > 0) {  // empty set: the previous plane stays (ref :49)
+                plane_from_mean_c6(mean, c6, Bt.debug, pl);
                 fitted = true;
             }
             if (needs_previous_plane(P, kind, zone, fitted)) {
@@ -1296,7 +1411,10 @@ struct MomentsWide {
 // Block-wide sum of the moments and, if the set is non-empty, the plane of ref :47-75.
 // An empty set leaves the previous plane in force, as ref :49 does.  The 128-bit second moments are
 // added up as three limbs (32 + 32 + 64 bits) and recombined: exact at any size.
-__device__ void reduce_and_fit(FitShared &sh, const MomentsWide &m, int shift, float ox, float oy, float z0, int debug = 0) {
+// `pts`, `iter`, `thr`: the set's membership test once more (R-GPF round: distance to the plane still in `sh` below th_dist = thr;
+// seed stages: z < thr) for the sets of 1-3 points, which follow the reference's float arithmetic (tiny_fit_row).
+__device__ void reduce_and_fit(FitShared &sh, const MomentsWide &m, int shift, float ox, float oy, float z0, const PatchRef &pts, bool iter,
+                               double thr, int debug = 0) {
     long long v[22];
     v[0] = m.n;
     v[1] = m.s1[0];
@@ -1332,7 +1450,12 @@ __device__ void reduce_and_fit(FitShared &sh, const MomentsWide &m, int shift, f
             for (int k = 0; k < 6; ++k) s2[k] = ((__int128)t[16 + k] << 64) + ((__int128)t[10 + k] << 32) + (__int128)t[4 + k];
             const long long s1[3] = {t[1], t[2], t[3]};
             PlaneFit pf;
-            plane_from_totals(n, s1, s2, shift, ox, oy, z0, debug, pf);
+            float mean[3], c6[6];
+            if (n <= 3)
+                tiny_fit_row<64>(pts, true, iter ? ST_ITER : ST_SEED, thr, thr, sh.normal[0], sh.normal[1], sh.normal[2], sh.d, mean, c6);
+            else
+                mean_cov_from_totals(n, s1, s2, shift, ox, oy, z0, mean, c6);
+            plane_from_mean_c6(mean, c6, debug, pf);
             if (ln == 0) {
                 sh.normal[0] = pf.nx;
                 sh.normal[1] = pf.ny;
@@ -1755,8 +1878,15 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         probe(4);
         PlaneFit fitted_pl = pl;
         if (tot[0] > 0) {  // empty: ref :49
-            const long long s1[3] = {tot[1], tot[2], tot[3]};
-            plane_from_totals_uniform(tot[0], s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug, fitted_pl);  // (totals are the same in every lane of this wave)
+            float mean[3], c6[6];
+            if (tot[0] <= 3) {  // contract v3 (wave-uniform): this wave gathers the 1-3 points of its set itself
+                const double thr_t = dual_now ? ((spec == v_is_hi) ? thr_seed : thr_band) : thr_seed;
+                tiny_fit_row<64>(pts, true, kind, thr_t, P.th_dist, pl.nx, pl.ny, pl.nz, pl.d, mean, c6);
+            } else {
+                const long long s1[3] = {tot[1], tot[2], tot[3]};
+                mean_cov_from_totals_uniform(tot[0], s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, mean, c6);  // (totals are the same in every lane of this wave)
+            }
+            plane_from_mean_c6(mean, c6, Bt.debug, fitted_pl);
         }
         if (dual_now) {
             if (ln == 0 && (wv == 0 || wv == kWaves / 2)) sh.plane[wv ? 1 : 0] = fitted_pl;
@@ -1892,7 +2022,7 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
                     m.add(xy.x, xy.y, z, scale, org);
                 }
             }
-            reduce_and_fit(sh, m, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug);
+            reduce_and_fit(sh, m, P.fxp_shift, pc.ox, pc.oy, z0, pts, false, thr, Bt.debug);
             fitted = fitted || sh.last_n > 0;
             if (!fitted && zone == 0) {  // the verticality test below would consult the plane fitted before this patch
                 if (threadIdx.x == 0) mark_needs_previous_plane(Bt, f, rec, n);
@@ -1933,7 +2063,7 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
                 m.add(xy.x, xy.y, z, scale, org);
             }
         }
-        reduce_and_fit(sh, m, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug);
+        reduce_and_fit(sh, m, P.fxp_shift, pc.ox, pc.oy, z0, pts, false, thr, Bt.debug);
         fitted = fitted || sh.last_n > 0;
     }
     if (!fitted) {  // the first R-GPF round would measure distances to the plane fitted before this patch
@@ -1983,7 +2113,7 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
                     plist[n - 1u - (bn + (unsigned)__popcll(mn & lt))] = nonground_entry(idx, z);
             }
         }
-        reduce_and_fit(sh, m, P.fxp_shift, pc.ox, pc.oy, z0, Bt.debug);  // ref :537-542
+        reduce_and_fit(sh, m, P.fxp_shift, pc.ox, pc.oy, z0, pts, true, P.th_dist, Bt.debug);  // ref :537-542
     }
 
     if (threadIdx.x == 0) {

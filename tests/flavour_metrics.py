@@ -23,13 +23,15 @@ def normal_distance(a, b):
     return np.where(amb, np.minimum(d, flip), d)
 
 
-def compare(ground_a, recs_a, ground_b, recs_b, min_points=0):
+def compare(ground_a, recs_a, ground_b, recs_b, min_points=0, min_ground=0):
     """a against b (b = the arbiter: its singular values define the conditioning).  recs_*: structured arrays
     with mean / normal / sv per processed patch, same patches in the same order.
     Returns dict(symdiff, iou, dc, dn, dn_well, cond_of_worst, excess) where excess = max over the patches of
     dn / (3e-5 + 4e-10 * cond): <= 1 means every patch is within the bound of DESIGN.md section 4.
     min_points: patches with fewer points are left out of the plane statistics (two or three points do not
-    define a plane: their normal is whatever the last bit of the covariance says, in every arithmetic)."""
+    define a plane: their normal is whatever the last bit of the covariance says, in every arithmetic).
+    min_ground: patches whose FINAL fit set (a's ground points) is smaller are left out of the plane statistics -- the
+    product evaluates sets of 1-3 points in the reference's float arithmetic (contract v3), which is not the arbiter's."""
     ga, gb = np.asarray(ground_a), np.asarray(ground_b)
     sym = len(np.setxor1d(ga, gb))
     union = len(np.union1d(ga, gb))
@@ -38,7 +40,7 @@ def compare(ground_a, recs_a, ground_b, recs_b, min_points=0):
         v = np.nan if out["patches_differ"] else 0.0  # (no patch at all: nothing to compare)
         out.update(dc=v, dn=v, dn_well=v, cond_of_worst=v, excess=v)
         return out
-    ok = np.isfinite(recs_b["normal"]).all(axis=1) & np.isfinite(recs_a["normal"]).all(axis=1) & (recs_b["n_points"] >= min_points)
+    ok = np.isfinite(recs_b["normal"]).all(axis=1) & np.isfinite(recs_a["normal"]).all(axis=1) & (recs_b["n_points"] >= min_points) & (recs_a["n_ground"] >= min_ground)
     cond = np.nan_to_num(patch_condition(recs_b["sv"]), nan=np.inf, posinf=1e300)
     dn = np.where(ok, normal_distance(recs_a["normal"], recs_b["normal"]), 0.0)
     dc = np.where(ok, np.abs(recs_a["mean"].astype(np.float64) - recs_b["mean"].astype(np.float64)).max(axis=1), 0.0)

@@ -9,7 +9,8 @@ CPU tests: the oracle's flavours among themselves on a few clouds.  GPU tests (-
 dense seeds {3, 77, 1000-1003} x {36-sector, default CZM}, synthetic + edge-case seeds 1-8 and every entry
 of PARAM_VARIANTS -- against the arbiter (must hold: identical index sets, centres < 2e-6 m, normals within
 3e-5 + 4e-10 * cond, i.e. < 1e-4 for every patch with cond < 1.7e5) and against the float reference
-(reported; IoU >= 0.9999: its own float sums move 0-2 indices per frame)."""
+(reported; IoU >= 0.9999: its own float sums move 0-2 indices per frame).  Parameter sets that produce fit sets of 1-3
+points are held to the FLOAT reference instead (contract v3: identical index sets; tests/test_tiny_fits.py)."""
 import json
 import os
 
@@ -105,19 +106,26 @@ def test_hip_path_against_the_exact_arbiter_and_the_float_reference(oracle_built
         g, rec = h.ground_indices(0), h.patch_records(0)
         ex = ol.Estimator(lib, op, arith=ol.ARITH_EXACT_F64).run(pts)
         f32 = ol.Estimator(lib, op, arith=ol.ARITH_EIGEN_F32).run(pts)
-        # Parameter sets that make fits of one or two points (bins of < 3 points let through; seeds picked around a
-        # single lowest point, or within a few centimetres of the lowest ones) have planes that no arithmetic
-        # defines: the last bit of a rank-deficient covariance decides the normal, and with it the fate of the
-        # patch -- the float reference departs from the arbiter there as much as this library does (the report
-        # has the numbers).  Only the overall agreement is required of them.
-        degenerate = variant.get("num_min_pts", 10) < 3 or variant.get("num_lpr", 20) < 3 or variant.get("th_seeds", 0.125) < 0.1
-        m = compare(g, rec, ex.ground_idx, ex.records)
+        # Parameter sets that make fits of one, two or three points (bins of < 4 points let through; seeds picked around a
+        # single lowest point, or within a few centimetres of the lowest ones).  Contract v3: such sets follow the
+        # reference's own float arithmetic, which is determinate there -- so these cases are held to the FLOAT build
+        # (identical index sets), not to the arbiter: a rank-deficient covariance is where exact and float arithmetic
+        # legitimately part ways (kitti0 | num_lpr=1: the float build itself is 116 indices from the arbiter).
+        tiny_prone = variant.get("num_min_pts", 10) < 4 or variant.get("num_lpr", 20) < 4 or variant.get("th_seeds", 0.125) < 0.1
+        m = compare(g, rec, ex.ground_idx, ex.records, min_ground=4)  # (planes of 1-3 points: float arithmetic, compared with f32 below)
         mf = compare(g, rec, f32.ground_idx, f32.records)
         mfe = compare(f32.ground_idx, f32.records, ex.ground_idx, ex.records)
-        report.append(dict(case=name, degenerate=degenerate, hip_vs_exact=m, hip_vs_f32=mf, f32_vs_exact=mfe))
-        if degenerate:
-            if not (m["iou"] >= 0.995 and mf["iou"] >= 0.995):
-                fails.append((name, "iou", m, mf))
+        tiny_final = (rec["n_ground"] >= 1) & (rec["n_ground"] <= 3)
+        if tiny_final.any() and len(rec) == len(f32.records) and np.array_equal(np.sort(g), np.sort(f32.ground_idx)):
+            for fld in ("mean", "normal", "sv"):  # same ground set, final fit of 1-3 points: the float build's plane, bit for bit
+                if not np.array_equal(rec[fld][tiny_final], f32.records[fld][tiny_final], equal_nan=True):
+                    fails.append((name, "tiny final planes vs f32", fld))
+        report.append(dict(case=name, tiny_prone=tiny_prone, hip_vs_exact=m, hip_vs_f32=mf, f32_vs_exact=mfe))
+        if tiny_prone:
+            if mf["symdiff"] != 0 or mf["patches_differ"]:
+                fails.append((name, "hip vs f32 (tiny fit sets)", mf))
+            if m["symdiff"] > mfe["symdiff"]:  # never further from the arbiter than the float build is
+                fails.append((name, "hip vs exact (tiny fit sets)", m, mfe))
             continue
         # the bar: identical index sets, centres < 2e-6 m, every normal within 3e-5 + 4e-10 * cond of the arbiter's
         if m["symdiff"] != 0 or m["patches_differ"] or not (m["dc"] < CENTRE_TOL and m["excess"] <= 1.0):

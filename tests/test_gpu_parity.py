@@ -65,6 +65,18 @@ def assert_frame_equal(h, frame, ref, n_points, state_index=None, check_state=Tr
             assert np.array_equal(h.history(idx, 1, ring), ref.hist_flat[ring])
 
 
+def reference_consensus(op, pts):
+    """The ground set the three builds of the reference (oracle/_ref: float sums, exact-f64 sums, 4-lane float sums) agree
+    on for one fresh frame -- None where they differ among themselves or did not travel."""
+    sets = []
+    for a in (ol.ARITH_EIGEN_F32, ol.ARITH_EXACT_F64, ol.ARITH_F32_PACKET4):
+        lib = ol.reference(a)
+        if lib is None:
+            return None
+        sets.append(np.sort(ol.Estimator(lib, op, arith=a).run(pts).ground_idx))
+    return sets[0] if all(np.array_equal(sets[0], x) for x in sets[1:]) else None
+
+
 def test_kitti_fresh_bitwise_vs_fxp_oracle(kitti, oracle):
     h = pwpp_hip.Handle()
     h.estimate_ground_batch(kitti, mode=pwpp_hip.MODE_FRESH)
@@ -202,9 +214,16 @@ def test_parameter_variants(kitti, oracle, variant):
     h = pwpp_hip.Handle(p)
     est = ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP)
     syn = pwpp_synth.add_edge_cases(pwpp_synth.make_cloud(5, beams=48, azimuth_steps=1500), 5)
-    for pts in (kitti[0], syn, kitti[4]):
+    tiny_prone = variant.get("num_min_pts", 10) < 4 or variant.get("num_lpr", 20) < 4
+    for k, pts in enumerate((kitti[0], syn, kitti[4])):
         h.estimate_ground(pts)
         assert_frame_equal(h, 0, est.run(pts), pts.shape[0], state_index=0)
+        if tiny_prone and k == 0:
+            # fit sets of 1-3 points follow the reference's own float arithmetic (contract v3): IoU == 1.0 against the REFERENCE
+            # BUILD wherever its three flavours agree (fresh object: the first frame of the sequence)
+            want = reference_consensus(to_oracle_params(p), pts)
+            if want is not None:
+                assert np.array_equal(np.sort(h.ground_indices(0)), want), "ground set differs from the reference build"
     # the same frames as one batch (one-pass binning), under the plan the launcher picks for this
     # little work (one wave per patch) and under the plans of bigger batches (k_fit_w64 kernels)
     frames = [kitti[1], syn, kitti[3], kitti[0], kitti[5], syn]
@@ -1043,11 +1062,21 @@ def test_ros_wrapper_parameters_and_pointcloud2_input(kitti, oracle):
     seq = [kitti[2], syn, kitti[3]]
     est = ol.Estimator(oracle, op, arith=ol.ARITH_FXP)
     refs = [est.run(np.ascontiguousarray(c[:, :3])) for c in seq]
-    # (i) N x 3 matrices, as PointCloud2ToEigenMat produces them
+    # (i) N x 3 matrices, as PointCloud2ToEigenMat produces them -- and against the REFERENCE BUILD itself (one object of each of
+    # its flavours over the sequence): identical ground sets in every frame on which the reference's float and exact-f64
+    # builds agree (contract v3: the bins of 0-3 points num_min_pts = 0 lets through follow the reference's float sums)
     h = pwpp_hip.Handle(p)
+    rlib, xlib = ol.reference(ol.ARITH_EIGEN_F32), ol.reference(ol.ARITH_EXACT_F64)
+    r_est = ol.Estimator(rlib, op, arith=ol.ARITH_EIGEN_F32) if rlib else None
+    x_est = ol.Estimator(xlib, op, arith=ol.ARITH_EXACT_F64) if xlib else None
     for c, ref in zip(seq, refs):
-        h.estimate_ground(np.ascontiguousarray(c[:, :3]))
+        c3 = np.ascontiguousarray(c[:, :3])
+        h.estimate_ground(c3)
         assert_frame_equal(h, 0, ref, c.shape[0], state_index=0)
+        if r_est and x_est:
+            a, b = r_est.run(c3), x_est.run(c3)
+            if len(np.setxor1d(a.ground_idx, b.ground_idx)) == 0:
+                assert np.array_equal(np.sort(h.ground_indices(0)), np.sort(a.ground_idx)), "ground set differs from the reference build"
     # (ii) the message's data blob, fields in place
     for step, off in ((32, (0, 4, 8, -1)), (32, (4, 12, 20, -1)), (72, (60, 8, 32, -1)), (16, (0, 4, 8, 12))):
         h2 = pwpp_hip.Handle(p)
