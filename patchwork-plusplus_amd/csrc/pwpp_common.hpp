@@ -282,9 +282,13 @@ struct Moments {
     __device__ __forceinline__ void add_uncounted(float x, float y, float z, double scale, const FxpOrg &o) {
         const int qx = fxp_q(x, scale, o.cx), qy = fxp_q(y, scale, o.cy);
         const int qz = fxp_q(__builtin_amdgcn_fmed3f(z, o.zlo, o.zhi), scale, o.cz);  // (a NaN z never gets here: every test on it fails)
-        s1[0] += qx;
-        s1[1] += qy;
-        s1[2] += qz;
+        // first moments as multiply-adds by a 1 the compiler cannot see through: ONE v_mad_i64_i32 each, where the plain
+        // 64-bit add of a sign-extended int is a shift and an add
+        int one = 1;
+        asm volatile("" : "+s"(one));
+        s1[0] += (long long)qx * one;
+        s1[1] += (long long)qy * one;
+        s1[2] += (long long)qz * one;
         s2[0] += (long long)qx * qx;
         s2[1] += (long long)qx * qy;
         s2[2] += (long long)qx * qz;
@@ -446,6 +450,38 @@ __device__ __forceinline__ float hi_split_z(const PwppDevParams &P, double senso
 // ref :551-554  (float products, float adds left to right, one double add)
 __device__ __forceinline__ double plane_dist(float nx, float ny, float nz, double d, float x, float y, float z) {
     return nx * x + ny * y + nz * z + d;
+}
+// the float part of that expression: what the streamed passes evaluate per point
+__device__ __forceinline__ float plane_s(float nx, float ny, float nz, float x, float y, float z) { return nx * x + ny * y + nz * z; }
+
+// The test of ref :525 / :108 / :499 per point is  double(s) + d < thr  with s the float above and d, thr fixed for a whole
+// pass.  double(s) + d is a correctly rounded, hence monotone function of s, so the set of floats that pass is a down-set
+// {s < T} (NaN passes neither form): T = the smallest float that FAILS.  The passes compare s with T in float -- one
+// v_cmp_f32 per point instead of a conversion, a double add and a double compare -- and the owner of the patch finds T
+// once per pass: from the real-number boundary thr - d, corrected by walking the ordered float keys until
+// "T fails and its predecessor passes" holds (a binary search over all floats backs that up; the result is exact by
+// construction whatever d and thr are: infinities and NaN included).
+__device__ __forceinline__ float plane_test_threshold(double d, double thr) {
+    const unsigned kmin = 0x007fffffu /* z_key(-inf) */, kmax = 0xff800000u /* z_key(+inf) */;
+    auto pass_key = [&](unsigned k) { return (double)key_z(k) + d < thr; };
+    if (!pass_key(kmin)) return key_z(kmin);  // nothing passes (d or thr NaN, d = +inf, thr = -inf): s < -inf never holds
+    float t = (float)(thr - d);
+    unsigned k = (t == t) ? z_key(t) : kmax;
+    k = k < kmin ? kmin : (k > kmax ? kmax : k);
+    for (int i = 0; i < 3 && k < kmax && pass_key(k); ++i) ++k;
+    for (int i = 0; i < 3 && k > kmin && !pass_key(k - 1u); ++i) --k;
+    if (pass_key(k) || !pass_key(k - 1u)) {  // (k > kmin here: kmin passes)  not bracketed by the short walk: search all floats
+        unsigned lo = kmin, hi = kmax;       // pass_key(lo), !pass_key(hi): +inf never passes (inf + d is inf or NaN)
+        while (hi - lo > 1u) {
+            const unsigned mid = lo + ((hi - lo) >> 1);
+            if (pass_key(mid))
+                lo = mid;
+            else
+                hi = mid;
+        }
+        k = hi;
+    }
+    return key_z(k);
 }
 
 // Patches are sorted by size into quarter-octave buckets (k_czm_scan); the fit kernels

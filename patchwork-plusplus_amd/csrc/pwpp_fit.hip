@@ -41,6 +41,9 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kPPT = 8;  // points per lane held in registers
+#ifndef PWPP_FIT_PREFETCH
+#define PWPP_FIT_PREFETCH 0
+#endif
 
 // ------------------------------------------------------------------------------------------
 // row = G consecutive lanes of a wave working on one patch
@@ -331,25 +334,39 @@ __device__ __forceinline__ int nonground_entry(int idx, float z) {
 // The loads are unconditional (the first points of the patch stand in beyond its end -- NOT whatever follows in
 // memory: a one-pass segment is mostly unwritten space, and fetching it cost k_fit_w64<16,64> 9 %): the compiler can
 // keep a whole chunk in flight behind the arithmetic of the previous one and wait with a counted s_waitcnt.
+// Which slots of a lane's chunk lie inside the part: slot k holds point first + k_off(k), so with
+//   rem = points of the part - index of the lane's first point          (signed; <= 0: nothing of this lane's)
+// slot k is valid iff k_off(k) < rem -- ONE compare with a constant per slot where it is needed at all: a chunk that is
+// valid in every lane of the wave needs none, but a second code path for it costs more registers than the compare).
 struct ChunkZ {  // what the lowest-point pass needs
     float z[kPPT];
-    unsigned valid;
+    int rem;
 };
 struct ChunkPts {
     float x[kPPT], y[kPPT], z[kPPT];
-    unsigned valid;
+    int rem;
 };
+template <int G>
+__device__ __forceinline__ constexpr int k_off(int k) {
+    return G == 64 ? (k >> 2) * 256 + (k & 3) : k * G;
+}
 template <int G>
 __device__ __forceinline__ unsigned chunk_point(unsigned c, int k, unsigned j) {
     if constexpr (G == 64) return c * 512u + (unsigned)(k >> 2) * 256u + 4u * j + (unsigned)(k & 3);
     return c * (8u * G) + (unsigned)k * G + j;
 }
 template <int G>
-__device__ __forceinline__ unsigned chunk_valid(unsigned n, unsigned c, unsigned j) {
+__device__ __forceinline__ int chunk_rem(unsigned n, unsigned c, unsigned j) {
+    return (int)n - (int)(G == 64 ? c * 512u + 4u * j : c * (8u * G) + j);
+}
+template <int G>
+__device__ __forceinline__ bool chunk_interior(int rem) { return k_off<G>(kPPT - 1) < rem; }
+template <int G>
+__device__ __forceinline__ unsigned chunk_valid_bits(int rem) {
     unsigned valid = 0;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k)
-        if (chunk_point<G>(c, k, j) < n) valid |= 1u << k;
+        if (k_off<G>(k) < rem) valid |= 1u << k;
     return valid;
 }
 // The lowest-point pass keeps the INTERLEAVED mapping (slot k of lane j = point c * 8G + k * G + j) for every row
@@ -360,18 +377,26 @@ __device__ __forceinline__ unsigned chunk_valid(unsigned n, unsigned c, unsigned
 template <int G>
 __device__ __forceinline__ void load_chunk_z(ChunkZ &cp, const PatchRef &pr, const PartSel &sel) {
     const unsigned j = (unsigned)lane_id() & (G - 1);
-    cp.valid = 0;
+    cp.rem = (int)sel.n - (int)(sel.c * (8u * G) + j);
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
         const unsigned i = sel.c * (8u * G) + (unsigned)k * G + j;
         cp.z[k] = pr.z[sel.off + (i < sel.n ? i : 0u)];
-        if (i < sel.n) cp.valid |= 1u << k;
     }
+}
+// the slots of a ChunkZ that are inside the part and still in the patch's working set (not removed by R-VPF)
+template <int G>
+__device__ __forceinline__ unsigned chunk_act_z(const ChunkZ &cp) {
+    unsigned act = 0;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k)
+        if (k * G < cp.rem && !z_stripped(cp.z[k])) act |= 1u << k;
+    return act;
 }
 template <int G>
 __device__ __forceinline__ void load_chunk(ChunkPts &cp, const PatchRef &pr, const PartSel &sel) {
     const unsigned j = (unsigned)lane_id() & (G - 1);
-    cp.valid = chunk_valid<G>(sel.n, sel.c, j);
+    cp.rem = chunk_rem<G>(sel.n, sel.c, j);
     if constexpr (G == 64) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -405,16 +430,6 @@ __device__ __forceinline__ void load_chunk(ChunkPts &cp, const PatchRef &pr, con
 // the slot of point k of this lane (what strip_point marks)
 template <int G>
 __device__ __forceinline__ unsigned chunk_slot(const PartSel &sel, int k, unsigned j) { return sel.off + chunk_point<G>(sel.c, k, j); }
-// the points of a chunk that are still in the patch's working set (not removed by R-VPF); evaluated
-// where the chunk is consumed, so that a chunk loaded ahead does not have to land early
-template <class C>
-__device__ __forceinline__ unsigned chunk_act(const C &cp) {
-    unsigned strip = 0;
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k)
-        if (z_stripped(cp.z[k])) strip |= 1u << k;
-    return cp.valid & ~strip;
-}
 // the cloud indices of a chunk (only the pass that writes the split needs them)
 template <int G>
 __device__ __forceinline__ void load_chunk_idx(int w[kPPT], const PatchRef &pr, const PartSel &sel) {
@@ -441,24 +456,22 @@ __device__ __forceinline__ void load_chunk_idx(int w[kPPT], const PatchRef &pr, 
 
 // per-lane part of one stage: adds the points of one chunk that enter this stage's fit to `m` (ground
 // set of an R-GPF round, seeds of a seed stage) and returns their mask.
-__device__ __forceinline__ unsigned lane_stage_accum(const ChunkPts &cp, unsigned act, int kind, double thr_seed, double th_dist,
-                                                     const PlaneFit &pl, double scale, const FxpOrg &org, Moments &m) {
-    // One test for every stage: a seed pass (ref :108,145, "z < lpr + th_seeds") is the plane test
-    // of ref :525 with normal (0,0,1), d = 0: 0*x + 0*y + 1*z + 0.0 == z for the finite x, y that
-    // binning lets through, so the per-point code has no branch on the stage.
+//   One test for every stage: a seed pass (ref :108,145, "z < lpr + th_seeds") is the plane test of ref :525 with normal
+//   (0,0,1), d = 0: 0*x + 0*y + 1*z + 0.0 == z for the finite x, y that binning lets through, so the per-point code has
+//   no branch on the stage.  The test itself is  s < T  in float, T = plane_test_threshold(d, thr) of the pass
+//   (pwpp_common.hpp): bit for bit the reference's  double(s) + d < thr.  A point R-VPF removed has a NaN for its z
+//   (strip_point) and fails like any NaN; a slot beyond the part's end holds a stand-in record and is masked by `rem`.
+template <int G>
+__device__ __forceinline__ unsigned lane_stage_accum(const ChunkPts &cp, int kind, float T, float nx, float ny, float nz,
+                                                     double scale, const FxpOrg &org, Moments &m) {
     const bool iter = kind == ST_ITER;
-    const float tx = iter ? pl.nx : 0.0f, ty = iter ? pl.ny : 0.0f, tz = iter ? pl.nz : 1.0f;
-    const double td = iter ? pl.d : 0.0;
-    const double thr = iter ? th_dist : thr_seed;
-    if (kind == ST_DONE) act = 0u;
+    const float tx = iter ? nx : 0.0f, ty = iter ? ny : 0.0f, tz = iter ? nz : 1.0f;
     unsigned gmask = 0;
+    // (ONE body: a second copy without the validity compare for chunks that are valid in every lane doubled the unrolled code
+    // and cost the kernels 40-110 spilled registers)
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
-        // (no short circuit: the distance of a slot beyond the patch's end is computed on a stand-in record and
-        // discarded -- one masked compare instead of a branch around the test)
-        const bool below = plane_dist(tx, ty, tz, td, cp.x[k], cp.y[k], cp.z[k]) < thr;  // one-sided
-        const bool inc = below & ((act >> k & 1u) != 0u);
-        if (inc) {  // (a branch on purpose: a seed pass includes about half of the points, an R-GPF round ~60 %)
+        if ((plane_s(tx, ty, tz, cp.x[k], cp.y[k], cp.z[k]) < T) & (k_off<G>(k) < cp.rem)) {  // (a branch on purpose: a seed pass includes about half of the points, an R-GPF round ~60 %)
             gmask |= 1u << k;
             m.add_uncounted(cp.x[k], cp.y[k], cp.z[k], scale, org);
         }
@@ -466,16 +479,31 @@ __device__ __forceinline__ unsigned lane_stage_accum(const ChunkPts &cp, unsigne
     m.n += __popc(gmask);
     return gmask;
 }
+// the pass's threshold for lane_stage_accum: the R-GPF rounds test the distance to the plane (d) against th_dist, the seed
+// stages the height against lpr + th_seeds(_v)
+__device__ __forceinline__ float stage_threshold(int kind, double d, double th_dist, double thr_seed) {
+    return kind == ST_ITER ? plane_test_threshold(d, th_dist) : plane_test_threshold(0.0, thr_seed);
+}
 
-// returns the points of this lane that the R-VPF plane removes (ref :495-503)
-__device__ __forceinline__ unsigned lane_strip(const ChunkPts &cp, unsigned act, bool on, const PlaneFit &pl, double th_dist_v) {
+// The points of this lane that the R-VPF plane removes (ref :495-503): |double(s) + d| < th_dist_v, i.e.
+// t_lo < s < t_hi with t_hi = plane_test_threshold(d, th_dist_v) and t_lo = -plane_test_threshold(-d, th_dist_v)
+// (negation is exact and rounding symmetric).  A point removed before is a NaN and is not hit again.
+struct StripBand {
+    float lo, hi;
+};
+__device__ __forceinline__ StripBand strip_band(double d, double th_dist_v) {
+    StripBand b;
+    b.hi = plane_test_threshold(d, th_dist_v);
+    b.lo = -plane_test_threshold(-d, th_dist_v);
+    return b;
+}
+template <int G>
+__device__ __forceinline__ unsigned lane_strip(const ChunkPts &cp, bool on, float nx, float ny, float nz, const StripBand &b) {
     unsigned hit = 0;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
-        if (on && (act >> k & 1u)) {
-            const double dist = plane_dist(pl.nx, pl.ny, pl.nz, pl.d, cp.x[k], cp.y[k], cp.z[k]);
-            if (fabs(dist) < th_dist_v) hit |= 1u << k;  // ref :499
-        }
+        const float sv = plane_s(nx, ny, nz, cp.x[k], cp.y[k], cp.z[k]);
+        if (on & (sv < b.hi) & (sv > b.lo) & (k_off<G>(k) < cp.rem)) hit |= 1u << k;  // ref :499
     }
     return hit;
 }
@@ -488,13 +516,10 @@ __device__ __forceinline__ unsigned lane_strip(const ChunkPts &cp, unsigned act,
 // evaluate mean and covariance side by side.  Rare (num_min_pts < 4, or a patch whose seeds / ground set dwindle to
 // a few points), so nothing here is tuned; `on` is row-uniform, the loops are wave-uniform.
 template <int G>
-__device__ void tiny_fit_row(const PatchRef &pts, bool on, int kind, double thr_seed, double th_dist, float nx, float ny, float nz, double d,
-                             float mean[3], float c6[6]) {
+__device__ void tiny_fit_row(const PatchRef &pts, bool on, int kind, float T, float nx, float ny, float nz, float mean[3], float c6[6]) {
     const unsigned j = (unsigned)lane_id() & (G - 1);
     const bool iter = kind == ST_ITER;
     const float tx = iter ? nx : 0.0f, ty = iter ? ny : 0.0f, tz = iter ? nz : 1.0f;  // (the one test of lane_stage_accum)
-    const double td = iter ? d : 0.0;
-    const double thr = iter ? th_dist : thr_seed;
     unsigned long long key[3] = {~0ull, ~0ull, ~0ull};
     float qx[3] = {0.0f, 0.0f, 0.0f}, qy[3] = {0.0f, 0.0f, 0.0f}, qz[3] = {0.0f, 0.0f, 0.0f};
     int cnt = 0;
@@ -507,7 +532,7 @@ __device__ void tiny_fit_row(const PatchRef &pts, bool on, int kind, double thr_
         const float pz = pts.z[sl];
         const float2 pxy = pts.xy[sl];
         const int pidx = pts.idx[sl];
-        const bool inc = in && !z_stripped(pz) && (plane_dist(tx, ty, tz, td, pxy.x, pxy.y, pz) < thr);
+        const bool inc = in && (plane_s(tx, ty, tz, pxy.x, pxy.y, pz) < T);  // (a point R-VPF removed is a NaN: it fails)
         unsigned long long mm = Row<G>::ballot(inc);
         while (__any(mm != 0ull)) {  // (wave-uniform: the shuffles below need every lane)
             const int src = Row<G>::first_lane() + (mm ? __ffsll((long long)mm) - 1 : (int)j);
@@ -572,7 +597,7 @@ __device__ double srow_lpr(const PatchRef &pts, bool need, bool use_cutoff, doub
     auto rank_chunk = [&](const PartSel &sel) {
         ChunkZ cp;
         load_chunk_z<G>(cp, pts, sel);
-        const unsigned act = chunk_act(cp);
+        const unsigned act = chunk_act_z<G>(cp);
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
             const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.z[k] < cutoff);
@@ -637,7 +662,7 @@ __device__ double srow_lpr(const PatchRef &pts, bool need, bool use_cutoff, doub
         for (unsigned c = 0; c < nchunk_max; ++c) {
             ChunkZ cp;
             load_chunk_z<G>(cp, pts, chunk_sel<G>(pts, c, use_hi, fast));
-            const unsigned act = chunk_act(cp);
+            const unsigned act = chunk_act_z<G>(cp);
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) {
                 const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.z[k] < cutoff);
@@ -694,7 +719,7 @@ __device__ double srow_lpr(const PatchRef &pts, bool need, bool use_cutoff, doub
             for (unsigned c = 0; c < nchunk_max; ++c) {
                 ChunkZ cp;
                 load_chunk_z<G>(cp, pts, chunk_sel<G>(pts, c, use_hi, remaining > 0));
-                const unsigned act = chunk_act(cp);
+                const unsigned act = chunk_act_z<G>(cp);
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k) {
                     const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.z[k] < cutoff);
@@ -861,6 +886,7 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
         const bool on = kind != ST_DONE;
         const bool use_hi = on && stage_needs_hi(kind, pc.n_hi, thr_seed, P.th_dist, pl, bb, zs);  // row-uniform
         const unsigned nchunk_max = wave_max_u32(on ? patch_chunks<G>(pts, use_hi) : 0u);
+        const float T = stage_threshold(kind, pl.d, P.th_dist, thr_seed);  // the pass's test in float (lane_stage_accum)
         Moments m;
         m.clear();
         unsigned run_g = 0, run_n = 0;
@@ -871,10 +897,10 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
             load_chunk<G>(nx, pts, chunk_sel<G>(pts, c + 1u, use_hi, on));
             int w[kPPT];
             if (__any(last)) load_chunk_idx<G>(w, pts, chunk_sel<G>(pts, c, use_hi, last));
-            const unsigned gmask = lane_stage_accum(cp, chunk_act(cp), kind, thr_seed, P.th_dist, pl, scale, org, m);
+            const unsigned gmask = lane_stage_accum<G>(cp, kind, T, pl.nx, pl.ny, pl.nz, scale, org, m);
             if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                 const unsigned gm = last ? gmask : 0u;
-                const unsigned ngm = last ? (cp.valid & ~gmask) : 0u;
+                const unsigned ngm = last ? (chunk_valid_bits<G>(cp.rem) & ~gmask) : 0u;
                 unsigned tg, tn;
                 unsigned bg = run_g + Row<G>::excl_scan((unsigned)__popc(gm), tg);
                 unsigned bn = run_n + Row<G>::excl_scan((unsigned)__popc(ngm), tn);
@@ -907,7 +933,7 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
             const bool fit = kind != ST_DONE && cnt > 0;  // empty: ref :49
             const bool tiny = fit && cnt <= 3;            // contract v3: the reference's float arithmetic (row-uniform)
             float mt[3], ct[6];
-            if (__any(tiny)) tiny_fit_row<G>(pts, tiny, kind, thr_seed, P.th_dist, pl.nx, pl.ny, pl.nz, pl.d, mt, ct);
+            if (__any(tiny)) tiny_fit_row<G>(pts, tiny, kind, T, pl.nx, pl.ny, pl.nz, mt, ct);
             if (fit) {
                 float mean[3], c6[6];
                 if (tiny) {
@@ -931,11 +957,12 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
         if (__any(vertical)) {
             bool any = false;
             const unsigned nstrip_max = wave_max_u32(vertical ? patch_chunks<G>(pts, true) : 0u);
+            const StripBand band = strip_band(pl.d, P.th_dist_v);
             for (unsigned c = 0; c < nstrip_max; ++c) {
                 ChunkPts cs2;
                 const PartSel sel = chunk_sel<G>(pts, c, true, vertical);
                 load_chunk<G>(cs2, pts, sel);
-                const unsigned hit = lane_strip(cs2, chunk_act(cs2), vertical, pl, P.th_dist_v);
+                const unsigned hit = lane_strip<G>(cs2, vertical, pl.nx, pl.ny, pl.nz, band);
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k) {
                     if (hit >> k & 1u) {
@@ -985,7 +1012,6 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo,
 // wave gets a similar mix and the rows of a points phase have similar trip counts.
 // Waves are independent: no workgroup barrier anywhere.
 // ------------------------------------------------------------------------------------------
-template <bool DUAL>
 struct W64Patch {
     unsigned off_lo, n_lo, off_hi, n_hi;  // the two parts of the bin
     int kind;        // stage of the coming points phase; ST_DONE = nothing to do
@@ -994,14 +1020,21 @@ struct W64Patch {
                      // round of the strip in progress (reference-order output)
     float nx, ny, nz;
     float z0;        // z origin of the patch's fixed-point sums
-    double d;
-    double thr_seed; // (the lowest-point phase hands the representative to the owner lane through this slot)
     float ox, oy;    // x, y origin
-    double thr_band[DUAL ? 1 : 0];  // dual seed pass: upper end of the band [thr_seed, thr_band)
+    // what the rows need of the pass's tests, as float thresholds (plane_test_threshold):
+    //   points phase: t = the stage's test, t2 = the upper end of the band of a dual seed pass;
+    //   R-VPF strip : (t, t2) = the band (lo, hi) around the plane.
+    // The lowest-point phase hands the representative (a double) to the owner lane through the same eight bytes.
+    union {
+        double lpr;
+        struct {
+            float t, t2;
+        } thr;
+    } u;
 };
 template <int PW, bool DUAL, int MW>
 struct W64Shared {
-    W64Patch<DUAL> p[PW];
+    W64Patch p[PW];
     long long mom[PW][MW];
     long long mom2[DUAL ? PW : 1][MW];  // dual seed pass: moments of the band; then the stashed seed totals of the R-GPF stage
 };
@@ -1095,11 +1128,11 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
                 const bool use_cutoff = (sh.p[q].flags & 2) != 0;
                 const PatchRef qpts = patch_ref(Bt, fd, sh.p[q].off_lo, sh.p[q].n_lo, sh.p[q].off_hi, sh.p[q].n_hi);
                 const double l = srow_lpr<G>(qpts, need_row, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
-                if (need_row && j == 0) sh.p[q].thr_seed = l;
+                if (need_row && j == 0) sh.p[q].u.lpr = l;
             }
             wave_lds_sync();
             if (need_lpr) {
-                lpr = sh.p[ln].thr_seed;
+                lpr = sh.p[ln].u.lpr;
                 lpr_valid = true;
                 if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative
                     z0 = fxp_z_origin(lpr);
@@ -1125,10 +1158,11 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
             sh.p[ln].nx = pl.nx;
             sh.p[ln].ny = pl.ny;
             sh.p[ln].nz = pl.nz;
-            sh.p[ln].d = pl.d;
             sh.p[ln].z0 = z0;
-            sh.p[ln].thr_seed = thr_seed;
-            if constexpr (DUAL) sh.p[ln].thr_band[0] = thr_band;
+            if (pub_kind != ST_DONE) {  // the pass's tests as float thresholds (lane_stage_accum)
+                sh.p[ln].u.thr.t = stage_threshold(kind, pl.d, P.th_dist, thr_seed);
+                sh.p[ln].u.thr.t2 = dual_now ? plane_test_threshold(0.0, thr_band) : 0.0f;
+            }
         }
         wave_lds_sync();
 
@@ -1137,15 +1171,10 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
         for (int sb = 0; sb < NSB; ++sb) {
             if (((act_mask >> (R * sb)) & ((1ull << R) - 1ull)) == 0ull) continue;
             const int q = R * sb + row;
-            const W64Patch<DUAL> pp = sh.p[q];
+            const W64Patch pp = sh.p[q];
             const bool on = pp.kind != ST_DONE;
             const bool last = on && (pp.flags & 1);
             const bool use_hi = (pp.flags & 8) != 0;
-            PlaneFit qpl;
-            qpl.nx = pp.nx;
-            qpl.ny = pp.ny;
-            qpl.nz = pp.nz;
-            qpl.d = pp.d;
             const FxpOrg org = fxp_org(pp.ox, pp.oy, pp.z0, scale, P.fxp_zr);
             const PatchRef pts = patch_ref(Bt, fd, pp.off_lo, pp.n_lo, pp.off_hi, pp.n_hi);
             int *plist = frame_plist + pp.off_lo;
@@ -1156,24 +1185,30 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
             m.clear();
             m2.clear();
             unsigned run_g = 0, run_n = 0;
+            // The loads of chunk c + 1 are issued before chunk c is consumed: a wave is a chain load -> wait -> ~250
+            // instructions, and with 3-4 waves per SIMD the waits were not covered (k_fit_w64<64,2> moved its bytes at
+            // 4.8 TB/s where a plain read stream reaches 6.3, tools/ubench/read_bw.hip).  The solve phase sets the
+            // register allocation of these kernels, so the second chunk in flight costs the points phase nothing.
+            const bool any_last = __any(last);
+            ChunkPts cp;
+            if (nchunk_max > 0u) load_chunk<G>(cp, pts, chunk_sel<G>(pts, 0u, use_hi, on));
             for (unsigned c = 0; c < nchunk_max; ++c) {
-                ChunkPts cp;
-                load_chunk<G>(cp, pts, chunk_sel<G>(pts, c, use_hi, on));
-                int w[kPPT];
-                if (__any(last)) load_chunk_idx<G>(w, pts, chunk_sel<G>(pts, c, use_hi, last));
-                const unsigned act = chunk_act(cp);
-                const unsigned gmask = lane_stage_accum(cp, act, pp.kind, pp.thr_seed, P.th_dist, qpl, scale, org, m);
+                ChunkPts nx;
+                if (PWPP_FIT_PREFETCH && c + 1u < nchunk_max) load_chunk<G>(nx, pts, chunk_sel<G>(pts, c + 1u, use_hi, on));  // (wave-uniform)
+                int w[kPPT];  // (the cloud indices are consumed last in the iteration: fetched here, not a chunk ahead -- registers)
+                if (any_last) load_chunk_idx<G>(w, pts, chunk_sel<G>(pts, c, use_hi, last));
+                const unsigned gmask = lane_stage_accum<G>(cp, pp.kind, pp.u.thr.t, pp.nx, pp.ny, pp.nz, scale, org, m);
                 if constexpr (DUAL) {
-                    if (__any(dual)) {  // the band [thr_seed, thr_band) of a dual seed pass
-                        const unsigned rest = dual ? (act & ~gmask) : 0u;
+                    if (__any(dual)) {  // the band [thr_seed, thr_band) of a dual seed pass: the heights below t2 that are not in the first set
+                        const unsigned rest = dual ? ~gmask : 0u;
 #pragma unroll
                         for (int k = 0; k < kPPT; ++k)
-                            if ((rest >> k & 1u) && (double)cp.z[k] < pp.thr_band[0]) m2.add(cp.x[k], cp.y[k], cp.z[k], scale, org);
+                            if ((rest >> k & 1u) & (cp.z[k] < pp.u.thr.t2) & (k_off<G>(k) < cp.rem)) m2.add(cp.x[k], cp.y[k], cp.z[k], scale, org);
                     }
                 }
-                if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
+                if (any_last) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                     const unsigned gm = last ? gmask : 0u;
-                    const unsigned ngm = last ? (cp.valid & ~gmask) : 0u;
+                    const unsigned ngm = last ? (chunk_valid_bits<G>(cp.rem) & ~gmask) : 0u;
                     unsigned tg, tn;
                     unsigned bg = run_g + Row<G>::excl_scan((unsigned)__popc(gm), tg);
                     unsigned bn = run_n + Row<G>::excl_scan((unsigned)__popc(ngm), tn);
@@ -1186,6 +1221,12 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
                         else if (ngm >> k & 1u)
                             plist[qn - 1u - (bn++)] = nonground_entry(w[k], cp.z[k]);
                     }
+                }
+                if (c + 1u < nchunk_max) {
+                    if (PWPP_FIT_PREFETCH)
+                        cp = nx;
+                    else
+                        load_chunk<G>(cp, pts, chunk_sel<G>(pts, c + 1u, use_hi, on));
                 }
             }
             // the row's totals -> LDS.  64-lane rows: reduce-scatter of sixteen values, each stored by the lane it
@@ -1232,14 +1273,14 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
                 if (((t_mask >> (R * sb)) & ((1ull << R) - 1ull)) == 0ull) continue;
                 const int q = R * sb + row;
                 const bool trow = (t_mask >> q) & 1ull;
-                const W64Patch<DUAL> pp = sh.p[q];
-                double thr = pp.thr_seed;
+                const W64Patch pp = sh.p[q];
+                float thr = pp.u.thr.t;
                 if constexpr (DUAL) {
-                    if ((pp.flags & 4) && v_is_hi) thr = pp.thr_band[0];  // dual pass: this round's set is the R-VPF one
+                    if ((pp.flags & 4) && v_is_hi) thr = pp.u.thr.t2;  // dual pass: this round's set is the R-VPF one
                 }
                 const PatchRef pts = patch_ref(Bt, fd, pp.off_lo, pp.n_lo, pp.off_hi, pp.n_hi);
                 float mt[3], ct[6];
-                tiny_fit_row<G>(pts, trow, pp.kind, thr, P.th_dist, pp.nx, pp.ny, pp.nz, pp.d, mt, ct);
+                tiny_fit_row<G>(pts, trow, pp.kind, thr, pp.nx, pp.ny, pp.nz, mt, ct);
                 if (trow && j == 0) {  // mean and covariance take the place of the patch's moments 1..5 (the count stays)
                     float *dst = reinterpret_cast<float *>(&sh.mom[q][1]);
 #pragma unroll
@@ -1300,7 +1341,11 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
                 sh.p[ln].nx = pl.nx;
                 sh.p[ln].ny = pl.ny;
                 sh.p[ln].nz = pl.nz;
-                sh.p[ln].d = pl.d;
+                if (vertical) {
+                    const StripBand band = strip_band(pl.d, P.th_dist_v);
+                    sh.p[ln].u.thr.t = band.lo;
+                    sh.p[ln].u.thr.t2 = band.hi;
+                }
                 sh.p[ln].flags = (sh.p[ln].flags & 0xef) | (it << 8);  // nothing removed yet; the round
             }
             wave_lds_sync();
@@ -1308,12 +1353,10 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
                 if (((v_mask >> (R * sb)) & ((1ull << R) - 1ull)) == 0ull) continue;
                 const int q = R * sb + row;
                 const bool vrow = (v_mask >> q) & 1ull;
-                const W64Patch<DUAL> pp = sh.p[q];
-                PlaneFit qpl;
-                qpl.nx = pp.nx;
-                qpl.ny = pp.ny;
-                qpl.nz = pp.nz;
-                qpl.d = pp.d;
+                const W64Patch pp = sh.p[q];
+                StripBand band;
+                band.lo = pp.u.thr.t;
+                band.hi = pp.u.thr.t2;
                 const PatchRef pts = patch_ref(Bt, fd, pp.off_lo, pp.n_lo, pp.off_hi, pp.n_hi);
                 const int vpf_round = (pp.flags >> 8) & 0xff;
                 const unsigned nchunk_max = wave_max_u32(vrow ? patch_chunks<G>(pts, true) : 0u);
@@ -1322,7 +1365,7 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
                     ChunkPts cp;
                     const PartSel sel = chunk_sel<G>(pts, c, true, vrow);
                     load_chunk<G>(cp, pts, sel);
-                    const unsigned hit = lane_strip(cp, chunk_act(cp), vrow, qpl, P.th_dist_v);
+                    const unsigned hit = lane_strip<G>(cp, vrow, pp.nx, pp.ny, pp.nz, band);
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k) {
                         if (hit >> k & 1u) {
@@ -1452,7 +1495,8 @@ __device__ void reduce_and_fit(FitShared &sh, const MomentsWide &m, int shift, f
             PlaneFit pf;
             float mean[3], c6[6];
             if (n <= 3)
-                tiny_fit_row<64>(pts, true, iter ? ST_ITER : ST_SEED, thr, thr, sh.normal[0], sh.normal[1], sh.normal[2], sh.d, mean, c6);
+                tiny_fit_row<64>(pts, true, iter ? ST_ITER : ST_SEED, stage_threshold(iter ? ST_ITER : ST_SEED, sh.d, thr, thr), sh.normal[0],
+                                 sh.normal[1], sh.normal[2], mean, c6);
             else
                 mean_cov_from_totals(n, s1, s2, shift, ox, oy, z0, mean, c6);
             plane_from_mean_c6(mean, c6, debug, pf);
@@ -1619,7 +1663,7 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, bool use_hi, boo
     for (unsigned c = (unsigned)wv; c < nchunk; c += kWaves) {
         ChunkZ nx;  // the next chunk is in flight while this one is ranked (this is the first, cold touch of the patch)
         load_chunk_z<64>(nx, pts, chunk_sel<64>(pts, c + kWaves, use_hi, c + kWaves < nchunk));
-        const unsigned act = chunk_act(cp);
+        const unsigned act = chunk_act_z<64>(cp);
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
             const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.z[k] < cutoff);
@@ -1788,6 +1832,8 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         const bool last = kind == ST_ITER && it == P.num_iter - 1;
         const bool use_hi = stage_needs_hi(kind, pc.n_hi, dual_now && thr_band > thr_seed ? thr_band : thr_seed, P.th_dist, pl, bb, zs);
         const unsigned nchunk = patch_chunks<64>(pts, use_hi);
+        const float T = stage_threshold(kind, pl.d, P.th_dist, thr_seed);  // the pass's tests in float (lane_stage_accum)
+        const float T_band = dual_now ? plane_test_threshold(0.0, thr_band) : 0.0f;
         Moments m, m2;
         m.clear();
         m2.clear();
@@ -1800,16 +1846,15 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
             load_chunk<64>(nx, pts, chunk_sel<64>(pts, c + kWaves, use_hi));
             int wnx[kPPT];
             if (last) load_chunk_idx<64>(wnx, pts, chunk_sel<64>(pts, c + kWaves, use_hi));
-            const unsigned act = chunk_act(cp);
-            const unsigned gmask = lane_stage_accum(cp, act, kind, thr_seed, P.th_dist, pl, scale, org, m);
+            const unsigned gmask = lane_stage_accum<64>(cp, kind, T, pl.nx, pl.ny, pl.nz, scale, org, m);
             if (dual_now) {  // the band [thr_seed, thr_band)
-                const unsigned rest = act & ~gmask;
+                const unsigned rest = ~gmask;
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k)
-                    if ((rest >> k & 1u) && (double)cp.z[k] < thr_band) m2.add(cp.x[k], cp.y[k], cp.z[k], scale, org);
+                    if ((rest >> k & 1u) & (cp.z[k] < T_band) & (k_off<64>(k) < cp.rem)) m2.add(cp.x[k], cp.y[k], cp.z[k], scale, org);
             }
             if (last) {  // the split is written BEFORE the plane is replaced (ref :529-541)
-                const unsigned ngm = cp.valid & ~gmask;
+                const unsigned ngm = chunk_valid_bits<64>(cp.rem) & ~gmask;
                 unsigned tg, tn;
                 unsigned bg = Row<64>::excl_scan((unsigned)__popc(gmask), tg);
                 unsigned bn = Row<64>::excl_scan((unsigned)__popc(ngm), tn);
@@ -1880,8 +1925,8 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         if (tot[0] > 0) {  // empty: ref :49
             float mean[3], c6[6];
             if (tot[0] <= 3) {  // contract v3 (wave-uniform): this wave gathers the 1-3 points of its set itself
-                const double thr_t = dual_now ? ((spec == v_is_hi) ? thr_seed : thr_band) : thr_seed;
-                tiny_fit_row<64>(pts, true, kind, thr_t, P.th_dist, pl.nx, pl.ny, pl.nz, pl.d, mean, c6);
+                const float thr_t = dual_now ? ((spec == v_is_hi) ? T : T_band) : T;
+                tiny_fit_row<64>(pts, true, kind, thr_t, pl.nx, pl.ny, pl.nz, mean, c6);
             } else {
                 const long long s1[3] = {tot[1], tot[2], tot[3]};
                 mean_cov_from_totals_uniform(tot[0], s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, mean, c6);  // (totals are the same in every lane of this wave)
@@ -1909,11 +1954,12 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
             if (vertical) {
                 int any = 0;
                 const unsigned nstrip = patch_chunks<64>(pts, true);
+                const StripBand band = strip_band(pl.d, P.th_dist_v);
                 for (unsigned c = (unsigned)wv; c < nstrip; c += kWaves) {
                     ChunkPts cs2;
                     const PartSel sel = chunk_sel<64>(pts, c, true);
                     load_chunk<64>(cs2, pts, sel);
-                    const unsigned hit = lane_strip(cs2, chunk_act(cs2), true, pl, P.th_dist_v);
+                    const unsigned hit = lane_strip<64>(cs2, true, pl.nx, pl.ny, pl.nz, band);
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k)
                         if (hit >> k & 1u) strip_point(pts, chunk_slot<64>(sel, k, (unsigned)ln), it);
