@@ -80,6 +80,41 @@ def cpu_baseline(src, budget_s=15.0):
     }
 
 
+def ingest_leg(pwpp_hip, src, gpu_index, chunk=256, chunks=8):
+    """Host-resident frames end to end: every frame is copied H2D (2 MB) and its index lists D2H (0.5 MB)."""
+    bufs, outs = [], []
+    for _ in range(2):
+        rows = sum(src[i % len(src)].shape[0] for i in range(chunk))
+        slab, at, fr = pwpp_hip.pinned_empty((rows, 4)), 0, []
+        for i in range(chunk):
+            a = src[i % len(src)]
+            slab[at:at + a.shape[0]] = a
+            fr.append(slab[at:at + a.shape[0]])
+            at += a.shape[0]
+        bufs.append(fr)
+        outs.append(pwpp_hip.pinned_empty((rows,), np.int32))
+    mb_in = sum(f.nbytes for f in bufs[0]) / 1e6
+    H = [pwpp_hip.Handle(device=gpu_index), pwpp_hip.Handle(device=gpu_index)]
+    for k in range(2):  # warm-up: allocations
+        H[k].submit_pinned_batch(bufs[k])
+        H[k].all_indices(outs[k])
+    t0 = time.perf_counter()
+    ground = 0
+    for k in range(chunks):
+        H[k % 2].submit_pinned_batch(bufs[k % 2])
+        if k > 0:
+            _, _, counts = H[(k - 1) % 2].all_indices(outs[(k - 1) % 2])
+            ground += int(counts[:, 0].sum())
+    _, _, counts = H[(chunks - 1) % 2].all_indices(outs[(chunks - 1) % 2])
+    ground += int(counts[:, 0].sum())
+    dt = time.perf_counter() - t0
+    for hh in H:
+        hh.close()
+    return {"frames_per_s": chunks * chunk / dt, "h2d_GBps": chunks * mb_in / 1e3 / dt, "chunk_frames": chunk, "chunks": chunks,
+            "ground_points": ground,
+            "what": "page-locked host slabs -> H2D -> pipeline -> D2H of all index lists, two handles double-buffered (PWPP_MEM_HOST_PINNED)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +130,7 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of the separate single-stream pass that measures per-kernel times")
     ap.add_argument("--skip-latency", action="store_true")
+    ap.add_argument("--skip-extras", action="store_true", help="no parity_check / reference_order / ingest legs (all of them run outside the timed region)")
     args = ap.parse_args()
 
     import torch
@@ -156,17 +192,40 @@ def main():
         by_src.setdefault(which[i], set()).add(tuple(int(v) for v in counts[i, :3]))
     assert os.environ.get("PWPP_BENCH_NO_SELFCHECK") or all(len(v) == 1 for v in by_src.values()), "replayed frames disagree: %r" % by_src
 
+    selfcheck = not os.environ.get("PWPP_BENCH_NO_SELFCHECK")
+    # oracle anchor (outside the timed region): the ground masks and plane normals of batch frames 0-5 and
+    # of one frame of the second frame range against the committed goldens, which tests/golden/make_golden.py generated
+    # from the reference's own patchworkpp.cpp (oracle/_ref, eigen-f32 build).  Nothing under oracle/ is touched here.
+    parity = None
+    gpath = os.path.join(ROOT, "tests", "golden", "kitti_golden.npz")
+    if args.workload == "kitti" and data_name.startswith("kitti") and os.path.exists(gpath) and not args.skip_extras:
+        gold = np.load(gpath)
+        picks = sorted(set(i for i in list(range(6)) + [F - 1 - (F // 4)] if 0 <= i < F))
+        iou_min, dn_max = 1.0, 0.0
+        for i in picks:
+            k = which[i]
+            mask = np.zeros(ns[i], np.uint8)
+            mask[h.ground_indices(i)] = 1
+            want = np.unpackbits(gold["f32/fresh/%d/ground_mask" % k])[:ns[i]]
+            inter, union = int((mask & want).sum()), int((mask | want).sum())
+            iou_min = min(iou_min, inter / union if union else 1.0)
+            dn_max = max(dn_max, float(np.abs(h.normals(i) - gold["f32/fresh/%d/normals" % k]).max()))
+        parity = {"frames": len(picks), "batch_frames": picks, "iou": iou_min, "max_dnormal": dn_max,
+                  "against": "tests/golden/kitti_golden.npz = the reference's patchworkpp.cpp (oracle/_ref, float sums), fresh state per frame"}
+        assert not selfcheck or (iou_min == 1.0 and dn_max < 1e-4), "parity anchor failed: %r" % parity
+
     # The timed region runs the library's default schedule (overlap mode for batches of 128+ frames) with no
     # profiling events in it; the per-kernel times and the roofline line come from a SEPARATE single-stream pass
     # after the timed region (HIP events around every launch would serialise the two frame ranges).
-    pwpp_dist.barrier()
+    pwpp_dist.barrier(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    pwpp_dist.barrier()
+    pwpp_dist.barrier(dev)
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
     elapsed, total_frames = pwpp_dist.aggregate(elapsed, F * args.steps, dev if backend == "nccl" else None)  # MAX time, SUM frames over ranks
     if not args.no_profile_events:  # kernel times of the single-stream schedule, outside the timed region
         h.set_profiling(True)
@@ -186,6 +245,32 @@ def main():
         lat.append(time.perf_counter() - t1)
     lat_gpu_us = h.time_us()
     lat = sorted(lat)[len(lat) // 2] if lat else 0.0
+
+    per_gpu = pwpp_dist.gather_values(F * args.steps / my_elapsed, dev if backend == "nccl" else None)  # every rank's own frames/s
+
+    # reference-order output mode: the same batch with every sub-list in the reference's z-sorted order
+    ref_order = None
+    if not args.skip_extras:
+        h.set_output_order(True)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        ref_order = {"ms_per_step": 1000.0 * (time.perf_counter() - t1) / 5, "steps": 5,
+                     "what": "pwpp_set_output_order(PWPP_ORDER_REFERENCE): k_order_sublists after k_emit, one stream"}
+        h.set_output_order(False)
+
+    # ingest (PCIe-inclusive, never `value`): chunks of 256 frames from page-locked host slabs, two handles
+    # double-buffered (H2D + pipeline of one chunk under the D2H of the other's index lists), rank 0 at N = 1 only
+    ingest = None
+    if world == 1 and args.workload == "kitti" and not args.skip_extras:
+        try:
+            ingest = ingest_leg(pwpp_hip, src, gpu_index)
+        except Exception as e:
+            ingest = {"frames_per_s": None, "error": str(e)}
 
     if rank == 0:
         fps = total_frames / elapsed
@@ -210,6 +295,14 @@ def main():
             "latency": {"workload": "configs[1]: single frame, device-resident, fresh state", "ms_per_frame_wall": 1000.0 * lat,
                         "gpu_us": lat_gpu_us},
         }
+        out["per_gpu"] = [{"rank": r, "frames_per_s": v} for r, v in enumerate(per_gpu)]
+        out["selfcheck"] = bool(selfcheck)
+        if parity is not None:
+            out["parity_check"] = parity
+        if ref_order is not None:
+            out["reference_order"] = ref_order
+        if ingest is not None:
+            out["ingest"] = ingest
         if prof:
             dom = max(prof, key=lambda k: prof[k][0])
             dom_ms = prof[dom][0] / max(prof[dom][1], 1)

@@ -20,6 +20,11 @@
 
 #include <stdint.h>
 
+/* Only the entry points below are exported: libpwpp_hip.so is built with -fvisibility=hidden. */
+#ifndef PWPP_API
+#define PWPP_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -122,27 +127,27 @@ typedef struct pwpp_handle pwpp_handle;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
 /* Params() defaults, reference patchworkpp.h:79-111 */
-int pwpp_params_default(pwpp_params *p);
+PWPP_API int pwpp_params_default(pwpp_params *p);
 /* PatchWorkpp::PatchWorkpp(Params), reference patchworkpp.h:120-150: validates, computes the
  * CZM geometry in double exactly as the reference constructor, creates stream + workspace. */
-int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out);
-int pwpp_destroy(pwpp_handle *h);
-const char *pwpp_last_error(void);
-int pwpp_device_count(void);
+PWPP_API int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out);
+PWPP_API int pwpp_destroy(pwpp_handle *h);
+PWPP_API const char *pwpp_last_error(void);
+PWPP_API int pwpp_device_count(void);
 
 /* ---- the hot path ---------------------------------------------------------------------- */
 /* void PatchWorkpp::estimateGround(Eigen::MatrixXf cloud_in), reference patchworkpp.cpp:151.
  * One frame, host memory, stream 0 of the handle, stateful like the reference object.
  * cols is 3 or 4 (3 only legal with enable_RNR == 0 semantics of patchworkpp.cpp:379-382:
  * RNR is skipped).  Synchronous: results are ready on return. */
-int pwpp_estimate_ground(pwpp_handle *h, const float *points, int n, int cols, int layout);
+PWPP_API int pwpp_estimate_ground(pwpp_handle *h, const float *points, int n, int cols, int layout);
 
 /* Many independent frames in one set of launches.  points[i] is frame i (host or device
  * memory according to `mem`), n[i] its point count.  PWPP_MODE_FRESH: each frame is
  * processed with fresh state.  PWPP_MODE_STREAMS: frames <= streams configured with
  * pwpp_set_num_streams(); frame i continues stream i.  Asynchronous when mem is
  * PWPP_MEM_DEVICE or PWPP_MEM_HOST_PINNED: call pwpp_synchronize() before reading results. */
-int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const int32_t *n, int frames,
+PWPP_API int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const int32_t *n, int frames,
                                int cols, int layout, int mem, int mode);
 /* The ROS 2 wrapper's input (reference ros/src/GroundSegmentationServer.cpp:72-75, ros/src/Utils.hpp:158-172
  * PointCloud2ToEigenMat: x, y, z read through one float32 iterator per field): `data` = msg->data, n = height * width,
@@ -150,15 +155,15 @@ int pwpp_estimate_ground_batch(pwpp_handle *h, const float *const *points, const
  * there is none -- RNR is then skipped as for an N x 3 matrix, patchworkpp.cpp:379-382).  The fields are read where
  * they lie: no repacked copy on the host.  pwpp_estimate_ground_fields = one frame on stream 0 from host memory, like
  * pwpp_estimate_ground; the _batch form takes `mem` and `mode` like pwpp_estimate_ground_batch. */
-int pwpp_estimate_ground_fields(pwpp_handle *h, const void *data, int n, int point_step, int off_x, int off_y, int off_z, int off_intensity);
-int pwpp_estimate_ground_fields_batch(pwpp_handle *h, const void *const *data, const int32_t *n, int frames, int point_step,
+PWPP_API int pwpp_estimate_ground_fields(pwpp_handle *h, const void *data, int n, int point_step, int off_x, int off_y, int off_z, int off_intensity);
+PWPP_API int pwpp_estimate_ground_fields_batch(pwpp_handle *h, const void *const *data, const int32_t *n, int frames, int point_step,
                                       int off_x, int off_y, int off_z, int off_intensity, int mem, int mode);
-int pwpp_synchronize(pwpp_handle *h);
-int pwpp_set_num_streams(pwpp_handle *h, int streams); /* (re)creates `streams` fresh stream states */
+PWPP_API int pwpp_synchronize(pwpp_handle *h);
+PWPP_API int pwpp_set_num_streams(pwpp_handle *h, int streams); /* (re)creates `streams` fresh stream states */
 
 /* ---- results of the last call ---------------------------------------------------------- */
 /* sizes of getGround()/getNonground()/getCenters(), reference patchworkpp.h:157-163 */
-int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32_t *n_nonground, int32_t *n_patches);
+PWPP_API int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32_t *n_nonground, int32_t *n_patches);
 /* getGroundIndices()/getNongroundIndices(), reference patchworkpp.h:159-160, patchworkpp.cpp:18-26.
  * The index SETS are those of the reference's control flow with the plane-fit sums of patchworkpp.cpp:56-60
  * evaluated (contract v3)
@@ -177,66 +182,66 @@ int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32_t *n_non
  *     arithmetic by more than this library does).
  * (NaN heights are undefined in the reference itself: it sorts bins with `a.z < b.z`.)
  * The order inside a list is not the reference's unless pwpp_set_output_order asks for it. */
-int pwpp_get_ground_indices(pwpp_handle *h, int frame, int32_t *out);
-int pwpp_get_nonground_indices(pwpp_handle *h, int frame, int32_t *out);
+PWPP_API int pwpp_get_ground_indices(pwpp_handle *h, int frame, int32_t *out);
+PWPP_API int pwpp_get_nonground_indices(pwpp_handle *h, int frame, int32_t *out);
 /* getGround()/getNonground(), reference patchworkpp.h:157-158: row-major (count,3) float32,
  * rows aligned with the index getters above. */
-int pwpp_get_ground_xyz(pwpp_handle *h, int frame, float *out);
-int pwpp_get_nonground_xyz(pwpp_handle *h, int frame, float *out);
+PWPP_API int pwpp_get_ground_xyz(pwpp_handle *h, int frame, float *out);
+PWPP_API int pwpp_get_nonground_xyz(pwpp_handle *h, int frame, float *out);
 /* getCenters()/getNormals(), reference patchworkpp.h:162-163: row-major (n_patches,3), bin traversal order */
-int pwpp_get_centers(pwpp_handle *h, int frame, float *out);
-int pwpp_get_normals(pwpp_handle *h, int frame, float *out);
+PWPP_API int pwpp_get_centers(pwpp_handle *h, int frame, float *out);
+PWPP_API int pwpp_get_normals(pwpp_handle *h, int frame, float *out);
 /* per-patch detail for parity checks (no reference getter; fields are the reference's scratch members) */
-int pwpp_get_patch_records(pwpp_handle *h, int frame, pwpp_patch_record *out, int capacity);
+PWPP_API int pwpp_get_patch_records(pwpp_handle *h, int frame, pwpp_patch_record *out, int capacity);
 /* getHeight(), reference patchworkpp.h:154 (stream 0) */
-double pwpp_get_height(pwpp_handle *h);
+PWPP_API double pwpp_get_height(pwpp_handle *h);
 /* getTimeTaken(), reference patchworkpp.h:155: microseconds of the last estimate call
  * (GPU time between HIP events on the handle's stream, batch calls: whole batch) */
-double pwpp_get_time_us(pwpp_handle *h);
+PWPP_API double pwpp_get_time_us(pwpp_handle *h);
 
 /* ---- adaptive state --------------------------------------------------------------------- */
 /* state after the last call; PWPP_MODE_FRESH: `index` is the frame, PWPP_MODE_STREAMS: the stream */
-int pwpp_get_state(pwpp_handle *h, int index, pwpp_state *out);
-int pwpp_get_history(pwpp_handle *h, int index, int which /*0 elevation, 1 flatness*/, int ring, double *out, int capacity);
+PWPP_API int pwpp_get_state(pwpp_handle *h, int index, pwpp_state *out);
+PWPP_API int pwpp_get_history(pwpp_handle *h, int index, int which /*0 elevation, 1 flatness*/, int ring, double *out, int capacity);
 /* overwrite the scalars of a stream state; its histories are cleared (elevation_len / flatness_len of `in` are ignored),
  * its plane members (pwpp_set_plane_state) are left as they are */
-int pwpp_set_state(pwpp_handle *h, int stream, const pwpp_state *in);
+PWPP_API int pwpp_set_state(pwpp_handle *h, int stream, const pwpp_state *in);
 /* ... and put a history back: after pwpp_set_state + eight pwpp_set_history calls with what pwpp_get_state /
  * pwpp_get_history returned, a stream continues exactly where the checkpointed one stood. */
-int pwpp_set_history(pwpp_handle *h, int stream, int which /*0 elevation, 1 flatness*/, int ring, const double *values, int count);
+PWPP_API int pwpp_set_history(pwpp_handle *h, int stream, int which /*0 elevation, 1 flatness*/, int ring, const double *values, int count);
 /* The plane members of the reference object (pc_mean_, normal_, singular_values_, d_: patchworkpp.h:177-182) as they
  * stand after the state's last frame -- {mean[3], normal[3], singular values[3], d}.  They are part of what a stream
  * carries from frame to frame: a bin that is processed without a fit (an empty bin let through by num_min_pts <= 0, the
  * ROS launch file's setting) reports whatever plane was fitted last, also across frames (patchworkpp.cpp:49).  Zero for a
  * new stream; a checkpoint is pwpp_get_state + the histories + this. */
-int pwpp_get_plane_state(pwpp_handle *h, int index, float out[10]);
+PWPP_API int pwpp_get_plane_state(pwpp_handle *h, int index, float out[10]);
 /* Frames this handle had to finish with the serial fix-up kernel: a patch whose first fit set is empty consults the
  * plane the reference object fitted last (the patch before it, or the frame before), which the parallel fit kernels
  * only recognise; the host then runs k_fit_fixup + the GLE and list kernels for that frame.  It takes a lowest height
  * of -inf, one beyond 1e15 m, or num_lpr = 0 -- no real scan; the count exists for tests. */
-int64_t pwpp_get_fixed_up_frames(pwpp_handle *h);
+PWPP_API int64_t pwpp_get_fixed_up_frames(pwpp_handle *h);
 /* Host only (no device needed): shift and per-bin origins {ox, oy} of the fixed-point plane-fit sums a handle created with
  * these parameters would use (= pwpp_get_fxp_shift / pwpp_get_fxp_origins of that handle).  The CPU tests compare them with
  * the restatement's for many CZM shapes.  Returns the number of bins; shift / out_xy may be NULL. */
-int pwpp_get_fxp_geometry(const pwpp_params *p, int *shift, float *out_xy, int capacity_bins);
+PWPP_API int pwpp_get_fxp_geometry(const pwpp_params *p, int *shift, float *out_xy, int capacity_bins);
 /* Host only (no device needed): the axis-aligned box {xmin, xmax, ymin, ymax} the library assumes around every CZM bin of
  * a parameter set, bins in traversal order (zone, ring, sector).  The fit kernels prove with it that no point of a bin's
  * high part can lie below a plane, so every point the reference bins into b must lie inside box b:
  * tests/test_capi_cpu.py checks exactly that.  Returns the number of bins (with out_boxes == NULL: just that). */
-int pwpp_get_bin_boxes(const pwpp_params *p, float *out_boxes, int capacity_bins);
-int pwpp_set_plane_state(pwpp_handle *h, int stream, const float in[10]);
+PWPP_API int pwpp_get_bin_boxes(const pwpp_params *p, float *out_boxes, int capacity_bins);
+PWPP_API int pwpp_set_plane_state(pwpp_handle *h, int stream, const float in[10]);
 
 /* ---- ingest ----------------------------------------------------------------- */
 /* Page-locked host memory: frames handed over in such buffers are DMA'd straight to the device
  * (pageable memory is staged by the runtime at a fraction of the PCIe rate), and result copies
  * into them do not block. */
-int pwpp_host_alloc(void **out, uint64_t bytes);
-int pwpp_host_free(void *p);
+PWPP_API int pwpp_host_alloc(void **out, uint64_t bytes);
+PWPP_API int pwpp_host_free(void *p);
 /* All index lists of the last batch in ONE device-to-host copy: out[frame_base[f] .. +n_ground)
  * is frame f's ground list, followed by its non-ground list; frame_base (frames+1 entries) and
  * counts (frames x 8 int32, see pwpp_device_view) are filled if not NULL.  `out` must hold the
  * total number of points of the batch. */
-int pwpp_get_all_indices(pwpp_handle *h, int32_t *out, int64_t *frame_base, int32_t *counts);
+PWPP_API int pwpp_get_all_indices(pwpp_handle *h, int32_t *out, int64_t *frame_base, int32_t *counts);
 
 /* ---- device-side views and measurement --------------------------------------------------- */
 typedef struct pwpp_device_view {
@@ -247,18 +252,21 @@ typedef struct pwpp_device_view {
     int32_t frames;
     int32_t pad_;
 } pwpp_device_view;
-int pwpp_get_device_view(pwpp_handle *h, pwpp_device_view *out);
+PWPP_API int pwpp_get_device_view(pwpp_handle *h, pwpp_device_view *out);
 
 /* per-kernel GPU time (HIP events on the handle's stream around every launch) */
 #define PWPP_NUM_KERNELS 11
-int pwpp_set_profiling(pwpp_handle *h, int enable);
-int pwpp_get_kernel_profile(pwpp_handle *h, double *sum_ms /*[PWPP_NUM_KERNELS]*/, int64_t *launches /*[PWPP_NUM_KERNELS]*/);
-int pwpp_reset_kernel_profile(pwpp_handle *h);
-const char *pwpp_kernel_name(int k);
+PWPP_API int pwpp_set_profiling(pwpp_handle *h, int enable);
+PWPP_API int pwpp_get_kernel_profile(pwpp_handle *h, double *sum_ms /*[PWPP_NUM_KERNELS]*/, int64_t *launches /*[PWPP_NUM_KERNELS]*/);
+PWPP_API int pwpp_reset_kernel_profile(pwpp_handle *h);
+PWPP_API const char *pwpp_kernel_name(int k);
 /* the fixed-point contract of the plane-fit sums for this handle: the shift s (grid 2^-s m) ... */
-int pwpp_get_fxp_shift(pwpp_handle *h);
-/* ... and every bin's origin (its polar centre rounded to 1/8 m): out_xy = B x {x, y}; returns B */
-int pwpp_get_fxp_origins(pwpp_handle *h, float *out_xy, int capacity_bins);
+PWPP_API int pwpp_get_fxp_shift(pwpp_handle *h);
+/* ... and every bin's origin (its polar centre rounded to 1/8 m): out_xy = B x {x, y}; returns B (out_xy = NULL: only B).
+ * The z coordinates of a fit of 4+ points are clamped to z0 +- 2^(26-s) m (32 m with the default CZM; z0 = the patch's first
+ * lowest-point representative rounded to 1/8 m) before they are quantised: a fit set that spans more than that vertically --
+ * no ground patch does; a facade that R-VPF did not strip could -- gets the plane of the clamped heights. */
+PWPP_API int pwpp_get_fxp_origins(pwpp_handle *h, float *out_xy, int capacity_bins);
 /* Order of the points INSIDE a patch's part of the index lists (the parts themselves always follow the
  * reference: bin traversal order, TGR candidates at the end of their ring).
  *   PWPP_ORDER_SCATTER   (default) whatever the binning atomics produced -- same sets, fastest;
@@ -268,18 +276,18 @@ int pwpp_get_fxp_origins(pwpp_handle *h, float *out_xy, int capacity_bins);
  *                        Equal z: cloud order (the reference's std::sort leaves ties unspecified).
  * Applies to the batches launched after the call. */
 enum { PWPP_ORDER_SCATTER = 0, PWPP_ORDER_REFERENCE = 1 };
-int pwpp_set_output_order(pwpp_handle *h, int order);
+PWPP_API int pwpp_set_output_order(pwpp_handle *h, int order);
 
 /* Overlap mode (ON by default): batches of 128 frames or more are processed as two frame ranges -- binning
  * and index lists of both on the handle's main stream, each range's plane fits on a stream of its own -- so
  * that the stages of one range fill the wave slots the other leaves empty (binning and index lists are bound
  * by memory, the plane fits by their dependent chains).  Same results; per-kernel profiling (pwpp_set_profiling) and PWPP_ORDER_REFERENCE use the single-stream
  * schedule.  pwpp_set_overlap(h, 0) / PWPP_OVERLAP=0 select that schedule for everything. */
-int pwpp_set_overlap(pwpp_handle *h, int on);
+PWPP_API int pwpp_set_overlap(pwpp_handle *h, int on);
 /* one-pass binning (fixed bin segments; DESIGN.md 3, K1'): batches launched that way and how many of
  * them had to be redone on the exact two-pass path because a bin outgrew its segment.  Finishes the
  * batch in flight first.  No reference counterpart. */
-int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone);
+PWPP_API int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone);
 
 
 /* Tuning and test switches (no reference counterpart).  The environment variables PWPP_DEBUG_FLAGS,
@@ -304,13 +312,16 @@ int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone);
  *   "debug_flags"         4: timing probes of the fit chain; 16: exact binning arithmetic only;
  *                         16384 / 32768: force the fall-back paths of the lowest-point selection
  * Returns PWPP_E_ARG for an unknown name or a value out of range. */
-int pwpp_set_option(pwpp_handle *h, const char *name, const char *value);
-/* Frees the per-batch workspaces (a handle that processed one large batch otherwise keeps them, e.g. 9.7 GB
- * after 1024 KITTI frames with one-pass binning); streams' state and results of the last call are kept
- * only as far as they live outside those buffers: fetch results first.  The next call allocates again. */
-int pwpp_trim_workspace(pwpp_handle *h);
-/* device memory the handle holds for its workspaces right now, in bytes (inputs handed over as device buffers are the caller's) */
-int64_t pwpp_get_workspace_bytes(pwpp_handle *h);
+PWPP_API int pwpp_set_option(pwpp_handle *h, const char *name, const char *value);
+/* Frees everything whose size follows the batch (a handle that processed one large batch otherwise keeps it, e.g. 9.7 GB
+ * after 1024 KITTI frames with one-pass binning): inputs staged from the host, the bin-ordered planes, the index lists,
+ * every per-frame table and patch record, the state of PWPP_MODE_FRESH frames and the one-pass snapshots.  Kept: the
+ * streams' state (thresholds, histories, plane members) and the per-handle tables (a few KB).  The results of the last
+ * call are gone: fetch them first.  The next call allocates again. */
+PWPP_API int pwpp_trim_workspace(pwpp_handle *h);
+/* device memory the handle holds right now, in bytes: EVERY device allocation of the handle (inputs handed over as device
+ * buffers are the caller's); after pwpp_trim_workspace what is left is the streams' state and the per-handle tables */
+PWPP_API int64_t pwpp_get_workspace_bytes(pwpp_handle *h);
 
 #ifdef __cplusplus
 }

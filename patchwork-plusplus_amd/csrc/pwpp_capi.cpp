@@ -5,6 +5,7 @@
 // (/root/reference/cpp/patchworkpp/include/patchwork/patchworkpp.h:120-150) and drives the six
 // kernels of pwpp_kernels.hip.  There is no CPU fallback: without a GPU every compute entry
 // point fails with PWPP_E_NODEVICE / PWPP_E_HIP.
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -354,6 +355,14 @@ void fill_default_state(const pwpp_handle *h, PwppStateScalar &s) {
 
 int finish_pending(pwpp_handle *h);
 
+// every stream a schedule may have put work on (error paths, pwpp_destroy): the main stream alone is not the join of a
+// schedule that stopped half way
+void sync_all_streams(pwpp_handle *h) {
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+    for (hipStream_t st : h->extra_streams) (void)hipStreamSynchronize(st);
+}
+
 // the stream history slabs [stream][2][4][cap] re-laid out for a larger cap (contents kept)
 int grow_stream_histories(pwpp_handle *h, int new_cap) {
     const size_t rows = (size_t)h->num_streams * 8;
@@ -608,17 +617,22 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
                 h->extra_streams.push_back(st);
             }
             hipStream_t mem = h->stream;
+            // (every record / wait is checked: a failed one would leave the fit streams unordered against binning and
+            // k_emit, and the batch would "succeed" with racy results -- ADVICE r02)
+            auto ordered_ok = [&](hipError_t e) {
+                if (e != hipSuccess && lrc == 0) lrc = (int)e;
+            };
             auto bin = [&](int r) {
                 const int k = r % h->num_fit_streams;
                 hipStream_t fit = k == 0 ? h->aux_stream : h->extra_streams[(size_t)k - 1];
                 stage(r, 1, mem);
-                (void)hipEventRecord(h->ev_ranges[2 * (size_t)r], mem);
-                (void)hipStreamWaitEvent(fit, h->ev_ranges[2 * (size_t)r], 0);
+                if (lrc == 0) ordered_ok(hipEventRecord(h->ev_ranges[2 * (size_t)r], mem));
+                if (lrc == 0) ordered_ok(hipStreamWaitEvent(fit, h->ev_ranges[2 * (size_t)r], 0));
                 stage(r, 2, fit);
-                (void)hipEventRecord(h->ev_ranges[2 * (size_t)r + 1], fit);
+                if (lrc == 0) ordered_ok(hipEventRecord(h->ev_ranges[2 * (size_t)r + 1], fit));
             };
             auto lists = [&](int r) {
-                (void)hipStreamWaitEvent(mem, h->ev_ranges[2 * (size_t)r + 1], 0);
+                if (lrc == 0) ordered_ok(hipStreamWaitEvent(mem, h->ev_ranges[2 * (size_t)r + 1], 0));
                 stage(r, 4, mem);
             };
             bin(0);
@@ -644,7 +658,10 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
         lrc = pwpp_launch_pipeline(&bt, h->stream, h->profiling ? h->ev_k : nullptr, h->aux_stream, h->aux_fork, h->aux_join,
                                    ordered ? h->d_ord_a.p : nullptr, ordered ? h->d_ord_b.p : nullptr, 7);
     }
-    if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    if (lrc != 0) {  // nothing of a half-launched schedule may still be running when the caller sees the error
+        sync_all_streams(h);
+        return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    }
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
     if (one_pass)  // the bins' largest counts, for the segment sizes of the next batches (finish_pending)
         HIPCHK(hipMemcpyAsync(h->h_bin_max.p, h->d_bin_max.p, (size_t)NP * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
@@ -908,7 +925,7 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
 int pwpp_destroy(pwpp_handle *h) {
     if (!h) return PWPP_OK;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    sync_all_streams(h);
     h->d_frames.release();
     h->h_frames.release();
     h->h_base.release();
@@ -988,6 +1005,12 @@ int pwpp_estimate_ground_fields_batch(pwpp_handle *h, const void *const *data, c
         if (off[k] < 0 || (off[k] & 3) || off[k] + 4 > point_step)
             return fail(PWPP_E_ARG, "field offset %d does not name a 4-byte aligned float32 inside a point of %d bytes", off[k], point_step);
     }
+    // the fields are read in place as float32 (host: merged copies computed in units of floats; device: aligned loads): a
+    // blob that does not start on a 4-byte boundary cannot be read that way
+    if (!data || !n) return fail(PWPP_E_ARG, "null argument");
+    for (int i = 0; i < frames; ++i)
+        if (n[i] > 0 && (reinterpret_cast<uintptr_t>(data[i]) & 3u) != 0)
+            return fail(PWPP_E_ARG, "frame %d: data pointer %p is not 4-byte aligned", i, data[i]);
     FieldSpec fs;
     fs.step = point_step;
     for (int k = 0; k < 4; ++k) fs.off[k] = off[k] < 0 ? -1 : off[k];
@@ -1430,6 +1453,11 @@ int pwpp_set_history(pwpp_handle *h, int stream, int which, int ring, const doub
     if (stream < 0 || stream >= h->num_streams) return fail(PWPP_E_ARG, "stream %d out of range", stream);
     if (which < 0 || which > 1 || ring < 0 || ring > 3) return fail(PWPP_E_ARG, "bad history selector");
     if (count < 0 || count > (1 << 24)) return fail(PWPP_E_ARG, "count %d out of range", count);
+    // (count is NOT limited to max_*_storage: the reference only trims a history in update_elevation_thr / update_flatness_thr,
+    // which stop at the first ring without data, so a sensor that sees no ground in ring 0 grows the others without bound --
+    // test_histories_the_reference_never_trims restores exactly such a state)
+    for (int i = 0; i < count; ++i)
+        if (!(std::fabs(values[i]) <= DBL_MAX)) return fail(PWPP_E_ARG, "history value %d is not finite: the reference only ever pushes finite heights and flatness values", i);
     while (count + h->max_pushes_per_frame + 8 > h->stream_hist_cap)
         if ((rc = grow_stream_histories(h, 2 * h->stream_hist_cap))) return rc;
     double *dst = h->d_hist_stream.p + ((size_t)stream * 8 + (size_t)which * 4 + ring) * h->stream_hist_cap;
@@ -1511,8 +1539,9 @@ int pwpp_reset_kernel_profile(pwpp_handle *h) {
 int pwpp_get_fxp_shift(pwpp_handle *h) { return h ? h->dp.fxp_shift : PWPP_E_ARG; }
 
 int pwpp_get_fxp_origins(pwpp_handle *h, float *out_xy, int capacity_bins) {
-    if (!h || !out_xy) return fail(PWPP_E_ARG, "null argument");
+    if (!h) return fail(PWPP_E_ARG, "null argument");
     const int B = h->dp.num_bins;
+    if (!out_xy) return B;  // size query
     if (capacity_bins < B) return fail(PWPP_E_ARG, "room for %d bins, %d needed", capacity_bins, B);
     int rc = use_device(h);
     if (rc) return rc;
@@ -1584,11 +1613,17 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
 
 int64_t pwpp_get_workspace_bytes(pwpp_handle *h) {
     if (!h) return PWPP_E_ARG;
+    // EVERY device allocation of the handle (the sum used to leave out the descriptors, the stream state and
+    // the tables, and reported the per-frame buffers pwpp_trim_workspace did not free)
     auto b = [](size_t cap, size_t elt) { return (int64_t)(cap * elt); };
-    return b(h->d_in.cap, 4) + b(h->d_codes.cap, 2) + b(h->d_sorted_z.cap, 4) + b(h->d_sorted_xy.cap, 8) + b(h->d_sorted_idx.cap, 4) +
+    return b(h->d_frames.cap, sizeof(PwppFrameDesc)) + b(h->d_frames_probe.cap, sizeof(PwppFrameDesc)) + b(h->d_in.cap, 4) + b(h->d_codes.cap, 2) +
+           b(h->d_sorted_z.cap, 4) + b(h->d_sorted_xy.cap, 8) + b(h->d_sorted_idx.cap, 4) + b(h->d_bin_origin.cap, 8) + b(h->d_bin_bbox.cap, 16) +
            b(h->d_plist.cap, 4) + b(h->d_out.cap, 4) + b(h->d_ord_a.cap, 8) + b(h->d_ord_b.cap, 8) + b(h->d_bins.cap, 4) + b(h->d_parts.cap, 4) +
-           b(h->d_recs.cap, sizeof(PwppPatchRec)) + b(h->d_cls_start.cap, 4) + b(h->d_cls_list.cap, 2) + b(h->d_centers.cap, 4) +
-           b(h->d_normals.cap, 4) + b(h->d_xyz.cap, 4) + b(h->d_hist_stream.cap, 8) + b(h->d_hist_fresh.cap, 8) + b(h->d_hist_snap.cap, 8);
+           b(h->d_cls_start.cap, 4) + b(h->d_cap_off.cap, 4) + b(h->d_bin_max.cap, 4) + b(h->d_cls_list.cap, 2) +
+           b(h->d_recs.cap, sizeof(PwppPatchRec)) + b(h->d_centers.cap, 4) + b(h->d_normals.cap, 4) + b(h->d_results.cap, sizeof(PwppFrameResult)) +
+           b(h->d_xyz.cap, 4) + b(h->d_dbg.cap, 8) + b(h->d_st_stream.cap, sizeof(PwppStateScalar)) + b(h->d_st_fresh.cap, sizeof(PwppStateScalar)) +
+           b(h->d_st_snap.cap, sizeof(PwppStateScalar)) + b(h->d_hist_stream.cap, 8) + b(h->d_hist_fresh.cap, 8) + b(h->d_hist_snap.cap, 8) +
+           b(h->d_pl_stream.cap, sizeof(PwppPlaneState)) + b(h->d_pl_fresh.cap, sizeof(PwppPlaneState)) + b(h->d_pl_snap.cap, sizeof(PwppPlaneState));
 }
 
 int pwpp_trim_workspace(pwpp_handle *h) {
@@ -1596,6 +1631,9 @@ int pwpp_trim_workspace(pwpp_handle *h) {
     int rc = use_device(h);
     if (rc) return rc;
     if ((rc = finish_pending(h))) return rc;
+    // everything whose size follows the batch: inputs, bin-ordered planes, lists, per-frame tables and records, the state of
+    // FRESH frames and the snapshots of a one-pass batch.  What stays: the streams' state (thresholds, histories, plane
+    // members), the per-handle tables (origins, boxes, segment table, largest counts) and 512 bytes of timing probes.
     h->d_in.release();
     h->d_codes.release();
     h->d_sorted_z.release();
@@ -1606,7 +1644,23 @@ int pwpp_trim_workspace(pwpp_handle *h) {
     h->d_ord_a.release();
     h->d_ord_b.release();
     h->d_xyz.release();
-    h->have_results = false;  // the index lists lived in d_out
+    h->d_frames.release();
+    h->d_frames_probe.release();
+    h->d_bins.release();
+    h->d_parts.release();
+    h->d_recs.release();
+    h->d_cls_start.release();
+    h->d_cls_list.release();
+    h->d_centers.release();
+    h->d_normals.release();
+    h->d_results.release();
+    h->d_st_fresh.release();
+    h->d_hist_fresh.release();
+    h->d_pl_fresh.release();
+    h->d_st_snap.release();
+    h->d_hist_snap.release();
+    h->d_pl_snap.release();
+    h->have_results = false;  // the index lists lived in d_out, the records in d_recs
     h->descs_on_device.clear();
     return PWPP_OK;
 }

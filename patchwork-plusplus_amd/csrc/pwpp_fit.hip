@@ -471,7 +471,7 @@ __device__ __forceinline__ unsigned lane_stage_accum(const ChunkPts &cp, int kin
     // and cost the kernels 40-110 spilled registers)
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
-        if ((plane_s(tx, ty, tz, cp.x[k], cp.y[k], cp.z[k]) < T) & (k_off<G>(k) < cp.rem)) {  // (a branch on purpose: a seed pass includes about half of the points, an R-GPF round ~60 %)
+        if ((int)(plane_s(tx, ty, tz, cp.x[k], cp.y[k], cp.z[k]) < T) & (int)(k_off<G>(k) < cp.rem)) {  // (a branch on purpose: a seed pass includes about half of the points, an R-GPF round ~60 %)
             gmask |= 1u << k;
             m.add_uncounted(cp.x[k], cp.y[k], cp.z[k], scale, org);
         }
@@ -1032,8 +1032,24 @@ struct W64Patch {
         } thr;
     } u;
 };
+// The state machine of a patch (what its owner lane carries from stage to stage).  In the kernels with 64-lane rows it
+// lives in LDS, not in registers: only PW = 2-8 lanes own a patch, but a register is 64 lanes wide, and the ~40 registers
+// of this state were what the points phase lacked to keep a second chunk in flight (182 spilled registers with the
+// prefetch, 8 without).  The 16-lane kernels (64 owners per wave, LDS full) keep it in registers.
+struct W64Owner {
+    PlaneFit pl;
+    double lpr;
+    float z0;
+    int kind, it;
+    int lpr_valid, z0_set, fitted, hi_skipped, stash_valid;
+    int bin, zone;
+    unsigned n, n_hi;
+    float4 bb;
+    long long cnt;
+};
 template <int PW, bool DUAL, int MW>
 struct W64Shared {
+    W64Owner o[DUAL ? PW + 1 : 1];  // (slot PW: the lanes that own nothing; they only ever read kind == ST_DONE)
     W64Patch p[PW];
     long long mom[PW][MW];
     long long mom2[DUAL ? PW : 1][MW];  // dual seed pass: moments of the band; then the stashed seed totals of the R-GPF stage
@@ -1080,18 +1096,28 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
     const unsigned slot = cbeg + w + (unsigned)ln * nwaves;
     const bool alive = ln < PW && slot < cend;
     const PatchCtx pc = patch_ctx(Bt, f, slot, alive);
-    const int bin = pc.bin, zone = pc.zone;
-    const unsigned n = pc.n;
-    const float4 bb = Bt.bin_bbox[bin];
-    PlaneFit pl;
-    plane_clear(pl);
-    double lpr = 0.0;
-    bool lpr_valid = false, z0_set = false;
-    float z0 = 0.0f;
-    int kind = !alive ? ST_DONE : ((P.enable_RVPF != 0 && zone == 0) ? ST_VPF : ST_SEED);
-    int it = 0;
-    bool fitted = false;      // a plane of this patch's own exists
-    bool hi_skipped = false;  // the last points phase of this patch did not read the high part
+    constexpr bool OWN_LDS = G == 64;  // the owner state in LDS (W64Owner)
+    W64Owner own_regs;
+    const int oi = ln < PW ? ln : PW;
+#define O(fld) (*(OWN_LDS ? &sh.o[OWN_LDS ? oi : 0].fld : &own_regs.fld))
+    if (!OWN_LDS || ln <= PW) {
+        plane_clear(O(pl));
+        O(lpr) = 0.0;
+        O(z0) = 0.0f;
+        O(kind) = !alive ? ST_DONE : ((P.enable_RVPF != 0 && pc.zone == 0) ? ST_VPF : ST_SEED);
+        O(it) = 0;
+        O(lpr_valid) = 0;
+        O(z0_set) = 0;
+        O(fitted) = 0;      // a plane of this patch's own exists
+        O(hi_skipped) = 0;  // the last points phase of this patch did not read the high part
+        O(stash_valid) = 0;
+        O(bin) = pc.bin;
+        O(zone) = pc.zone;
+        O(n) = pc.n;
+        O(n_hi) = pc.n_hi;
+        O(bb) = Bt.bin_bbox[pc.bin];
+        O(cnt) = 0;
+    }
     // Dual seed pass (big bins, G == 64): the R-VPF round and the R-GPF seed stage of a zone-0 patch
     // select seeds from the same working set with the same lowest-point representative and two
     // thresholds (th_seeds_v / th_seeds, ref :480,:511).  The R-VPF pass therefore accumulates the
@@ -1100,14 +1126,13 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
     // stage takes its totals from the stash instead of streaming the patch again.
     constexpr bool DUAL = G == 64;
     const bool v_is_hi = P.th_seeds_v >= P.th_seeds;
-    bool stash_valid = false, dual_now = false;
     if (ln < PW) {
         sh.p[ln].off_lo = pc.off_lo;
         sh.p[ln].n_lo = pc.n_lo;
         sh.p[ln].off_hi = pc.off_hi;
         sh.p[ln].n_hi = pc.n_hi;
         sh.p[ln].kind = ST_DONE;
-        sh.p[ln].flags = zone == 0 ? 2 : 0;
+        sh.p[ln].flags = pc.zone == 0 ? 2 : 0;
         sh.p[ln].ox = pc.ox;
         sh.p[ln].oy = pc.oy;
         sh.p[ln].z0 = 0.0f;
@@ -1115,10 +1140,10 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
     wave_lds_sync();
 
     for (int guard = 0; guard < 4 * P.num_iter + 8; ++guard) {
-        if (!__any(kind != ST_DONE)) break;
+        if (!__any(O(kind) != ST_DONE)) break;
 
         // ---- A. lowest-point representative (ref :84-103) for the patches whose working set is new: z only
-        const bool need_lpr = (kind == ST_VPF || kind == ST_SEED) && !lpr_valid;
+        const bool need_lpr = (O(kind) == ST_VPF || O(kind) == ST_SEED) && !O(lpr_valid);
         const unsigned long long lpr_mask = __ballot(need_lpr);
         if (lpr_mask) {
             for (int sb = 0; sb < NSB; ++sb) {
@@ -1132,33 +1157,38 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
             }
             wave_lds_sync();
             if (need_lpr) {
-                lpr = sh.p[ln].u.lpr;
-                lpr_valid = true;
-                if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative
-                    z0 = fxp_z_origin(lpr);
-                    z0_set = true;
+                const double l = sh.p[ln].u.lpr;
+                O(lpr) = l;
+                O(lpr_valid) = 1;
+                if (!O(z0_set)) {  // the z origin of this patch's sums: its first lowest-point representative
+                    O(z0) = fxp_z_origin(l);
+                    O(z0_set) = 1;
                 }
             }
         }
 
         // ---- B. publish the stage of every patch
-        dual_now = DUAL && kind == ST_VPF;                      // this round's pass also fills the stash
-        const bool from_stash = DUAL && kind == ST_SEED && stash_valid;  // no pass: totals come from the stash
-        const int pub_kind = from_stash ? ST_DONE : kind;
+        const bool dual_now = DUAL && O(kind) == ST_VPF;                         // this round's pass also fills the stash
+        const bool from_stash = DUAL && O(kind) == ST_SEED && O(stash_valid) != 0;  // no pass: totals come from the stash
+        const int pub_kind = from_stash ? ST_DONE : O(kind);
         if (ln < PW) {
-            const bool last = kind == ST_ITER && it == P.num_iter - 1;
+            const int kind = O(kind);
+            const PlaneFit pl = O(pl);
+            const double lpr = O(lpr);
+            const bool last = kind == ST_ITER && O(it) == P.num_iter - 1;
             const double th = (kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds;
             const double thr_seed = lpr + (dual_now ? (v_is_hi ? P.th_seeds : P.th_seeds_v) : th);
             const double thr_band = lpr + (v_is_hi ? P.th_seeds_v : P.th_seeds);
+            const unsigned n_hi = O(n_hi);
             const bool use_hi = pub_kind != ST_DONE &&
-                                stage_needs_hi(kind, pc.n_hi, dual_now && thr_band > thr_seed ? thr_band : thr_seed, P.th_dist, pl, bb, zs);
-            if (pub_kind != ST_DONE) hi_skipped = !use_hi && pc.n_hi > 0u;
+                                stage_needs_hi(kind, n_hi, dual_now && thr_band > thr_seed ? thr_band : thr_seed, P.th_dist, pl, O(bb), zs);
+            if (pub_kind != ST_DONE) O(hi_skipped) = !use_hi && n_hi > 0u;
             sh.p[ln].kind = pub_kind;
-            sh.p[ln].flags = (zone == 0 ? 2 : 0) | (last ? 1 : 0) | (dual_now ? 4 : 0) | (use_hi ? 8 : 0);
+            sh.p[ln].flags = (O(zone) == 0 ? 2 : 0) | (last ? 1 : 0) | (dual_now ? 4 : 0) | (use_hi ? 8 : 0);
             sh.p[ln].nx = pl.nx;
             sh.p[ln].ny = pl.ny;
             sh.p[ln].nz = pl.nz;
-            sh.p[ln].z0 = z0;
+            sh.p[ln].z0 = O(z0);
             if (pub_kind != ST_DONE) {  // the pass's tests as float thresholds (lane_stage_accum)
                 sh.p[ln].u.thr.t = stage_threshold(kind, pl.d, P.th_dist, thr_seed);
                 sh.p[ln].u.thr.t2 = dual_now ? plane_test_threshold(0.0, thr_band) : 0.0f;
@@ -1189,12 +1219,13 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
             // instructions, and with 3-4 waves per SIMD the waits were not covered (k_fit_w64<64,2> moved its bytes at
             // 4.8 TB/s where a plain read stream reaches 6.3, tools/ubench/read_bw.hip).  The solve phase sets the
             // register allocation of these kernels, so the second chunk in flight costs the points phase nothing.
+            constexpr bool kPrefetch = PWPP_FIT_PREFETCH != 0 && G == 64;  // (the 16-lane kernels have no registers to spare: 76 spilled without it)
             const bool any_last = __any(last);
             ChunkPts cp;
             if (nchunk_max > 0u) load_chunk<G>(cp, pts, chunk_sel<G>(pts, 0u, use_hi, on));
             for (unsigned c = 0; c < nchunk_max; ++c) {
                 ChunkPts nx;
-                if (PWPP_FIT_PREFETCH && c + 1u < nchunk_max) load_chunk<G>(nx, pts, chunk_sel<G>(pts, c + 1u, use_hi, on));  // (wave-uniform)
+                if (kPrefetch && c + 1u < nchunk_max) load_chunk<G>(nx, pts, chunk_sel<G>(pts, c + 1u, use_hi, on));  // (wave-uniform)
                 int w[kPPT];  // (the cloud indices are consumed last in the iteration: fetched here, not a chunk ahead -- registers)
                 if (any_last) load_chunk_idx<G>(w, pts, chunk_sel<G>(pts, c, use_hi, last));
                 const unsigned gmask = lane_stage_accum<G>(cp, pp.kind, pp.u.thr.t, pp.nx, pp.ny, pp.nz, scale, org, m);
@@ -1223,7 +1254,7 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
                     }
                 }
                 if (c + 1u < nchunk_max) {
-                    if (PWPP_FIT_PREFETCH)
+                    if (kPrefetch)
                         cp = nx;
                     else
                         load_chunk<G>(cp, pts, chunk_sel<G>(pts, c + 1u, use_hi, on));
@@ -1262,7 +1293,7 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
         // ---- D. solve phase: lane p fits patch p (ref :47-75)
         long long cnt = 0;
         bool tiny = false;  // contract v3: a fit set of 1-3 points follows the reference's float arithmetic (tiny_fit_row)
-        if (kind != ST_DONE) {
+        if (O(kind) != ST_DONE) {
             const long long a0 = sh.mom[ln][0], b0 = DUAL ? sh.mom2[DUAL ? ln : 0][0] : 0;
             cnt = from_stash ? b0 : (dual_now ? (v_is_hi ? a0 + b0 : a0) : a0);
             tiny = cnt >= 1 && cnt <= 3;
@@ -1291,7 +1322,7 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
             }
             wave_lds_sync();
         }
-        if (kind != ST_DONE) {
+        if (O(kind) != ST_DONE) {
             float mean[3], c6[6];
             if (tiny) {
                 const float *src = reinterpret_cast<const float *>(&sh.mom[ln][1]);
@@ -1299,7 +1330,7 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
                 for (int k = 0; k < 3; ++k) mean[k] = src[k];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) c6[k] = src[3 + k];
-                if (dual_now) stash_valid = false;  // (its moments are gone: the R-GPF seed stage streams the patch itself)
+                if (dual_now) O(stash_valid) = 0;  // (its moments are gone: the R-GPF seed stage streams the patch itself)
             } else {
                 long long tot[MW];
 #pragma unroll
@@ -1313,31 +1344,35 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
                         sh.mom2[DUAL ? ln : 0][k] = v_is_hi ? a : ab;    // stash: the R-GPF seeds (th_seeds)
                         if (k == 0) stash_cnt = v_is_hi ? a : ab;
                     }
-                    stash_valid = !(stash_cnt >= 1 && stash_cnt <= 3);  // (1-3 seeds: that stage gathers the points, it needs its own pass)
+                    O(stash_valid) = !(stash_cnt >= 1 && stash_cnt <= 3);  // (1-3 seeds: that stage gathers the points, it needs its own pass)
                 }
                 if (cnt > 0) {
                     const long long s1[3] = {tot[1], tot[2], tot[3]};
                     __int128 s2[6];
 #pragma unroll
                     for (int k = 0; k < 6; ++k) s2[k] = G == 64 ? join_halves(tot[4 + k], tot[MW == 16 ? 10 + k : 4 + k]) : (__int128)tot[4 + k];
-                    mean_cov_from_totals(cnt, s1, s2, P.fxp_shift, pc.ox, pc.oy, z0, mean, c6);
+                    mean_cov_from_totals(cnt, s1, s2, P.fxp_shift, sh.p[ln].ox, sh.p[ln].oy, O(z0), mean, c6);
                 }
             }
             if (cnt > 0) {  // empty set: the previous plane stays (ref :49)
-                plane_from_mean_c6(mean, c6, Bt.debug, pl);
-                fitted = true;
+                PlaneFit npl;
+                plane_from_mean_c6(mean, c6, Bt.debug, npl);
+                O(pl) = npl;
+                O(fitted) = 1;
             }
-            if (needs_previous_plane(P, kind, zone, fitted)) {
-                mark_needs_previous_plane(Bt, f, Bt.recs + (size_t)f * P.num_bins + bin, n);
-                kind = ST_DONE;
+            if (needs_previous_plane(P, O(kind), O(zone), O(fitted) != 0)) {
+                mark_needs_previous_plane(Bt, f, Bt.recs + (size_t)f * P.num_bins + O(bin), O(n));
+                O(kind) = ST_DONE;
             }
+            O(cnt) = cnt;
         }
 
         // ---- E. R-VPF strip (ref :489-505) for the zone-0 patches whose plane came out vertical
-        const bool vertical = kind == ST_VPF && (double)pl.nz < P.uprightness_thr;
+        const bool vertical = O(kind) == ST_VPF && (double)O(pl).nz < P.uprightness_thr;
         const unsigned long long v_mask = __ballot(vertical);
         if (v_mask) {
             if (ln < PW) {
+                const PlaneFit pl = O(pl);
                 sh.p[ln].nx = pl.nx;
                 sh.p[ln].ny = pl.ny;
                 sh.p[ln].nz = pl.nz;
@@ -1346,7 +1381,7 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
                     sh.p[ln].u.thr.t = band.lo;
                     sh.p[ln].u.thr.t2 = band.hi;
                 }
-                sh.p[ln].flags = (sh.p[ln].flags & 0xef) | (it << 8);  // nothing removed yet; the round
+                sh.p[ln].flags = (sh.p[ln].flags & 0xef) | (O(it) << 8);  // nothing removed yet; the round
             }
             wave_lds_sync();
             for (int sb = 0; sb < NSB; ++sb) {
@@ -1378,30 +1413,35 @@ __global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, i
             }
             wave_lds_sync();
             if (vertical && (sh.p[ln].flags & 16)) {  // the working set changed
-                lpr_valid = false;
-                stash_valid = false;
+                O(lpr_valid) = 0;
+                O(stash_valid) = 0;
             }
         }
 
         // ---- what comes next for the patch of this lane
+        const int kind = O(kind);
         if (kind == ST_VPF) {
-            ++it;
+            const int it = O(it) + 1;
+            O(it) = it;
             if (!vertical || it >= P.num_iter) {  // ref :506 / loop end
-                kind = ST_SEED;
-                it = 0;
+                O(kind) = ST_SEED;
+                O(it) = 0;
             }
         } else if (kind == ST_SEED) {
-            kind = (cnt == 0 && P.enable_RVPF != 0 && zone != 0) ? ST_LAZY : ST_ITER;
+            O(kind) = (O(cnt) == 0 && P.enable_RVPF != 0 && O(zone) != 0) ? ST_LAZY : ST_ITER;
         } else if (kind == ST_LAZY) {
-            kind = ST_ITER;
+            O(kind) = ST_ITER;
         } else if (kind == ST_ITER) {
+            const int it = O(it);
             if (it == P.num_iter - 1) {
-                write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt, hi_skipped);
-                kind = ST_DONE;
+                write_record(Bt.recs + (size_t)f * P.num_bins + O(bin), O(pl), O(n), (unsigned)O(cnt), O(hi_skipped) != 0);
+                O(kind) = ST_DONE;
             }
-            ++it;
+            O(it) = it + 1;
         }
+        if (OWN_LDS) wave_lds_sync();  // (the owner state is LDS: ordered like every other hand-over between the phases)
     }
+#undef O
 }
 
 struct FitShared {
@@ -2306,8 +2346,9 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     const bool concurrent = aux != nullptr && !ev && B.fit_concurrent != 0;
     const bool fork = concurrent;
     if (fork) {  // every class only depends on K3
-        (void)hipEventRecord(aux_fork, stream);
-        (void)hipStreamWaitEvent(aux, aux_fork, 0);
+        hipError_t e = hipEventRecord(aux_fork, stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(aux, aux_fork, 0);
+        if (e != hipSuccess) return (int)e;  // (unordered classes would race with K3: nothing has been launched yet)
     }
     const char *p = plan;
     while (*p && slot < 5) {
@@ -2380,8 +2421,9 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
         hipLaunchKernelGGL(k_fit_stream, dim3(F, cap(n_lo)), dim3(kBlock), 0, stream, B, k_lo);
     }
     if (fork) {
-        (void)hipEventRecord(aux_join, aux);
-        (void)hipStreamWaitEvent(stream, aux_join, 0);
+        hipError_t e = hipEventRecord(aux_join, aux);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, aux_join, 0);
+        if (e != hipSuccess) return (int)e;  // (the caller synchronises every stream on an error: pwpp_capi.cpp)
     }
     if (ev) (void)hipEventRecord(ev[6], stream);
     return (int)hipGetLastError();

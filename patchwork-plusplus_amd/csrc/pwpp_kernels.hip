@@ -1770,6 +1770,7 @@ extern "C" int pwpp_launch_fixup(const PwppBatch *batch, hipStream_t stream);
 
 // K0: the per-launch zeroing (histogram / cursor slabs and the frame counters) in ONE dispatch; two
 // hipMemsetAsync calls were three fill kernels of the runtime, ~6 us apart on the queue
+namespace {
 __global__ __launch_bounds__(kBlock) void k_clear(uint4 *slabs, size_t n16, PwppFrameResult *results, int frames) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n16) slabs[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1779,6 +1780,7 @@ __global__ __launch_bounds__(kBlock) void k_clear(uint4 *slabs, size_t n16, Pwpp
         results[i] = z;
     }
 }
+}  // namespace
 
 // part_count (+ part_off, part_cursor on the two-pass path: adjacent slabs) and the result counters start at zero
 static void launch_clear(const PwppBatch &B, hipStream_t stream) {

@@ -24,10 +24,13 @@ def init(backend, device=None):
     return world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def barrier():
+def barrier(device=None):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if device is not None and dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[device.index])  # (RCCL: name the rank's own GPU, or the barrier guesses one from the rank)
+        else:
+            dist.barrier()
 
 
 def aggregate(elapsed_s, frames_done, device=None):
@@ -41,6 +44,18 @@ def aggregate(elapsed_s, frames_done, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(n, op=dist.ReduceOp.SUM)
     return float(t.item()), int(n.item())
+
+
+def gather_values(value, device=None):
+    """One float of every rank, in rank order (the per-GPU frames/s of BASELINE.json configs[3])."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [float(p.item()) for p in parts]
 
 
 def finalize():

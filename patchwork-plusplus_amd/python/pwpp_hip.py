@@ -381,7 +381,9 @@ class Handle:
 
     def fxp_origins(self):
         """(B, 2) float32: the origin of every bin's fixed-point plane-fit sums."""
-        out = np.zeros((4096, 2), np.float32)
+        nb = self._L.pwpp_get_fxp_origins(self._h, None, 0)  # size query
+        self._check(nb)
+        out = np.zeros((nb, 2), np.float32)
         b = self._L.pwpp_get_fxp_origins(self._h, _vp(out), out.shape[0])
         self._check(b)
         return out[:b].copy()

@@ -33,6 +33,11 @@ def test_exports_every_declared_symbol(lib):
     assert len(names) >= 25
     for n in sorted(names):
         assert hasattr(lib, n), "libpwpp_hip.so does not export %s" % n
+    # ... and nothing else: the library is built with -fvisibility=hidden and a version script (VERDICT r02 item 8:
+    # pwpp_launch_*, pwpp_debug_read and a kernel stub used to be visible)
+    out = subprocess.run(["nm", "-D", "--defined-only", pwpp_hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == names, (sorted(exported - names), sorted(names - exported))
 
 
 def test_params_default_mirror_reference(lib, oracle_built):

@@ -25,7 +25,8 @@ def _worker(rank, world, port, q):
     shard = pwpp_dist.shard_sources(6, 8, rank)
     pwpp_dist.barrier()
     elapsed, frames = pwpp_dist.aggregate(1.0 + rank, len(shard) * 3)
-    q.put((rank, shard, elapsed, frames))
+    per_rank = pwpp_dist.gather_values(100.0 * (rank + 1))  # every rank's own rate, in rank order
+    q.put((rank, shard, elapsed, frames, per_rank))
     pwpp_dist.finalize()
 
 
@@ -41,9 +42,10 @@ def test_two_rank_aggregation():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert out[0][1] == [0, 1, 2, 3, 4, 5, 0, 1] and out[1][1] == [1, 2, 3, 4, 5, 0, 1, 2]
-    for _, _, elapsed, frames in out:
+    for _, _, elapsed, frames, per_rank in out:
         assert elapsed == 2.0      # MAX over ranks
         assert frames == 48        # SUM over ranks: whole-job frames
+        assert per_rank == [100.0, 200.0]  # bench.py's "per_gpu" list
 
 
 def test_single_process_passthrough():
@@ -52,4 +54,5 @@ def test_single_process_passthrough():
                                     "patchwork-plusplus_amd", "python"))
     import pwpp_dist
     assert pwpp_dist.aggregate(0.5, 7) == (0.5, 7)
+    assert pwpp_dist.gather_values(3.5) == [3.5]
     assert pwpp_dist.shard_sources(6, 4, 5) == [5, 0, 1, 2]

@@ -1021,9 +1021,13 @@ def test_trim_workspace_and_options(kitti, oracle):
     h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
     ref = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(kitti[1])
     assert_frame_equal(h, 1, ref, kitti[1].shape[0])
+    before = h.workspace_bytes()
     h.trim_workspace()
+    # (every frames-proportional buffer goes -- what is left is the stream state and the per-handle tables)
+    assert before > 8 * kitti[0].shape[0] * 16 and h.workspace_bytes() < 2 << 20
     with pytest.raises(pwpp_hip.PwppError):
         h.ground_indices(0)  # the lists lived in the workspace
+    assert h.state(0).sensor_height == pwpp_hip.default_params().sensor_height  # the (untouched) stream state is still readable
     h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
     assert_frame_equal(h, 1, ref, kitti[1].shape[0])
     with pytest.raises(pwpp_hip.PwppError):
@@ -1228,14 +1232,28 @@ def test_bench_two_ranks_on_one_gpu():
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, PWPP_BENCH_SHARE_DEVICE="1", PWPP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--frames", "192", "--no-cpu-baseline", "--skip-latency"]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout  # rank 0 alone prints
-    d = json.loads(lines[0])
+
+    def run(frames, extra):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+               "--frames", str(frames), "--no-cpu-baseline", "--skip-latency"] + extra
+        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout  # rank 0 alone prints
+        return json.loads(lines[0])
+
+    d = run(192, [])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak"
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 192) < 1e-6 * 2 * 192  # whole-job frames per step / max time
     assert "cpu_baseline" not in d and d["config"]["frames_per_gpu"] == 192
+    # per-GPU and aggregate (BASELINE.json configs[3]): every rank's own rate, in rank order; the aggregate is total frames
+    # over the SLOWEST rank's time, so it cannot exceed the sum of the ranks' rates
+    assert [g["rank"] for g in d["per_gpu"]] == [0, 1] and all(g["frames_per_s"] > 0 for g in d["per_gpu"])
+    assert d["value"] <= sum(g["frames_per_s"] for g in d["per_gpu"]) * (1 + 1e-9)
+    assert d["selfcheck"] is True and d["parity_check"]["iou"] == 1.0 and d["parity_check"]["frames"] == 7
+    assert d["reference_order"]["ms_per_step"] > 0 and "ingest" not in d  # (the ingest leg is rank 0's at N = 1 only)
+    # the dense workload (configs[4]) through the same N > 1 path: 2 x 16 frames of ~486 k points, 36-sector CZM
+    d = run(16, ["--workload", "dense", "--skip-extras"])
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 16 and d["config"]["points_per_frame"] > 400000
+    assert len(d["per_gpu"]) == 2 and "parity_check" not in d
