@@ -83,8 +83,10 @@ float f_max(float a, float b) { return a < b ? b : a; }
 //   * Q_x(v) = rint(double(v) * 2^s - ox * 2^s), Q_y alike, Q_z(v) the same around z0 after
 //     clamping v to [z0 - ZR, z0 + ZR] in float (fmaxf, then fminf);
 //   * exact integer moments n, S1_a = sum Q_a, S2_ab = sum Q_a Q_b;
-//   * mean_a = float(double(S1_a) / double(n) * 2^-s + origin_a);
-//     cov_ab = float(double(n S2_ab - S1_a S1_b) / (double(n) double(n-1)) * 2^-2s), numerator exact.
+//   * mean_a = float(double(S1_a) * (1 / double(n)) * 2^-s + origin_a);
+//     cov_ab = float(double(n S2_ab - S1_a S1_b) * (1 / (double(n) double(n-1))) * 2^-2s), numerator exact,
+//     the two reciprocals formed once per fit in double (contract v3);
+//   * fit sets of 1-3 points: the reference's own float sums in (z, cloud index) order (estimate_plane below).
 // ---------------------------------------------------------------------------------
 constexpr int kFxpMaxShift = 21;
 constexpr double kFxpQMax = 67108864.0;  // 2^26
@@ -617,12 +619,14 @@ private:
                 }
             }
             const double inv = 1.0 / fxp.scale;
-            const double den = (double)n * (double)(n - 1);
+            // (contract v3: ONE reciprocal for the means and one for the covariance entries, both in double -- the product
+            // with a correctly rounded reciprocal is within an ulp of a double of the quotient, 2^-29 of a float ulp)
+            const double rn = 1.0 / (double)n, rd = 1.0 / ((double)n * (double)(n - 1));
             for (int a = 0; a < 3; ++a) {
-                mean[a] = (float)(((double)s1[a] / (double)n) * inv + org[a]);
+                mean[a] = (float)(((double)s1[a] * rn) * inv + org[a]);
                 for (int b = 0; b < 3; ++b) {
                     const __int128 num = (__int128)n * s2[a * 3 + b] - (__int128)s1[a] * (__int128)s1[b];
-                    cov[a * 3 + b] = (float)(((double)num / den) * (inv * inv));
+                    cov[a * 3 + b] = (float)(((double)num * rd) * (inv * inv));
                 }
             }
         }

@@ -585,7 +585,7 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
         // with the fit plan of the WHOLE batch (the machine is shared, not split).
         int R = h->overlap_ranges < 2 ? 2 : h->overlap_ranges;
         while (R > 2 && frames / R < 64) --R;
-        static const char *kBigPlan = "W16:1023,W64.2:65535";
+        static const char *kBigPlan = "W16:1023,W64.4:65535";  // (four big bins per wave: +2 % over two in interleaved end-to-end runs, profiles/r03_*)
         const double eff = (double)frames * (double)h->max_n / 125000.0;
         if (!bt.fit_plan && eff > 640.0) bt.fit_plan = kBigPlan;
         std::vector<int> first((size_t)R + 1, 0);

@@ -304,8 +304,8 @@ struct Moments {
 
 // ------------------------------------------------------------------------------------------
 // plane of ref :47-75 from the exact integer moments of a point set:
-//   mean_a = float( (S1_a / n) * 2^-s + origin_a )
-//   cov_ab = float( ((n*S2_ab - S1_a*S1_b) / (n*(n-1))) * 2^-2s )     numerator exact in 128 bits
+//   mean_a = float( (S1_a * (1/n)) * 2^-s + origin_a )
+//   cov_ab = float( ((n*S2_ab - S1_a*S1_b) * (1/(n*(n-1)))) * 2^-2s )     numerator exact in 128 bits; both reciprocals in double
 // then Eigen's JacobiSVD on the float covariance, normal = U.col(2) flipped to z >= 0 (:66-68),
 // d = -(normal . mean) as a float dot product widened to double (:74).
 // ------------------------------------------------------------------------------------------
@@ -340,12 +340,18 @@ __device__ __forceinline__ void plane_from_cov(const float mean[3], const float 
 }
 
 // output o of the moments -> (mean, covariance) step: o = 0..2 mean[o], o = 3..8 cov of the pair (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
-__device__ __forceinline__ float moment_output(int o, long long n, const long long s1[3], const __int128 s2[6], int shift, const double org[3]) {
+//   mean_a = float( S1_a * (1/n) * 2^-s + origin_a )                 cov_ab = float( (n*S2_ab - S1_a*S1_b) * (1/(n*(n-1))) * 2^-2s )
+// with the two reciprocals formed ONCE per fit in double (contract v3: nine IEEE double divisions were 270 of a solve's
+// 2 100 instructions; a product with the correctly rounded reciprocal differs from the quotient by at most one ulp of a
+// double, 2^-29 of a float ulp, before the single rounding to float).  rn = 1/n, rd = 1/(n*(n-1)) (n = 1: 1/0 = inf, and
+// 0 * inf = NaN as the reference's 0/0).
+__device__ __forceinline__ float moment_output(int o, long long n, const long long s1[3], const __int128 s2[6], int shift, const double org[3],
+                                               double rn, double rd) {
     const double inv = __longlong_as_double((long long)(1023 - shift) << 52);  // 2^-shift, exactly what 1.0 / (1 << shift) gives, without the division
     if (o < 3) {
         const long long v = o == 0 ? s1[0] : (o == 1 ? s1[1] : s1[2]);
         const double g = o == 0 ? org[0] : (o == 1 ? org[1] : org[2]);
-        return (float)(((double)v / (double)n) * inv + g);
+        return (float)(((double)v * rn) * inv + g);
     }
     const int k = o - 3;  // pair index
     const int a = k < 3 ? 0 : (k < 5 ? 1 : 2), b = k < 3 ? k : (k < 5 ? k - 2 : 2);
@@ -354,18 +360,23 @@ __device__ __forceinline__ float moment_output(int o, long long n, const long lo
 #pragma unroll
     for (int q = 1; q < 6; ++q) m2 = k == q ? s2[q] : m2;
     const __int128 num = (__int128)n * m2 - (__int128)sa * (__int128)sb;
-    const double den = (double)n * (double)(n - 1);
-    return (float)((i128_to_double(num) / den) * (inv * inv));
+    return (float)((i128_to_double(num) * rd) * (inv * inv));
+}
+__device__ __forceinline__ void fit_reciprocals(long long n, double &rn, double &rd) {
+    rn = 1.0 / (double)n;
+    rd = 1.0 / ((double)n * (double)(n - 1));
 }
 
 // the moments -> (mean, covariance) step alone: mean[3] and the six distinct covariance entries (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
 __device__ __forceinline__ void mean_cov_from_totals(long long n, const long long s1[3], const __int128 s2[6], int shift,
                                                      float ox, float oy, float z0, float mean[3], float c6[6]) {
     const double org[3] = {(double)ox, (double)oy, (double)z0};
+    double rn, rd;
+    fit_reciprocals(n, rn, rd);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) mean[a] = moment_output(a, n, s1, s2, shift, org);
+    for (int a = 0; a < 3; ++a) mean[a] = moment_output(a, n, s1, s2, shift, org, rn, rd);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) c6[k] = moment_output(3 + k, n, s1, s2, shift, org);
+    for (int k = 0; k < 6; ++k) c6[k] = moment_output(3 + k, n, s1, s2, shift, org, rn, rd);
 }
 __device__ __forceinline__ void plane_from_mean_c6(const float mean[3], const float c6[6], int debug, PlaneFit &out) {
     const int map[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
@@ -429,7 +440,9 @@ __device__ __forceinline__ void mean_cov_from_totals_uniform(long long n, const 
                                                              float ox, float oy, float z0, float mean[3], float c6[6]) {
     const double org[3] = {(double)ox, (double)oy, (double)z0};
     const int o = lane_id() & 15;
-    const float mine = moment_output(o < 9 ? o : 0, n, s1, s2, shift, org);
+    double rn, rd;
+    fit_reciprocals(n, rn, rd);
+    const float mine = moment_output(o < 9 ? o : 0, n, s1, s2, shift, org, rn, rd);
 #pragma unroll
     for (int a = 0; a < 3; ++a) mean[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), a));
 #pragma unroll

@@ -41,6 +41,9 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kPPT = 8;  // points per lane held in registers
+#ifndef PWPP_W64_OCC
+#define PWPP_W64_OCC 3  // waves per SIMD the 64-lane fit kernel is compiled for
+#endif
 #ifndef PWPP_FIT_PREFETCH
 #define PWPP_FIT_PREFETCH 0
 #endif
@@ -1066,7 +1069,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // Moments per patch in LDS: rows of 16 lanes only see patches below 2048 points, whose ten totals fit
 // int64; 64-lane rows leave sixteen values (second moments as 32-bit halves, Row<64>::reduce16_scatter).
 template <int G, int PW>
-__global__ __launch_bounds__(64, G == 64 ? 3 : 4) void k_fit_w64(PwppBatch Bt, int b_lo, int b_hi) {
+__global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(PwppBatch Bt, int b_lo, int b_hi) {
     // ONE WAVE PER WORKGROUP: the waves never talk to each other, and a workgroup of four only starts when a CU has
     // room for all four at once -- with waves of very different lifetimes the slots of the early finishers stood empty
     // (27 % of the wave slots of k_fit_w64<64,2>, profiles/).
@@ -2295,7 +2298,7 @@ extern "C" int pwpp_launch_fixup(const PwppBatch *batch, hipStream_t stream) {
 }
 
 // launches of K4; ev (optional) = 7 events recorded around up to six launches
-#define PWPP_DEFAULT_FIT_PLAN "W16:1023,W64.2:65535"
+#define PWPP_DEFAULT_FIT_PLAN "W16:1023,W64.4:65535"
 #define PWPP_LATENCY_FIT_PLAN "H64:1023"
 // `aux` (optional): a second stream + two events, for the fit_concurrent option (classes of a plan side by side).
 extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
