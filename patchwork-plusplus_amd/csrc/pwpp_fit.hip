@@ -597,41 +597,39 @@ __device__ double srow_lpr(const PatchRef &pts, bool need, bool use_cutoff, doub
     const unsigned INF = 0xFFFFFFFFu;
     unsigned k0 = INF, k1 = INF, k2 = INF, k3 = INF, dropped = INF;
     int elig = 0;
-    auto rank_chunk = [&](const PartSel &sel) {
+    // (the pass is a pure latency chain -- eight loads, ~100 instructions -- so the next chunk's z values are requested
+    // before this chunk's are ranked: eight registers, in a phase that is far from the kernels' register peak)
+    auto rank_part = [&](unsigned off, unsigned n, unsigned nchunks) {
+        PartSel sel;
+        sel.off = off;
+        sel.n = n;
+        sel.c = 0u;
         ChunkZ cp;
-        load_chunk_z<G>(cp, pts, sel);
-        const unsigned act = chunk_act_z<G>(cp);
+        if (nchunks > 0u) load_chunk_z<G>(cp, pts, sel);
+        for (unsigned c = 0; c < nchunks; ++c) {
+            ChunkZ nx;
+            sel.c = c + 1u;
+            if (c + 1u < nchunks) load_chunk_z<G>(nx, pts, sel);
+            const unsigned act = chunk_act_z<G>(cp);
 #pragma unroll
-        for (int k = 0; k < kPPT; ++k) {
-            const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.z[k] < cutoff);
-            unsigned x = e ? z_key(cp.z[k]) : INF;
-            ce(k0, x);
-            ce(k1, x);
-            ce(k2, x);
-            ce(k3, x);
-            dropped = x < dropped ? x : dropped;
-            elig += e ? 1 : 0;
+            for (int k = 0; k < kPPT; ++k) {
+                const bool e = (act >> k & 1u) && !(use_cutoff && (double)cp.z[k] < cutoff);
+                unsigned x = e ? z_key(cp.z[k]) : INF;
+                ce(k0, x);
+                ce(k1, x);
+                ce(k2, x);
+                ce(k3, x);
+                dropped = x < dropped ? x : dropped;
+                elig += e ? 1 : 0;
+            }
+            if (c + 1u < nchunks) cp = nx;
         }
     };
-    const unsigned nc_lo = wave_max_u32(need ? part_chunks<G>(pts.n_lo) : 0u);
-    for (unsigned c = 0; c < nc_lo; ++c) {
-        PartSel sel;
-        sel.off = pts.off_lo;
-        sel.n = need ? pts.n_lo : 0u;
-        sel.c = c;
-        rank_chunk(sel);
-    }
+    rank_part(pts.off_lo, need ? pts.n_lo : 0u, wave_max_u32(need ? part_chunks<G>(pts.n_lo) : 0u));
     int total = Row<G>::sum_i32(elig);
     const bool use_hi = need && pts.n_hi > 0u && total < num_lpr;  // row-uniform
     if (__any(use_hi)) {
-        const unsigned nc_hi = wave_max_u32(use_hi ? part_chunks<G>(pts.n_hi) : 0u);
-        for (unsigned c = 0; c < nc_hi; ++c) {
-            PartSel sel;
-            sel.off = pts.off_hi;
-            sel.n = use_hi ? pts.n_hi : 0u;
-            sel.c = c;
-            rank_chunk(sel);
-        }
+        rank_part(pts.off_hi, use_hi ? pts.n_hi : 0u, wave_max_u32(use_hi ? part_chunks<G>(pts.n_hi) : 0u));
         total = Row<G>::sum_i32(elig);
     }
     const int keff = total < num_lpr ? total : num_lpr;  // row-uniform
