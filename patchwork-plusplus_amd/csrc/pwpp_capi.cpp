@@ -122,6 +122,7 @@ struct pwpp_handle {
     bool fit_concurrent = false;
     bool no_one_pass = false;
     int one_pass_min_frames = 5;
+    int one_pass_min_fresh = 1;      // ... and for batches of FRESH frames (no stream state to snapshot: a single frame already gains, 118 -> 107 us)
     double one_pass_scale = 4.0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     hipEvent_t ev_k[PWPP_NUM_KERNELS + 1] = {};
@@ -867,7 +868,7 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
     if (const char *e = std::getenv("PWPP_FIT_PLAN")) h->fit_plan = e;
     h->fit_concurrent = std::getenv("PWPP_FIT_CONCURRENT") != nullptr;
     h->no_one_pass = std::getenv("PWPP_NO_ONE_PASS") != nullptr;
-    if (const char *e = std::getenv("PWPP_ONE_PASS_MIN_FRAMES")) h->one_pass_min_frames = std::atoi(e);
+    if (const char *e = std::getenv("PWPP_ONE_PASS_MIN_FRAMES")) h->one_pass_min_frames = h->one_pass_min_fresh = std::atoi(e);
     if (const char *e = std::getenv("PWPP_OVERLAP_RANGES")) h->overlap_ranges = std::atoi(e) < 2 ? 2 : std::atoi(e);
     if (const char *e = std::getenv("PWPP_OVERLAP_MODE")) h->overlap_mode = std::atoi(e) != 0;
     if (const char *e = std::getenv("PWPP_BIN_BLOCK")) h->bin_block = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 512 ? 512 : (std::atoi(e) == 1024 ? 1024 : 256));
@@ -1144,7 +1145,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     size_t bin_slots = compact_slots;
     if (h->one_pass_holdoff > 0) {
         --h->one_pass_holdoff;
-    } else if (!h->no_one_pass && frames >= h->one_pass_min_frames && max_n > 0) {
+    } else if (!h->no_one_pass && frames >= (mode == PWPP_MODE_FRESH ? h->one_pass_min_fresh : h->one_pass_min_frames) && max_n > 0) {
         if (2 * (int64_t)max_n < h->cap_max_n) {  // a much smaller sensor than the table was built for: start over
             HIPCHK(hipMemsetAsync(h->d_bin_max.p, 0, (size_t)NP * sizeof(uint32_t), h->stream));
             h->have_observation = false;
@@ -1566,7 +1567,7 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
     } else if (k == "one_pass_min_frames") {
         const int v = std::atoi(value);
         if (v < 1) return fail(PWPP_E_ARG, "one_pass_min_frames=%s: >= 1 expected", value);
-        h->one_pass_min_frames = v;
+        h->one_pass_min_frames = h->one_pass_min_fresh = v;
     } else if (k == "one_pass_scale") {
         const double v = std::atof(value);
         if (!(v > 0.0 && v <= 1024.0)) return fail(PWPP_E_ARG, "one_pass_scale=%s: a positive number up to 1024 expected", value);
