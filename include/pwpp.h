@@ -220,6 +220,12 @@ PWPP_API int pwpp_get_plane_state(pwpp_handle *h, int index, float out[10]);
  * only recognise; the host then runs k_fit_fixup + the GLE and list kernels for that frame.  It takes a lowest height
  * of -inf, one beyond 1e15 m, or num_lpr = 0 -- no real scan; the count exists for tests. */
 PWPP_API int64_t pwpp_get_fixed_up_frames(pwpp_handle *h);
+/* Frames this handle has seen in which the FINAL ground set of some patch held a height outside z0 +- 2^(26-s) m (32 m with
+ * the default CZM), i.e. a fit of 4+ points whose z coordinates were clamped before they were quantised (see
+ * pwpp_get_fxp_origins): that patch's plane is the plane of the clamped heights, not the reference's.  No ground patch is
+ * that tall; a steep facade or cliff filling a bin can be (it is rejected as "not upright" either way with the default
+ * parameters).  0 on every scan of the test suite. */
+PWPP_API int64_t pwpp_get_clamped_frames(pwpp_handle *h);
 /* Host only (no device needed): shift and per-bin origins {ox, oy} of the fixed-point plane-fit sums a handle created with
  * these parameters would use (= pwpp_get_fxp_shift / pwpp_get_fxp_origins of that handle).  The CPU tests compare them with
  * the restatement's for many CZM shapes.  Returns the number of bins; shift / out_xy may be NULL. */

@@ -104,7 +104,8 @@ struct PwppFrameResult {
     int32_t hist_state;  // (entries of the fullest A-GLE history after this frame << 1) | a push found its slab full
     int32_t overflow;  // bit 0: one-pass binning: some bin of this frame outgrew its segment (the batch is redone on the two-pass
                        // path); bit 1: some patch of the frame needs the plane fitted before it (PwppPatchRec.valid bit 2): K5 and K6
-                       // leave the frame alone and the host runs k_fit_fixup + K5 + K6 for it when the batch lands
+                       // leave the frame alone and the host runs k_fit_fixup + K5 + K6 for it when the batch lands; bit 2: the final
+                       // ground set of some patch held a height outside z0 +- ZR (clamped before it was quantised: pwpp_get_clamped_frames)
 };
 
 // everything a launch needs, by value in the kernarg segment

@@ -511,6 +511,17 @@ __device__ __forceinline__ unsigned lane_strip(const ChunkPts &cp, bool on, floa
     return hit;
 }
 
+// Did a height of the FINAL ground set of a patch lie outside z0 +- ZR (its quantised value was clamped, Moments)?  Checked in
+// the pass that writes the split only; the frame is flagged (PwppFrameResult.overflow bit 2, pwpp_get_clamped_frames): the
+// plane of such a patch -- more than 32 m tall with the default CZM -- is the plane of the clamped heights (include/pwpp.h).
+__device__ __forceinline__ bool chunk_clamped(const ChunkPts &cp, unsigned gm, const FxpOrg &org) {
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) hit = hit || ((gm >> k & 1u) && !(cp.z[k] >= org.zlo && cp.z[k] <= org.zhi));
+    return hit;
+}
+__device__ __forceinline__ void flag_clamped(const PwppBatch &Bt, int f) { atomicOr((unsigned *)&Bt.results[f].overflow, 4u); }
+
 // Contract v3 (pwpp_common.hpp, mean_cov_tiny): a fit set of one, two or three points follows the reference's own float
 // arithmetic, which needs the POINTS, not their moments.  The pass that found so few members is repeated here for the
 // row's patch with the same test on the same data (both parts: skipping the high part is only ever an optimisation),
@@ -902,6 +913,7 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
             if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                 const unsigned gm = last ? gmask : 0u;
                 const unsigned ngm = last ? (chunk_valid_bits<G>(cp.rem) & ~gmask) : 0u;
+                if (__any(chunk_clamped(cp, gm, org)) && lane_id() == 0) flag_clamped(Bt, f);
                 unsigned tg, tn;
                 unsigned bg = run_g + Row<G>::excl_scan((unsigned)__popc(gm), tg);
                 unsigned bn = run_n + Row<G>::excl_scan((unsigned)__popc(ngm), tn);
@@ -1241,6 +1253,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(Pwpp
                 if (any_last) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                     const unsigned gm = last ? gmask : 0u;
                     const unsigned ngm = last ? (chunk_valid_bits<G>(cp.rem) & ~gmask) : 0u;
+                    if (__any(chunk_clamped(cp, gm, org)) && ln == 0) flag_clamped(Bt, f);
                     unsigned tg, tn;
                     unsigned bg = run_g + Row<G>::excl_scan((unsigned)__popc(gm), tg);
                     unsigned bn = run_n + Row<G>::excl_scan((unsigned)__popc(ngm), tn);
@@ -1896,6 +1909,7 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
             }
             if (last) {  // the split is written BEFORE the plane is replaced (ref :529-541)
                 const unsigned ngm = chunk_valid_bits<64>(cp.rem) & ~gmask;
+                if (__any(chunk_clamped(cp, gmask, org)) && ln == 0) flag_clamped(Bt, f);
                 unsigned tg, tn;
                 unsigned bg = Row<64>::excl_scan((unsigned)__popc(gmask), tg);
                 unsigned bn = Row<64>::excl_scan((unsigned)__popc(ngm), tn);
@@ -2181,6 +2195,7 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
             }
             if (g) m.add(xy.x, xy.y, z, scale, org);
             if (last) {
+                if (__any(g && !(z >= org.zlo && z <= org.zhi)) && ln == 0) flag_clamped(Bt, f);
                 // regionwise_ground_ from the front, regionwise_nonground_ (R-VPF strips included,
                 // ref :500,532) from the back of this patch's slot range
                 const int idx = in ? pts.idx[sl] : 0;
@@ -2297,6 +2312,12 @@ extern "C" int pwpp_launch_fixup(const PwppBatch *batch, hipStream_t stream) {
 
 // launches of K4; ev (optional) = 7 events recorded around up to six launches
 #define PWPP_DEFAULT_FIT_PLAN "W16:1023,W64.4:65535"
+#define PWPP_DENSE_FIT_PLAN "W16:1023,W64.2:65535"
+// the plan of a big batch: four big bins per wave share a solve on scans of KITTI density; with several times more points
+// per bin (dense 128-beam frames) a wave's chain gets too long and two per wave win (profiles/r03_bench_dense_1024.json)
+extern "C" const char *pwpp_big_batch_plan(int max_n, int num_bins) {
+    return (double)max_n / (double)(num_bins > 0 ? num_bins : 1) < 500.0 ? PWPP_DEFAULT_FIT_PLAN : PWPP_DENSE_FIT_PLAN;
+}
 #define PWPP_LATENCY_FIT_PLAN "H64:1023"
 // `aux` (optional): a second stream + two events, for the fit_concurrent option (classes of a plan side by side).
 extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
@@ -2337,7 +2358,7 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
              : eff <= 320.0 ? "W16.16:1023,S64:65535"
              : eff <= 448.0 ? "W16.16:1023,W64.2:65535"
              : eff <= 640.0 ? "W16.32:1023,W64.2:65535"
-                            : PWPP_DEFAULT_FIT_PLAN;
+                            : pwpp_big_batch_plan(B.max_n, nb);
     }
     int k_lo = 0, slot = 0;
     unsigned n_lo = 1;

@@ -96,6 +96,8 @@ def load():
         L.pwpp_get_fxp_geometry.argtypes = [vp, vp, vp, ci]
         L.pwpp_get_fixed_up_frames.argtypes = [vp]
         L.pwpp_get_fixed_up_frames.restype = ctypes.c_int64
+        L.pwpp_get_clamped_frames.argtypes = [vp]
+        L.pwpp_get_clamped_frames.restype = ctypes.c_int64
         L.pwpp_get_plane_state.argtypes = [vp, ci, vp]
         L.pwpp_set_plane_state.argtypes = [vp, ci, vp]
         L.pwpp_get_device_view.argtypes = [vp, ctypes.POINTER(DeviceView)]
@@ -316,6 +318,10 @@ class Handle:
                 self.set_history(stream, w, r, ck["hist"][w][r])
         if "plane" in ck:
             self.set_plane_state(stream, ck["plane"])
+
+    def clamped_frames(self):
+        """Frames in which a patch's final ground set spanned more than z0 +- ZR vertically (pwpp_get_clamped_frames)."""
+        return int(self._L.pwpp_get_clamped_frames(self._h))
 
     def fixed_up_frames(self):
         """Frames finished by the serial fix-up kernel so far (pwpp_get_fixed_up_frames)."""

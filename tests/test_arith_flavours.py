@@ -188,3 +188,54 @@ def test_contract_is_no_further_from_exact_arithmetic_than_float_sums_on_adversa
         os.environ.pop("FUZZ_NO_ODD", None)
     assert fxp_frames <= f32_frames + 3, (frames, fxp_frames, f32_frames)
     assert fxp_frames <= frames // 4 and f32_frames <= frames // 4, (frames, fxp_frames, f32_frames)
+
+
+def steep_plane_cloud(base):
+    """`base` with one far bin rebuilt as a plane that rises 56 m over 7 m of range: every fit of that patch ends up with
+    (nearly) all of its points, more than 2 x 32 m apart vertically -- the z range of the fixed-point sums."""
+    rng = np.random.default_rng(3)
+    rb, ab = np.hypot(base[:, 0], base[:, 1]), np.degrees(np.arctan2(base[:, 1], base[:, 0])) % 360.0
+    base = base[~((rb > 40.0) & (ab >= 0.0) & (ab < 35.0))]
+    m = 3000
+    r, a = rng.uniform(51.5, 58.5, m), np.radians(rng.uniform(12.0, 21.0, m))
+    z = -1.7 + 8.0 * (r - 51.5) + rng.normal(0.0, 0.01, m)
+    wall = np.stack([r * np.cos(a), r * np.sin(a), z, rng.uniform(0.0, 1.0, m)], 1).astype(np.float32)
+    return np.ascontiguousarray(np.concatenate([base, wall]).astype(np.float32))
+
+
+def test_fit_sets_taller_than_the_z_range_of_the_sums(oracle_built, kitti):
+    """CPU: what the clamp of a fit's z coordinates to z0 +- 2^(26-s) m (32 m) does when it acts.  The steep patch gets the
+    plane of the clamped heights -- its normal is 0.05 off the arbiter's, its candidate count differs -- but it is not
+    upright in any arithmetic, so the index sets of the frame agree with the arbiter and with the float build; every other
+    patch of the frame is within the usual bounds.  (The GPU half checks that the library flags the frame.)"""
+    lib = oracle_built.restatement()
+    pts = steep_plane_cloud(kitti[2])
+    fx = ol.Estimator(lib, arith=ol.ARITH_FXP).run(pts)
+    ex = ol.Estimator(lib, arith=ol.ARITH_EXACT_F64).run(pts)
+    assert len(np.setxor1d(fx.ground_idx, ex.ground_idx)) == 0
+    tall = np.where(ex.records["mean"][:, 2] > 5.0)[0]
+    assert len(tall) == 1 and ex.records["decision"][tall[0]] == 1 and fx.records["decision"][tall[0]] == 1  # not upright
+    assert np.abs(fx.records["normal"][tall[0]] - ex.records["normal"][tall[0]]).max() > 1e-2       # the clamp acted ...
+    others = np.ones(len(ex.records), bool)
+    others[tall[0]] = False
+    m = compare(fx.ground_idx, fx.records[others], ex.ground_idx, ex.records[others], min_ground=4)
+    assert m["dc"] < CENTRE_TOL and m["excess"] <= 1.0                                               # ... there and nowhere else
+
+
+@pytest.mark.gpu
+def test_hip_flags_frames_with_clamped_fit_sets(oracle_built, kitti):
+    import pwpp_hip
+    from test_gpu_parity import assert_frame_equal
+    lib = oracle_built.restatement()
+    pts = steep_plane_cloud(kitti[2])
+    for frames in ([pts], [kitti[0], pts, kitti[1], pts, kitti[3], kitti[4], kitti[5], kitti[2]]):
+        for plan in ("", "W16:1023,W64.2:65535", "S64:65535", "B64:65535", "W16:255"):
+            h = pwpp_hip.Handle()
+            h.set_option("fit_plan", plan)
+            h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+            for i, f in enumerate(frames):
+                assert_frame_equal(h, i, ol.Estimator(lib, arith=ol.ARITH_FXP).run(f), f.shape[0])
+            assert h.clamped_frames() == sum(1 for f in frames if f is pts), plan
+    h = pwpp_hip.Handle()
+    h.estimate_ground_batch(kitti, mode=pwpp_hip.MODE_FRESH)
+    assert h.clamped_frames() == 0

@@ -3,6 +3,8 @@ declares, mirrors the reference's parameter defaults, validates arguments, and F
 without a GPU instead of falling back to a CPU path."""
 import ctypes
 import os
+
+import numpy as np
 import re
 import subprocess
 
@@ -280,3 +282,70 @@ def test_plane_distance_is_monotone_in_every_coordinate():
             point = dist(nrm[:, 0], nrm[:, 1], nrm[:, 2], d, pt[:, 0], pt[:, 1], pt[:, 2])
             ok = np.isfinite(corner) & np.isfinite(point)
             assert (point[ok] >= corner[ok]).all(), (scale, width)
+
+
+def test_float_threshold_of_the_plane_tests_is_exact():
+    """The streamed passes compare the float part s of the reference's distance expression with ONE float threshold T instead
+    of evaluating  double(s) + d < thr  per point (pwpp_common.hpp, plane_test_threshold).  Restated here step for step
+    (start at the real-number boundary, walk the ordered float keys, binary search as the backstop) and checked against
+    the definition -- T is the smallest float that fails -- on thresholds and offsets of every scale, the ends of the float
+    range, infinities and NaN, and by brute force over every float around T."""
+    rng = np.random.default_rng(11)
+
+    def key(f):
+        b = np.float32(f).view(np.uint32)
+        return int(~b & 0xffffffff) if b & 0x80000000 else int(b | 0x80000000)
+
+    def unkey(k):
+        k = np.uint32(k)
+        return (np.uint32(k & 0x7fffffff) if k & 0x80000000 else np.uint32(~k)).view(np.float32)
+
+    KMIN, KMAX = 0x007fffff, 0xff800000
+    assert unkey(KMIN) == -np.inf and unkey(KMAX) == np.inf and key(-0.0) + 1 == key(0.0)
+
+    with np.errstate(invalid="ignore", over="ignore"):  # (inf - inf, inf + -inf: NaN on purpose)
+        def passes(k, d, thr):
+            return bool(np.float64(unkey(k)) + d < thr)
+
+        def threshold(d, thr):
+            if not passes(KMIN, d, thr):
+                return KMIN
+            t = np.float32(thr - d)
+            k = key(t) if t == t else KMAX
+            k = min(max(k, KMIN), KMAX)
+            for _ in range(3):
+                if k < KMAX and passes(k, d, thr):
+                    k += 1
+            for _ in range(3):
+                if k > KMIN and not passes(k - 1, d, thr):
+                    k -= 1
+            if passes(k, d, thr) or not passes(k - 1, d, thr):
+                lo, hi = KMIN, KMAX
+                while hi - lo > 1:
+                    mid = lo + ((hi - lo) >> 1)
+                    if passes(mid, d, thr):
+                        lo = mid
+                    else:
+                        hi = mid
+                k = hi
+            return k
+
+        cases = [(0.0, 0.125), (1.723, 0.125), (-1.723, 0.125), (0.0, -1.6), (1e-30, 1e-30), (3e38, 1.0), (-3e38, 1.0), (0.0, 3.5e38),
+                 (0.0, -3.5e38), (np.inf, 1.0), (-np.inf, 1.0), (np.nan, 1.0), (1.0, np.nan), (1.0, np.inf), (1.0, -np.inf), (0.0, 0.0),
+                 (1e-320, 1e-320), (2.0 ** 60, 2.0 ** 60 + 4096.0)]
+        for _ in range(3000):
+            s = 10.0 ** rng.uniform(-12, 12)
+            cases.append((float(rng.normal() * s), float(rng.normal() * s * 10.0 ** rng.uniform(-3, 3))))
+        for d, thr in cases:
+            d, thr = np.float64(d), np.float64(thr)
+            k = threshold(d, thr)
+            T = unkey(k)
+            if k == KMIN:
+                assert not passes(KMIN, d, thr) or T == -np.inf
+            else:
+                assert not passes(k, d, thr) and passes(k - 1, d, thr), (d, thr, T)
+            # the test the kernels run (s < T) against the reference's expression, on the floats around T and a few others
+            for kk in list(range(max(KMIN, k - 6), min(KMAX, k + 6) + 1)) + [KMIN, KMAX, key(0.0), key(-0.0), key(1.0), key(-1.0)]:
+                sv = unkey(kk)
+                assert bool(sv < T) == passes(kk, d, thr), (d, thr, sv, T)
+            assert not (np.float32(np.nan) < T)
