@@ -94,8 +94,8 @@ struct PinnedBuf {
     }
 };
 
-const char *kKernelNames[PWPP_NUM_KERNELS] = {"k_czm_bin", "k_czm_scan", "k_czm_scatter", "k_fit_w64<16,64>", "k_fit_w64<64,2>",
-                                              "k_fit[2]", "k_fit[3]", "k_fit[4]", "k_fit_stream", "k_gle_tgr", "k_emit"};  // fit slots: default PWPP_FIT_PLAN
+const char *kKernelNames[PWPP_NUM_KERNELS] = {"k_czm_bin", "k_czm_scan", "k_czm_scatter", "k_fit_w64<16,64>", "k_fit_w64<64,p>",
+                                              "k_fit[2]", "k_fit[3]", "k_fit[4]", "k_fit_stream", "k_gle_tgr", "k_emit"};  // fit slots: the classes of the big-batch plan (p = 4 big bins per wave on scans of KITTI density, 2 on denser ones)
 
 std::atomic<bool> g_slot0_one_pass{false};  // diagnostic only (pwpp_kernel_name); handles on different threads may race to set it
 

@@ -319,7 +319,14 @@ struct PlaneFit {
 // (mean, covariance) -> plane: Eigen's JacobiSVD on the float covariance, normal = U.col(2) flipped to z >= 0, d
 __device__ __forceinline__ void plane_from_cov(const float mean[3], const float cov[9], int debug, PlaneFit &out) {
     float u[9], sv[3];
+#ifdef PWPP_ABLATE_NO_JACOBI  // (timing experiments only: a horizontal plane through the mean instead of the eigen-solve)
+    for (int k = 0; k < 9; ++k) u[k] = (k == 8) ? 1.0f : 0.0f;
+    sv[0] = cov[0];
+    sv[1] = cov[4];
+    sv[2] = cov[8] * 1e-3f;
+#else
     jacobi_svd3(cov, u, sv);
+#endif
     float nx = u[2], ny = u[5], nz = u[8];  // U.col(2), ref :66
     if (nz < 0) {                           // ref :68
         nx *= -1;
