@@ -168,7 +168,8 @@ struct pwpp_handle {
     DevBuf<unsigned long long> d_ord_a, d_ord_b;  // scratch of the reference-order mode (long sub-lists)
     int output_order = PWPP_ORDER_SCATTER;
     DevBuf<uint32_t> d_bins;   // 4 slabs of frames*(B+2): bin_count, bin_off, dst_a, dst_b
-    DevBuf<uint32_t> d_parts;  // 3 slabs of frames*(2B+2): part_count, part_off, part_cursor (pwpp_dev.h: a bin is stored in two parts)
+    DevBuf<uint32_t> d_parts;  // TWO copies of 3 slabs of frames*(2B+2): part_count, part_off, part_cursor (pwpp_dev.h: a bin is stored in two
+                               // parts); a call works on one copy while its K5 zeroes the other for the next call (PwppBatch.next_part_count)
     DevBuf<uint32_t> d_cls_start;  // frames * 8
     DevBuf<uint32_t> d_cap_off;    // 2B + 3 segment starts of the one-pass path (one segment per part)
     DevBuf<uint32_t> d_bin_max;    // 2B + 2: largest count of every part so far (k_czm_scan)
@@ -179,7 +180,12 @@ struct pwpp_handle {
     DevBuf<uint16_t> d_cls_list;   // frames * B
     DevBuf<PwppPatchRec> d_recs;
     DevBuf<float> d_centers, d_normals;
-    DevBuf<PwppFrameResult> d_results;
+    DevBuf<PwppFrameResult> d_results;  // two copies (see d_parts)
+    int counters_copy = 0;           // which copy of d_parts / d_results the call in flight (or the last one) works on
+    bool next_clean = false;         // the OTHER copy was zeroed by the last call's K5 ...
+    int next_clean_frames = 0, next_clean_slabs = 0;   // ... for a call of this many frames and slabs (1: one-pass, 3: two-pass)
+    const void *next_clean_parts = nullptr, *next_clean_results = nullptr;  // ... in these allocations
+    size_t next_clean_parts_cap = 0, next_clean_results_cap = 0;
     PinnedBuf<PwppFrameResult> h_results;
     DevBuf<float> d_xyz;  // gather scratch
     DevBuf<unsigned long long> d_dbg;  // timing probes (PWPP_DEBUG_FLAGS & 4)
@@ -446,6 +452,8 @@ int probe_histogram(pwpp_handle *h) {
     bt.num_frames = S;
     bt.max_n = max_n;
     bt.cap_off = nullptr;
+    h->next_clean = false;  // (the probe's own K0-K2 run on sample frames with their own frame count)
+    bt.next_part_count = nullptr;
     const int lrc = pwpp_launch_histogram(&bt, h->stream);
     if (lrc != 0) return fail(PWPP_E_HIP, "histogram probe failed: %s", hipGetErrorString((hipError_t)lrc));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -482,9 +490,15 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
     bt.bin_off = h->d_bins.p + slab;
     bt.dst_a = h->d_bins.p + 2 * slab;
     bt.dst_b = h->d_bins.p + 3 * slab;
-    bt.part_count = h->d_parts.p;
-    bt.part_off = h->d_parts.p + pslab;
-    bt.part_cursor = h->d_parts.p + 2 * pslab;
+    const size_t pcopy = 3 * pslab + 4;  // (+4: k_clear zeroes whole 16-byte words)
+    uint32_t *parts = h->d_parts.p + (size_t)h->counters_copy * pcopy;
+    bt.part_count = parts;
+    bt.part_off = parts + pslab;
+    bt.part_cursor = parts + 2 * pslab;
+    bt.next_part_count = h->d_parts.p + (size_t)(h->counters_copy ^ 1) * pcopy;
+    bt.next_results = h->d_results.p + (size_t)(h->counters_copy ^ 1) * (size_t)h->frames;
+    bt.next_slab_stride = (int64_t)pslab;
+    bt.next_slabs = 3;  // (launch_prepared narrows it to 1 for a one-pass batch)
     bt.cls_start = h->d_cls_start.p;
     bt.cls_list = h->d_cls_list.p;
     bt.sorted_z = h->d_sorted_z.p;
@@ -497,7 +511,7 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
     bt.out_idx = h->d_out.p;
     bt.centers = h->d_centers.p;
     bt.normals = h->d_normals.p;
-    bt.results = h->d_results.p;
+    bt.results = h->d_results.p + (size_t)h->counters_copy * (size_t)h->frames;
     bt.results_host = h->h_results.p;  // hipHostMalloc'ed: the same address on the device
     bt.dbg = h->d_dbg.p;
 
@@ -539,6 +553,8 @@ PwppBatch frame_range(const pwpp_handle *h, const PwppBatch &bt, int f0, int nf)
     v.normals += (size_t)f0 * B * 3;
     v.results += f0;
     v.results_host += f0;
+    v.next_part_count += (size_t)f0 * NP;  // (the other copy: same frame, same slab stride)
+    v.next_results += f0;
     return v;
 }
 
@@ -565,8 +581,18 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
         h->descs_dev_ptr = h->d_frames.p;
     }
 
+    // this call works on the other copy of the counters; if the last call's K5 zeroed exactly what this one needs, no
+    // clearing kernel runs in front of the binning
+    h->counters_copy ^= 1;
+    const int slabs = one_pass ? 1 : 3;
+    const bool pre_cleared = h->next_clean && h->next_clean_frames == frames && h->next_clean_slabs >= slabs &&
+                             h->next_clean_parts == h->d_parts.p && h->next_clean_results == h->d_results.p &&
+                             h->next_clean_parts_cap == h->d_parts.cap && h->next_clean_results_cap == h->d_results.cap;
+    h->next_clean = false;  // (set again below, once this call's K5 is on its way for every frame)
     PwppBatch bt;
     fill_batch(h, bt);
+    bt.next_slabs = slabs;
+    bt.no_clear = pre_cleared ? 1 : 0;
 
     bt.cap_off = one_pass ? h->d_cap_off.p : nullptr;
     HIPCHK(hipEventRecord(h->ev_begin, h->stream));
@@ -597,7 +623,7 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
             int f1 = r == R ? frames : (int)(((int64_t)frames * r / R + 7) / 8 * 8);
             first[(size_t)r] = f1 > frames ? frames : f1;
         }
-        lrc = pwpp_launch_clear(&bt, h->stream);
+        lrc = pre_cleared ? 0 : pwpp_launch_clear(&bt, h->stream);
         if (h->overlap_mode == 1) {
             // A software pipeline over the two streams: the MEMORY stream bins range r + 2 and then writes the lists of
             // range r, the FIT stream runs the plane fits (and K5) of range r + 1 meanwhile -- the streams never run the
@@ -667,6 +693,13 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
         return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     }
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
+    h->next_clean = true;  // every frame's K5 is enqueued: the other copy will be zero for a call of this shape
+    h->next_clean_frames = frames;
+    h->next_clean_slabs = slabs;
+    h->next_clean_parts = h->d_parts.p;
+    h->next_clean_results = h->d_results.p;
+    h->next_clean_parts_cap = h->d_parts.cap;
+    h->next_clean_results_cap = h->d_results.cap;
     if (one_pass)  // the bins' largest counts, for the segment sizes of the next batches (finish_pending)
         HIPCHK(hipMemcpyAsync(h->h_bin_max.p, h->d_bin_max.p, (size_t)NP * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     h->profile_pending = h->profiling;
@@ -1074,13 +1107,13 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
         if ((rc = h->d_ord_b.ensure(tp))) return rc;
     }
     if ((rc = h->d_bins.ensure((size_t)frames * NB * 4))) return rc;
-    if ((rc = h->d_parts.ensure((size_t)frames * NP * 3 + 4))) return rc;  // (+4: k_clear zeroes whole 16-byte words)
+    if ((rc = h->d_parts.ensure(2 * ((size_t)frames * NP * 3 + 4)))) return rc;  // two copies; (+4: k_clear zeroes whole 16-byte words)
     if ((rc = h->d_recs.ensure((size_t)frames * B))) return rc;
     if ((rc = h->d_cls_start.ensure((size_t)frames * PWPP_CLS_STRIDE))) return rc;
     if ((rc = h->d_cls_list.ensure((size_t)frames * B))) return rc;
     if ((rc = h->d_centers.ensure((size_t)frames * B * 3))) return rc;
     if ((rc = h->d_normals.ensure((size_t)frames * B * 3))) return rc;
-    if ((rc = h->d_results.ensure((size_t)frames))) return rc;
+    if ((rc = h->d_results.ensure(2 * (size_t)frames))) return rc;  // two copies
     if ((rc = h->d_dbg.ensure(64))) return rc;
     if ((rc = h->h_results.ensure((size_t)frames))) return rc;
     if (mode == PWPP_MODE_FRESH) {
@@ -1673,6 +1706,7 @@ int pwpp_trim_workspace(pwpp_handle *h) {
     h->d_hist_snap.release();
     h->d_pl_snap.release();
     h->have_results = false;  // the index lists lived in d_out, the records in d_recs
+    h->next_clean = false;    // (the counters' copies are gone with d_parts / d_results)
     h->descs_on_device.clear();
     return PWPP_OK;
 }

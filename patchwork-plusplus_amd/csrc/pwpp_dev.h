@@ -158,6 +158,13 @@ struct PwppBatch {
     int32_t fit_concurrent;      // option "fit_concurrent": the classes of a plan side by side on two streams
     int32_t emit_parts;          // waves per bin in k_emit (1..8, from the largest bin seen so far)
     int32_t bin_block;           // option "bin_block": threads per workgroup of k_czm_bin_scatter (256, 512, 1024; four points each)
+    // The counters a call starts from (part_count [+ part_off, part_cursor], results) exist TWICE; a call works on one copy
+    // and its K5 zeroes the frame's share of the OTHER copy, so that the next call of the same shape needs no clearing
+    // kernel in front of its binning (a single frame: k_clear and the dispatch gap behind it were 5-7 of 105 us).
+    uint32_t *next_part_count;   // the other copy's part_count slab, this batch's frames (null: nothing to prepare)
+    PwppFrameResult *next_results;
+    int64_t next_slab_stride;    // words from part_count to part_off / part_cursor in the other copy (= frames of the CALL x parts)
+    int32_t next_slabs;          // 1 (one-pass binning: counts only) or 3
 };
 
 #endif

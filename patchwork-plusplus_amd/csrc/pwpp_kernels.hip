@@ -638,7 +638,24 @@ __device__ void mean_stdev_lds(const double *v, int stride, int n, double &mean,
     stdev = sqrt(stdev);
 }
 
+// K5 prepares the NEXT call's counters (pwpp_dev.h: next_part_count): this frame's share of the other copy, zeroed by the
+// workgroup that finishes the frame anyway.  Nothing of the current call reads or writes that copy.
+__device__ __forceinline__ void clear_next_counters(const PwppBatch &Bt, int f, int nthreads) {
+    if (!Bt.next_part_count) return;
+    const int NP = PWPP_NUM_PARTS(Bt.P.num_bins);
+    for (int s = 0; s < Bt.next_slabs; ++s) {
+        uint32_t *dst = Bt.next_part_count + (int64_t)s * Bt.next_slab_stride + (size_t)f * NP;
+        for (int i = threadIdx.x; i < NP; i += nthreads) dst[i] = 0u;
+    }
+    if (threadIdx.x == 0) {
+        PwppFrameResult z;
+        z.n_ground = z.n_nonground = z.n_patches = z.n_rnr = z.n_oor = z.n_dropped = z.hist_state = z.overflow = 0;
+        Bt.next_results[f] = z;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_gle_tgr_seq(PwppBatch Bt) {
+    clear_next_counters(Bt, blockIdx.x, 64);
     __shared__ double s_ring_flat[PWPP_MAX_NEAR_BINS];
     __shared__ uint8_t s_dec[PWPP_MAX_BINS];
     const int f = blockIdx.x;
@@ -966,6 +983,7 @@ __device__ __forceinline__ void block_excl_scan(unsigned v[K], unsigned (*s_wave
 // stage instead of three; otherwise the tile lives in the retired prefix arrays (32 KB).
 template <bool LAT>
 __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
+    clear_next_counters(Bt, blockIdx.x, kBlock);
     __shared__ uint8_t s_dec[PWPP_MAX_BINS];
     __shared__ __attribute__((aligned(16))) unsigned s_e[4][PWPP_MAX_BINS + 1];   // exclusive prefixes: gmain, gtail, nmain, ntail;
                                                                                 // later the staging tile of the histories

@@ -12,7 +12,7 @@ def short(n): return n.split('::')[-1].split('(')[0][:22]
 # take the un-profiled phase: sequences starting with k_clear
 seqs=[];cur=[]
 for r in rows:
-    if 'k_clear' in r['Kernel_Name']:
+    if 'k_clear' in r['Kernel_Name'] or ('k_czm_bin' in r['Kernel_Name'] and cur and 'k_clear' not in cur[-1]['Kernel_Name']):
         if cur: seqs.append(cur)
         cur=[]
     cur.append(r)
