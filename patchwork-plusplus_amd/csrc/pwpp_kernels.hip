@@ -500,13 +500,16 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
         atomicAdd(&s_cnt[pwpp_size_bucket(n)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned run = 0;
-        for (int c = 0; c < PWPP_NUM_BUCKETS; ++c) {
-            s_start[c] = run;
-            run += s_cnt[c];
-        }
-        s_start[PWPP_NUM_BUCKETS] = run;
+    if (threadIdx.x < 64) {  // exclusive prefix over the 96 buckets by one wave, two buckets per lane (a serial loop of 96 LDS
+                             // round trips by one thread was 1.4 us of a single frame's chain)
+        static_assert(PWPP_NUM_BUCKETS <= 128, "two buckets per lane");
+        const int c0 = 2 * (int)threadIdx.x, c1 = c0 + 1;
+        const unsigned a = c0 < PWPP_NUM_BUCKETS ? s_cnt[c0] : 0u, b = c1 < PWPP_NUM_BUCKETS ? s_cnt[c1] : 0u;
+        const unsigned incl = wave_incl_scan(a + b);
+        const unsigned excl = incl - (a + b);
+        if (c0 < PWPP_NUM_BUCKETS) s_start[c0] = excl;
+        if (c1 < PWPP_NUM_BUCKETS) s_start[c1] = excl + a;
+        if (threadIdx.x == 63) s_start[PWPP_NUM_BUCKETS] = incl;
     }
     __syncthreads();
     for (int c = threadIdx.x; c <= PWPP_NUM_BUCKETS; c += kBlock) Bt.cls_start[(size_t)f * PWPP_CLS_STRIDE + c] = s_start[c];
