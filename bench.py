@@ -320,7 +320,10 @@ def main():
                                                  "workload on this build (tools/profile_r02.sh), not measured inside this run",
                                "algorithmic_bytes_per_launch": b_alg, "kernel_ms": dom_ms,
                                "pipeline_achieved": b_alg * args.steps / elapsed / 1e9,
-                               "pipeline_frac": b_alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}
+                               "pipeline_frac": b_alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                               # fps x B_alg against the 8 TB/s peak (above) and against what a read
+                               # stream reaches on this chip (6.29 TB/s in MI355X_MICROARCH.md; 6.3-6.45 measured: profiles/r03_read_bw.txt)
+                               "pipeline_frac_of_achievable": b_alg * args.steps / elapsed / 1e9 / 6290.0}
             out["kernel_ms"] = {k: v[0] / max(v[1], 1) for k, v in prof.items()}
         if world == 1 and not args.no_cpu_baseline:
             try:
