@@ -1257,3 +1257,60 @@ def test_bench_two_ranks_on_one_gpu():
     d = run(16, ["--workload", "dense", "--skip-extras"])
     assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 16 and d["config"]["points_per_frame"] > 400000
     assert len(d["per_gpu"]) == 2 and "parity_check" not in d
+
+
+def test_precleared_counters_under_changing_call_shapes(kitti, oracle):
+    """The counters a call starts from exist twice: a call's K5 zeroes the other copy for the next call, which then needs no
+    clearing kernel -- but only if that call has the same shape (frames, binning path, allocations).  One handle through
+    calls whose shape keeps changing: single fresh frames back to back (the pre-cleared path), batches of other sizes in
+    between, stream mode, a trimmed workspace, the two-pass path forced, a segment overflow with its redo, a frame that needs
+    the serial fix-up -- every result against the oracle."""
+    h = pwpp_hip.Handle()
+    refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(k) for k in kitti]
+
+    def fresh(idx):
+        h.estimate_ground_batch([kitti[i] for i in idx], mode=pwpp_hip.MODE_FRESH)
+        for j, i in enumerate(idx):
+            assert_frame_equal(h, j, refs[i], kitti[i].shape[0])
+
+    for i in (0, 1, 2):
+        fresh([i])                      # same shape three times: the second and third run without k_clear
+    fresh([3, 4, 5, 0, 1, 2, 3, 4])     # other frame count: cleared by the kernel again ...
+    fresh([5, 4, 3, 2, 1, 0, 5, 4])     # ... and pre-cleared
+    fresh([2])
+    h.trim_workspace()
+    fresh([1])
+    fresh([1])
+    h.set_option("one_pass", 0)         # two-pass binning: three slabs of counters instead of one
+    fresh([4])
+    fresh([4])
+    h.set_option("one_pass", 1)
+    fresh([0])
+    fresh([0])
+    # a stateful stream on the same handle in between (its own sequential oracle)
+    est = ol.Estimator(oracle, arith=ol.ARITH_FXP)
+    for i in (0, 1):
+        h.estimate_ground(kitti[i])
+        assert_frame_equal(h, 0, est.run(kitti[i]), kitti[i].shape[0], state_index=0)
+    fresh([3])
+    # a cloud that overflows its one-pass segments (70 % of the points in one wedge): redo on the other path, then on
+    rng = np.random.default_rng(9)
+    wedge = kitti[2].copy()
+    sel = rng.random(wedge.shape[0]) < 0.7
+    r = np.hypot(wedge[sel, 0], wedge[sel, 1])
+    a = rng.uniform(0.1, 0.27, sel.sum())
+    wedge[sel, 0] = (r * np.cos(a)).astype(np.float32)
+    wedge[sel, 1] = (r * np.sin(a)).astype(np.float32)
+    wref = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(wedge)
+    for _ in range(2):
+        h.estimate_ground_batch([wedge], mode=pwpp_hip.MODE_FRESH)
+        assert_frame_equal(h, 0, wref, wedge.shape[0])
+        fresh([5])
+    # a frame with a patch that starts from the plane fitted before it (k_fit_fixup runs K5 a second time for it)
+    odd = kitti[1].copy()
+    odd[:40, 2] = -np.inf
+    oref = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(odd)
+    for _ in range(2):
+        h.estimate_ground_batch([odd], mode=pwpp_hip.MODE_FRESH)
+        assert_frame_equal(h, 0, oref, odd.shape[0])
+    fresh([0])
