@@ -349,3 +349,19 @@ def test_float_threshold_of_the_plane_tests_is_exact():
                 sv = unkey(kk)
                 assert bool(sv < T) == passes(kk, d, thr), (d, thr, sv, T)
             assert not (np.float32(np.nan) < T)
+
+
+def test_field_blobs_must_be_float_aligned(lib):
+    """a PointCloud2 blob is read in place as float32 -- a data pointer off a 4-byte boundary is refused before
+    anything touches it (no handle, no GPU needed for the check)."""
+    buf = (ctypes.c_uint8 * 256)()
+    base = ctypes.addressof(buf)
+    base += (-base) % 16
+    n = (ctypes.c_int32 * 1)(4)
+    for off, want in ((1, -1), (2, -1), (3, -1)):
+        ptrs = (ctypes.c_void_p * 1)(base + off)
+        rc = lib.pwpp_estimate_ground_fields_batch(None, ptrs, n, 1, 16, 0, 4, 8, -1, 0, 0)
+        assert rc == want and b"aligned" in lib.pwpp_last_error()
+    ptrs = (ctypes.c_void_p * 1)(base)  # aligned: the call gets as far as the missing handle
+    assert lib.pwpp_estimate_ground_fields_batch(None, ptrs, n, 1, 16, 0, 4, 8, -1, 0, 0) == -1
+    assert b"aligned" not in lib.pwpp_last_error()

@@ -1011,6 +1011,17 @@ def test_checkpoint_and_restore_a_stream(kitti, oracle):
     for k in (4, 5, 0):
         b.estimate_ground(kitti[k])
         assert_frame_equal(b, 0, est.run(kitti[k]), kitti[k].shape[0], state_index=0)
+    # what a restore refuses: histories the reference could never hold -- non-finite entries; and a PointCloud2
+    # blob that does not start on a float boundary
+    before = b.history(0, 0, 0)
+    for bad in (np.nan, np.inf, -np.inf):
+        with pytest.raises(pwpp_hip.PwppError):
+            b.set_history(0, 0, 0, [0.5, bad, 0.25])
+    assert np.array_equal(b.history(0, 0, 0), before)  # (a refused call changes nothing)
+    blob = np.zeros(16 * 64 + 8, np.uint8)
+    off = (-blob.ctypes.data) % 4 + 1  # one byte past a 4-byte boundary
+    with pytest.raises(pwpp_hip.PwppError):
+        b.estimate_ground_fields(blob[off:off + 16 * 64], 64, 16, 0, 4, 8)
 
 
 def test_trim_workspace_and_options(kitti, oracle):
