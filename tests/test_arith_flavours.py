@@ -106,6 +106,15 @@ def test_hip_path_against_the_exact_arbiter_and_the_float_reference(oracle_built
         g, rec = h.ground_indices(0), h.patch_records(0)
         ex = ol.Estimator(lib, op, arith=ol.ARITH_EXACT_F64).run(pts)
         f32 = ol.Estimator(lib, op, arith=ol.ARITH_EIGEN_F32).run(pts)
+        # the arbiter and the float yardstick ARE the reference's own code: the restatement's flavours (which carry the
+        # per-patch records the comparison needs) must equal oracle/_ref's builds on every case, output order included
+        for arith, mine in ((ol.ARITH_EXACT_F64, ex), (ol.ARITH_EIGEN_F32, f32)):
+            rlib = ol.reference(arith)
+            if rlib is not None:
+                theirs = ol.Estimator(rlib, op, arith=arith).run(pts)
+                for fld in ("ground_idx", "nonground_idx", "centers", "normals"):
+                    if not np.array_equal(getattr(theirs, fld), getattr(mine, fld), equal_nan=True):
+                        fails.append((name, "restatement vs oracle/_ref", arith, fld))
         # Parameter sets that make fits of one, two or three points (bins of < 4 points let through; seeds picked around a
         # single lowest point, or within a few centimetres of the lowest ones).  Contract v3: such sets follow the
         # reference's own float arithmetic, which is determinate there -- so these cases are held to the FLOAT build
