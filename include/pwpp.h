@@ -320,6 +320,10 @@ PWPP_API int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *
  *                         16384 / 32768: force the fall-back paths of the lowest-point selection
  * Returns PWPP_E_ARG for an unknown name or a value out of range. */
 PWPP_API int pwpp_set_option(pwpp_handle *h, const char *name, const char *value);
+/* The 64 timing probes of the last call when "debug_flags" has bit 2 set (device-side timestamps along the fit chain of the
+ * largest patch, (code << 56) | 100 MHz ticks; slots 60-62: first start, last end, the patch's size): what tools/brows_chain.py
+ * prints.  PWPP_E_STATE if no call has run.  A measurement aid; results never depend on it. */
+PWPP_API int pwpp_debug_read(pwpp_handle *h, unsigned long long *out64);
 /* Frees everything whose size follows the batch (a handle that processed one large batch otherwise keeps it, e.g. 9.7 GB
  * after 1024 KITTI frames with one-pass binning): inputs staged from the host, the bin-ordered planes, the index lists,
  * every per-frame table and patch record, the state of PWPP_MODE_FRESH frames and the one-pass snapshots.  Kept: the

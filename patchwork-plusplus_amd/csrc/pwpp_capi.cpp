@@ -1740,7 +1740,7 @@ int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone) {
     return PWPP_OK;
 }
 
-/* not part of the public header: timing probes of the last call (PWPP_DEBUG_FLAGS & 4) */
+/* timing probes of the last call (PWPP_DEBUG_FLAGS & 4) */
 int pwpp_debug_read(pwpp_handle *h, unsigned long long *out64) {
     if (!h || !out64) return fail(PWPP_E_ARG, "null argument");
     int rc = use_device(h);
