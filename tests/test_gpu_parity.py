@@ -1325,3 +1325,18 @@ def test_precleared_counters_under_changing_call_shapes(kitti, oracle):
         h.estimate_ground_batch([odd], mode=pwpp_hip.MODE_FRESH)
         assert_frame_equal(h, 0, oref, odd.shape[0])
     fresh([0])
+
+
+def test_rccl_code_path_with_a_single_rank_group():
+    """What can be run of bench.py's RCCL plumbing on a one-GPU box: a process group of ONE rank on backend "nccl" (= RCCL)
+    with device_id, the barrier that names the rank's device, the MAX / SUM all-reduces and the all-gather of the per-GPU
+    rates (tools/rccl_single_rank.py, its own process).  Ranks 1-7 and xGMI stay unmeasured until the driver's SCALE run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_single_rank.py")], cwd=root, env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "aggregate (1.5, 7)" in out.stdout and "gather [3.25]" in out.stdout and "rccl single-rank ok" in out.stdout
