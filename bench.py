@@ -72,11 +72,22 @@ def cpu_baseline(src, budget_s=15.0):
     total = int(max(cores * 2, min(4096, budget_s / max(per_frame, 1e-6) * cores)))
     total -= total % cores
     wall, call = ol.cpu_bench(lib, src, total, cores, arith=arith)
+    mid = min(32, cores)  # a thread count at which the frame-parallel harness still scales: context for the full-machine number
+    tot_mid = max(mid * 2, int(min(4096, 4.0 / max(per_frame, 1e-6) * mid)))
+    tot_mid -= tot_mid % mid
+    wall_mid, _ = ol.cpu_bench(lib, src, tot_mid, mid, arith=arith)
+    fps, fps1 = total / wall, 1.0 / per_frame
     return {
-        "value": total / wall, "unit": "frames/s", "cores": cores, "kind": kind,
-        "single_thread_fps": 1.0 / per_frame,
+        "value": fps, "unit": "frames/s", "cores": cores, "kind": kind,
+        "single_thread_fps": fps1,
+        # value / single-thread / cores: 1.0 = the harness scales linearly.  It does not (one PatchWorkpp object and ~3 N heap
+        # allocations per frame: allocator- and bandwidth-bound), so GPU / CPU ratios taken from `value` flatter the GPU.
+        "scaling": fps / fps1 / cores,
+        "mid_threads": {"threads": mid, "frames_per_s": tot_mid / wall_mid, "scaling": tot_mid / wall_mid / fps1 / mid},
         "sample": "%d frames (%d distinct source frames, fresh state each) in %.1f s wall, %d host threads, "
-                  "g++ -O3 build of the reference patchworkpp.cpp + Eigen stand-in" % (total, len(src), wall, cores),
+                  "g++ -O3 build of the reference patchworkpp.cpp + Eigen stand-in; frame-parallel harness (oracle/ref_capi.cpp) reaches "
+                  "%.1fx one thread on %d threads: allocator/bandwidth-bound, not a tuned CPU implementation"
+                  % (total, len(src), wall, cores, fps / fps1, cores),
     }
 
 
@@ -115,6 +126,61 @@ def ingest_leg(pwpp_hip, src, gpu_index, chunk=256, chunks=8):
             "what": "page-locked host slabs -> H2D -> pipeline -> D2H of all index lists, two handles double-buffered (PWPP_MEM_HOST_PINNED)"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks under torch.distributed.run
+    (static rendezvous on 127.0.0.1 and a free port: the container's hostname may not resolve).  Returns the exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, PWPP_BENCH_SELF_SPAWNED="1")
+    return subprocess.call(cmd, env=env)
+
+
+def dense_leg(pwpp_hip, torch, dev, gpu_index, frames=64, steps=5):
+    """BASELINE.json configs[4] on this GPU, outside the timed region: dense synthetic 128-beam ~480k-point frames, 36-sector CZM."""
+    import pwpp_synth
+    src = [pwpp_synth.make_dense_cloud(1000 + k) for k in range(4)]
+    ns = [src[i % 4].shape[0] for i in range(frames)]
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    big = torch.empty((int(offs[-1]), 4), dtype=torch.float32, device=dev)
+    sd = [torch.from_numpy(a).to(dev) for a in src]
+    for i in range(frames):
+        big[offs[i]:offs[i + 1]].copy_(sd[i % 4])
+    torch.cuda.synchronize()
+    params = pwpp_hip.default_params()
+    for k in range(4):
+        params.num_sectors_each_zone[k] = 36
+    h = pwpp_hip.Handle(params, device=gpu_index)
+    batch = h.make_device_batch([big.data_ptr() + int(offs[i]) * 16 for i in range(frames)], ns)
+
+    def step():
+        h.launch_device_batch(batch, cols=4, mode=pwpp_hip.MODE_FRESH)
+        h.synchronize()
+
+    for _ in range(3):
+        step()
+    counts = h.all_counts()
+    for i in range(frames):
+        assert counts[i, 0] + counts[i, 1] + counts[i, 5] == ns[i], "dense leg: partition property violated in frame %d" % i
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    b_alg = float(sum(20 * ns[i] + 24 * int(counts[i, 2]) for i in range(frames)))
+    ws = h.workspace_bytes() / 1e9
+    h.close()
+    return {"workload": "configs[4] on one GPU: %d dense synthetic 128-beam frames (~%d points each), 36-sector CZM, device-resident, fresh state"
+                        % (frames, int(np.mean(ns))),
+            "frames": frames, "steps": steps, "frames_per_s": frames / dt, "ms_per_step": 1000.0 * dt,
+            "algorithmic_bytes_per_step": b_alg, "pipeline_achieved_GBps": b_alg / dt / 1e9, "pipeline_frac": b_alg / dt / 1e9 / HBM_PEAK_GBS,
+            "workspace_gb": ws, "note": "a 64-frame batch does not fill the chip the way 1024 frames do (profiles/: 1024 dense frames per batch)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,9 +195,19 @@ def main():
                          "as two frame ranges on two streams")
     ap.add_argument("--overlap", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of the separate single-stream pass that measures per-kernel times")
+    ap.add_argument("--dense-frames", type=int, default=64, help="frames of the configs[4] leg (outside the timed region, N = 1 only)")
     ap.add_argument("--skip-latency", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="no parity_check / reference_order / ingest legs (all of them run outside the timed region)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # Started as a plain process (`python bench.py --gpus N`, the way the driver starts --gpus 1): become the launcher --
+        # N ranks of this script under torch.distributed.run on this node, one per GPU; rank 0's JSON line passes through.
+        raise SystemExit(spawn_ranks(args.gpus))
+
+    if os.environ.get("PWPP_BENCH_ECHO_RANK"):  # (tests/test_dist_cpu.py: which ranks were started, and by whom)
+        print("bench rank %s of %s%s" % (os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1"),
+                                         " (self-spawned)" if os.environ.get("PWPP_BENCH_SELF_SPAWNED") else ""), file=sys.stderr, flush=True)
 
     import torch
 
@@ -211,6 +287,9 @@ def main():
             iou_min = min(iou_min, inter / union if union else 1.0)
             dn_max = max(dn_max, float(np.abs(h.normals(i) - gold["f32/fresh/%d/normals" % k]).max()))
         parity = {"frames": len(picks), "batch_frames": picks, "iou": iou_min, "max_dnormal": dn_max,
+                  "scope": "%d of the %d batch frames (the six distinct sources + one frame of the second frame range): ground masks and "
+                           "plane normals only; the bit-for-bit check of all %d frames (index lists, planes, state) is "
+                           "tests/test_gpu_parity.py::test_full_size_batch_properties in the -m gpu suite" % (len(picks), F, F),
                   "against": "tests/golden/kitti_golden.npz = the reference's patchworkpp.cpp (oracle/_ref, float sums), fresh state per frame"}
         assert not selfcheck or (iou_min == 1.0 and dn_max < 1e-4), "parity anchor failed: %r" % parity
 
@@ -247,6 +326,10 @@ def main():
     lat = sorted(lat)[len(lat) // 2] if lat else 0.0
 
     per_gpu = pwpp_dist.gather_values(F * args.steps / my_elapsed, dev if backend == "nccl" else None)  # every rank's own frames/s
+    dist_info = pwpp_dist.describe(backend, dev)  # backend, world size, RCCL version, every rank's GPU (all-gather)
+    dist_info["launcher"] = "bench.py spawned its own ranks (torch.distributed.run)" if os.environ.get("PWPP_BENCH_SELF_SPAWNED") else \
+        ("torch.distributed.run" if world > 1 else "single process")
+    dist_info["workspace_gb_per_rank"] = [v / 1e9 for v in pwpp_dist.gather_values(float(h.workspace_bytes()), dev if backend == "nccl" else None)]
 
     # reference-order output mode: the same batch with every sub-list in the reference's z-sorted order
     ref_order = None
@@ -272,6 +355,13 @@ def main():
         except Exception as e:
             ingest = {"frames_per_s": None, "error": str(e)}
 
+    dense = None
+    if world == 1 and args.workload == "kitti" and not args.skip_extras:
+        try:
+            dense = dense_leg(pwpp_hip, torch, dev, gpu_index, frames=args.dense_frames)
+        except Exception as e:
+            dense = {"frames_per_s": None, "error": str(e)}
+
     if rank == 0:
         fps = total_frames / elapsed
         b_alg = float(sum(20 * ns[i] + 24 * int(n_patches[i]) for i in range(F)))  # bytes per batch (one GPU)
@@ -296,6 +386,7 @@ def main():
                         "gpu_us": lat_gpu_us},
         }
         out["per_gpu"] = [{"rank": r, "frames_per_s": v} for r, v in enumerate(per_gpu)]
+        out["dist"] = dist_info
         out["selfcheck"] = bool(selfcheck)
         if parity is not None:
             out["parity_check"] = parity
@@ -303,6 +394,8 @@ def main():
             out["reference_order"] = ref_order
         if ingest is not None:
             out["ingest"] = ingest
+        if dense is not None:
+            out["dense"] = dense
         if prof:
             dom = max(prof, key=lambda k: prof[k][0])
             dom_ms = prof[dom][0] / max(prof[dom][1], 1)
@@ -316,8 +409,9 @@ def main():
             ach = b_alg / (dom_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                               "traffic_source": "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same "
-                                                 "workload on this build (tools/profile_r02.sh), not measured inside this run",
+                               "traffic_source": "profiles/hbm_traffic.json (its own `source` key names the script and round that wrote it): "
+                                                 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same workload, per launch over the "
+                                                 "whole batch, 2 x FETCH_SIZE + WRITE_SIZE; a constant read from a tracked file, not measured inside this run",
                                "algorithmic_bytes_per_launch": b_alg, "kernel_ms": dom_ms,
                                "pipeline_achieved": b_alg * args.steps / elapsed / 1e9,
                                "pipeline_frac": b_alg * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,

@@ -421,6 +421,10 @@ int build_capacity_table(pwpp_handle *h, int max_n) {
 }
 
 void fill_batch(pwpp_handle *h, PwppBatch &bt);
+// Words of ONE copy of the part counters (part_count, part_off, part_cursor: three slabs of frames x parts words).  A multiple of
+// four words with four to spare: k_clear zeroes whole 16-byte words from the copy's first word, so the SECOND copy must start
+// on a 16-byte boundary too (3 x frames x parts + 4 is 8 mod 16 bytes for a single frame of the default CZM).
+inline size_t counters_copy_words(size_t slab_words) { return (3 * slab_words + 4 + 3) & ~(size_t)3; }
 
 int read_observed(pwpp_handle *h) {
     const size_t NB = (size_t)PWPP_NUM_PARTS(h->dp.num_bins);
@@ -490,7 +494,7 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
     bt.bin_off = h->d_bins.p + slab;
     bt.dst_a = h->d_bins.p + 2 * slab;
     bt.dst_b = h->d_bins.p + 3 * slab;
-    const size_t pcopy = 3 * pslab + 4;  // (+4: k_clear zeroes whole 16-byte words)
+    const size_t pcopy = counters_copy_words(pslab);
     uint32_t *parts = h->d_parts.p + (size_t)h->counters_copy * pcopy;
     bt.part_count = parts;
     bt.part_off = parts + pslab;
@@ -1046,7 +1050,8 @@ int pwpp_estimate_ground_fields_batch(pwpp_handle *h, const void *const *data, c
     }
     // the fields are read in place as float32 (host: merged copies computed in units of floats; device: aligned loads): a
     // blob that does not start on a 4-byte boundary cannot be read that way
-    if (!data || !n) return fail(PWPP_E_ARG, "null argument");
+    if (!h || !data || !n) return fail(PWPP_E_ARG, "null argument");
+    if (frames < 1 || frames > 65535) return fail(PWPP_E_ARG, "frames=%d: 1 ... 65535 per call expected", frames);  // (before n[] / data[] are walked)
     for (int i = 0; i < frames; ++i)
         if (n[i] > 0 && (reinterpret_cast<uintptr_t>(data[i]) & 3u) != 0)
             return fail(PWPP_E_ARG, "frame %d: data pointer %p is not 4-byte aligned", i, data[i]);
@@ -1107,7 +1112,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
         if ((rc = h->d_ord_b.ensure(tp))) return rc;
     }
     if ((rc = h->d_bins.ensure((size_t)frames * NB * 4))) return rc;
-    if ((rc = h->d_parts.ensure(2 * ((size_t)frames * NP * 3 + 4)))) return rc;  // two copies; (+4: k_clear zeroes whole 16-byte words)
+    if ((rc = h->d_parts.ensure(2 * counters_copy_words((size_t)frames * NP)))) return rc;  // two copies
     if ((rc = h->d_recs.ensure((size_t)frames * B))) return rc;
     if ((rc = h->d_cls_start.ensure((size_t)frames * PWPP_CLS_STRIDE))) return rc;
     if ((rc = h->d_cls_list.ensure((size_t)frames * B))) return rc;

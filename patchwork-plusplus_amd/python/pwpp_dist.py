@@ -58,6 +58,34 @@ def gather_values(value, device=None):
     return [float(p.item()) for p in parts]
 
 
+def describe(backend, device=None):
+    """What the N > 1 record shows of the process group: backend, world size, RCCL version, and every rank's GPU
+    (index and PCI bus id, all-gathered in rank order) -- evidence that RCCL saw N ranks on N different devices."""
+    import torch
+    import torch.distributed as dist
+    info = {"backend": backend, "world_size": 1, "rccl_version": None, "devices": []}
+    try:
+        v = torch.cuda.nccl.version()  # ("nccl" IS RCCL on ROCm)
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        pass
+    idx, bus = -1, -1
+    if device is not None and device.type == "cuda":
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(idx)
+        bus = int(getattr(pr, "pci_bus_id", -1))
+        info["device_name"] = pr.name
+        info["hbm_gb"] = pr.total_memory / 1e9
+    dev = device if backend == "nccl" else None
+    if dist.is_available() and dist.is_initialized():
+        info["world_size"] = dist.get_world_size()
+        info["backend"] = dist.get_backend()
+    ids = gather_values(idx, dev)
+    buses = gather_values(bus, dev)
+    info["devices"] = [{"rank": r, "index": int(i), "pci_bus_id": int(b)} for r, (i, b) in enumerate(zip(ids, buses))]
+    return info
+
+
 def finalize():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

@@ -26,6 +26,8 @@ def _worker(rank, world, port, q):
     pwpp_dist.barrier()
     elapsed, frames = pwpp_dist.aggregate(1.0 + rank, len(shard) * 3)
     per_rank = pwpp_dist.gather_values(100.0 * (rank + 1))  # every rank's own rate, in rank order
+    info = pwpp_dist.describe("gloo")  # the "dist" record of the N > 1 bench line
+    assert info["world_size"] == world and info["backend"] == "gloo" and [d["rank"] for d in info["devices"]] == list(range(world))
     q.put((rank, shard, elapsed, frames, per_rank))
     pwpp_dist.finalize()
 
@@ -56,3 +58,20 @@ def test_single_process_passthrough():
     assert pwpp_dist.aggregate(0.5, 7) == (0.5, 7)
     assert pwpp_dist.gather_values(3.5) == [3.5]
     assert pwpp_dist.shard_sources(6, 4, 5) == [5, 0, 1, 2]
+
+
+def test_bench_spawns_its_own_ranks_when_started_bare():
+    """`python bench.py --gpus 2` as a plain process (the way the driver starts --gpus 1): bench.py must become the launcher.
+    Without a GPU every rank stops at "needs a GPU" -- what is checked here is that TWO ranks were started and said so."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PWPP_BENCH_ECHO_RANK"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    seen = sorted(l for l in out.stderr.splitlines() if l.startswith("bench rank "))
+    assert seen == ["bench rank 0 of 2 (self-spawned)", "bench rank 1 of 2 (self-spawned)"], out.stderr[-2000:]
+    import torch
+    if not torch.cuda.is_available():
+        assert out.returncode != 0 and "needs a GPU" in out.stderr

@@ -1244,11 +1244,14 @@ def test_bench_two_ranks_on_one_gpu():
     s.close()
     env = dict(os.environ, PWPP_BENCH_SHARE_DEVICE="1", PWPP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
 
-    def run(frames, extra):
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-               "--frames", str(frames), "--no-cpu-baseline", "--skip-latency"] + extra
-        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    def run(frames, extra, bare=False):
+        # bare: `python bench.py --gpus 2` as a plain process -- the way the driver starts --gpus 1 -- which must spawn its own ranks
+        launcher = [] if bare else ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                    "--master-port", str(port)]
+        cmd = [sys.executable] + launcher + [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                                             "--frames", str(frames), "--no-cpu-baseline", "--skip-latency"] + extra
+        out = subprocess.run(cmd, env={k: v for k, v in env.items() if bare is False or k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")},
+                             cwd=root, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, out.stdout  # rank 0 alone prints
@@ -1264,6 +1267,12 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["value"] <= sum(g["frames_per_s"] for g in d["per_gpu"]) * (1 + 1e-9)
     assert d["selfcheck"] is True and d["parity_check"]["iou"] == 1.0 and d["parity_check"]["frames"] == 7
     assert d["reference_order"]["ms_per_step"] > 0 and "ingest" not in d  # (the ingest leg is rank 0's at N = 1 only)
+    assert d["dist"]["world_size"] == 2 and d["dist"]["backend"] == "gloo" and len(d["dist"]["devices"]) == 2
+    assert d["dist"]["launcher"] == "torch.distributed.run" and len(d["dist"]["workspace_gb_per_rank"]) == 2
+    # the bare form: no launcher around it, WORLD_SIZE unset -- bench.py re-runs itself as two ranks and still prints ONE line
+    d = run(64, ["--skip-extras"], bare=True)
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 64 and len(d["per_gpu"]) == 2
+    assert d["dist"]["world_size"] == 2 and d["dist"]["launcher"].startswith("bench.py spawned")
     # the dense workload (configs[4]) through the same N > 1 path: 2 x 16 frames of ~486 k points, 36-sector CZM
     d = run(16, ["--workload", "dense", "--skip-extras"])
     assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 16 and d["config"]["points_per_frame"] > 400000
