@@ -169,7 +169,10 @@ PWPP_API int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32
  * evaluated (contract v3)
  *   - for a fit set of 1, 2 or 3 points: in the reference's own float arithmetic, which is determinate there (Eigen
  *     reduces fewer elements than one SIMD packet sequentially; two terms commute) -- points in the order of the
- *     reference's z-sorted bin, equal heights in cloud order.  All three builds of the reference under oracle/_ref agree
+ *     reference's z-sorted bin, equal heights in cloud order (the reference's std::sort is stable only for bins of up
+ *     to 16 points -- libstdc++'s insertion sort; beyond that members of EQUAL height may reach it in another order, and
+ *     the last bits of a 2-3 point float mean / covariance with them: the bit-for-bit statement holds for distinct heights,
+ *     tests/test_tiny_fits.py records the behaviour with duplicated heights).  All three builds of the reference under oracle/_ref agree
  *     on such sets and this library agrees with them: identical ground sets under the ROS launch file's parameters,
  *     num_min_pts 0-3, num_lpr 1-3 on the KITTI samples (tests/test_tiny_fits.py, CPU and GPU);
  *   - for 4 points and more: in exact arithmetic (integer moments on a 2^-21 m grid around per-bin / per-patch origins,
@@ -317,6 +320,8 @@ PWPP_API int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *
  *                         prove that none of its points can enter the pass
  *   "hi_split_zones"      how many zones' bins are stored in two parts (0..4, default 1: the near zone)
  *   "debug_flags"         4: timing probes of the fit chain; 16: exact binning arithmetic only;
+ *                         64: before a call that skips the clearing kernel (the last call's K5 zeroed this call's counters),
+ *                         read the counters back and fail with PWPP_E_STATE unless every word is zero;
  *                         16384 / 32768: force the fall-back paths of the lowest-point selection
  * Returns PWPP_E_ARG for an unknown name or a value out of range. */
 PWPP_API int pwpp_set_option(pwpp_handle *h, const char *name, const char *value);

@@ -164,6 +164,7 @@ struct pwpp_handle {
     DevBuf<float2> d_bin_origin;  // [B] origins of the fixed-point plane-fit sums
     DevBuf<float4> d_bin_bbox;    // [B] {xmin, xmax, ymin, ymax} of every bin (the fit kernels' skip test of the high parts)
     DevBuf<int32_t> d_plist;
+    DevBuf<uint8_t> d_member;     // membership plane (pwpp_dev.h, PWPP_SLOT_ALIGN): one bit per slot + PWPP_MEMBER_PAD bytes per part
     DevBuf<int32_t> d_out;
     DevBuf<unsigned long long> d_ord_a, d_ord_b;  // scratch of the reference-order mode (long sub-lists)
     int output_order = PWPP_ORDER_SCATTER;
@@ -404,7 +405,7 @@ int build_capacity_table(pwpp_handle *h, int max_n) {
         off[(size_t)b] = (uint32_t)run;
         double cap = scale * (double)h->observed[(size_t)b] + (h->one_pass_scale >= 1.0 ? 256.0 : 16.0);
         if (cap > (double)max_n + 16.0) cap = (double)max_n + 16.0;
-        uint64_t c = ((uint64_t)cap + 15u) & ~(uint64_t)15u;
+        uint64_t c = ((uint64_t)cap + (PWPP_SLOT_ALIGN - 1)) & ~(uint64_t)(PWPP_SLOT_ALIGN - 1);
         if (b < 2 * P.num_bins && (b & 1) && b / 2 >= P.split_end) c = 0;  // the high part of a bin that is not split: never used
         h->cap_table[(size_t)b] = (uint32_t)c;
         run += c;
@@ -511,6 +512,7 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
     bt.bin_origin = h->d_bin_origin.p;
     bt.bin_bbox = h->d_bin_bbox.p;
     bt.plist = h->d_plist.p;
+    bt.member = h->d_member.p;
     bt.recs = h->d_recs.p;
     bt.out_idx = h->d_out.p;
     bt.centers = h->d_centers.p;
@@ -572,7 +574,9 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     for (int f = 0; f < frames; ++f) {
         PwppFrameDesc &d = h->descs[(size_t)f];
         d.sbase = one_pass ? (int64_t)f * h->slots_per_frame : base;
-        base += ((int64_t)d.n + 3 * (int64_t)NP + 3) & ~(int64_t)3;  // compact layout: every part starts at a multiple of four slots (k_czm_scan)
+        d.mbase = d.sbase / 8 + (int64_t)PWPP_MEMBER_PAD * NP * f;  // (sbase is a multiple of PWPP_SLOT_ALIGN in both layouts)
+        // compact layout: every part starts at a multiple of PWPP_SLOT_ALIGN slots (k_czm_scan)
+        base += ((int64_t)d.n + (PWPP_SLOT_ALIGN - 1) * (int64_t)NP + (PWPP_SLOT_ALIGN - 1)) & ~(int64_t)(PWPP_SLOT_ALIGN - 1);
     }
     // the descriptors on the device are reused when nothing changed (a caller cycling through the same
     // device buffers, a replayed batch): one host-to-device copy less in front of the first kernel
@@ -599,6 +603,21 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     bt.no_clear = pre_cleared ? 1 : 0;
 
     bt.cap_off = one_pass ? h->d_cap_off.p : nullptr;
+    if (pre_cleared && (bt.debug & 64)) {
+        // the pre-cleared path rests on every K5 variant zeroing the OTHER copy of the counters for every frame.
+        // Debug option: read this call's copy back before the binning touches it; anything but zeros is a broken invariant.
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const size_t words = (size_t)slabs * (size_t)frames * (size_t)PWPP_NUM_PARTS(h->dp.num_bins);
+        std::vector<uint32_t> hp(words);
+        std::vector<PwppFrameResult> hr((size_t)frames);
+        HIPCHK(hipMemcpy(hp.data(), bt.part_count, words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hr.data(), bt.results, hr.size() * sizeof(PwppFrameResult), hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (uint32_t v : hp) bad += v != 0u;
+        const unsigned char *rb = reinterpret_cast<const unsigned char *>(hr.data());
+        for (size_t i = 0; i < hr.size() * sizeof(PwppFrameResult); ++i) bad += rb[i] != 0;
+        if (bad) return fail(PWPP_E_STATE, "pre-cleared counters are not zero (%zu words / bytes): a K5 variant skipped clear_next_counters", bad);
+    }
     HIPCHK(hipEventRecord(h->ev_begin, h->stream));
     // (the histogram, the scatter cursors and the per-frame result counters are zeroed by the pipeline's
     // first kernel, k_clear)
@@ -984,6 +1003,7 @@ int pwpp_destroy(pwpp_handle *h) {
     h->h_bin_max.release();
     h->d_frames_probe.release();
     h->d_plist.release();
+    h->d_member.release();
     h->d_out.release();
     h->d_ord_a.release();
     h->d_ord_b.release();
@@ -1184,7 +1204,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     // bin-ordered buffers hold frames x slots_per_frame records instead of one per point.  Used when the memory
     // is there; any overflow is caught when the batch lands and the batch is redone exactly.
     bool one_pass = false;
-    const size_t compact_slots = tp + (size_t)frames * (size_t)(3 * NP + 4);  // parts padded to multiples of four slots
+    const size_t compact_slots = tp + (size_t)frames * (size_t)((PWPP_SLOT_ALIGN - 1) * NP + PWPP_SLOT_ALIGN);  // parts padded to multiples of PWPP_SLOT_ALIGN slots
     size_t bin_slots = compact_slots;
     if (h->one_pass_holdoff > 0) {
         --h->one_pass_holdoff;
@@ -1221,6 +1241,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     if ((rc = h->d_sorted_xy.ensure(bin_slots + 1024))) return rc;
     if ((rc = h->d_sorted_idx.ensure(bin_slots))) return rc;
     if ((rc = h->d_plist.ensure(bin_slots))) return rc;
+    if ((rc = h->d_member.ensure(bin_slots / 8 + (size_t)frames * (size_t)NP * PWPP_MEMBER_PAD + 4096))) return rc;
 
     h->frames = frames;
     h->mode = mode;
@@ -1668,7 +1689,7 @@ int64_t pwpp_get_workspace_bytes(pwpp_handle *h) {
     auto b = [](size_t cap, size_t elt) { return (int64_t)(cap * elt); };
     return b(h->d_frames.cap, sizeof(PwppFrameDesc)) + b(h->d_frames_probe.cap, sizeof(PwppFrameDesc)) + b(h->d_in.cap, 4) + b(h->d_codes.cap, 2) +
            b(h->d_sorted_z.cap, 4) + b(h->d_sorted_xy.cap, 8) + b(h->d_sorted_idx.cap, 4) + b(h->d_bin_origin.cap, 8) + b(h->d_bin_bbox.cap, 16) +
-           b(h->d_plist.cap, 4) + b(h->d_out.cap, 4) + b(h->d_ord_a.cap, 8) + b(h->d_ord_b.cap, 8) + b(h->d_bins.cap, 4) + b(h->d_parts.cap, 4) +
+           b(h->d_plist.cap, 4) + b(h->d_member.cap, 1) + b(h->d_out.cap, 4) + b(h->d_ord_a.cap, 8) + b(h->d_ord_b.cap, 8) + b(h->d_bins.cap, 4) + b(h->d_parts.cap, 4) +
            b(h->d_cls_start.cap, 4) + b(h->d_cap_off.cap, 4) + b(h->d_bin_max.cap, 4) + b(h->d_cls_list.cap, 2) +
            b(h->d_recs.cap, sizeof(PwppPatchRec)) + b(h->d_centers.cap, 4) + b(h->d_normals.cap, 4) + b(h->d_results.cap, sizeof(PwppFrameResult)) +
            b(h->d_xyz.cap, 4) + b(h->d_dbg.cap, 8) + b(h->d_st_stream.cap, sizeof(PwppStateScalar)) + b(h->d_st_fresh.cap, sizeof(PwppStateScalar)) +
@@ -1690,6 +1711,7 @@ int pwpp_trim_workspace(pwpp_handle *h) {
     h->d_sorted_xy.release();
     h->d_sorted_idx.release();
     h->d_plist.release();
+    h->d_member.release();
     h->d_out.release();
     h->d_ord_a.release();
     h->d_ord_b.release();

@@ -22,6 +22,14 @@
 // pass that provably cannot use it (pwpp_fit.hip).  Parts are numbered in memory order -- the two parts of a bin are
 // neighbours, so a bin's slot range [first slot of its low part, +points of the bin) exists in every layout:
 //   2 b, 2 b + 1   low / high part of bin b;   2 B, 2 B + 1   the two pseudo-bins (RNR hits, out of range)
+// Every part starts at a multiple of PWPP_SLOT_ALIGN slots (16-byte loads of four points per lane; whole bytes of the membership
+// plane).  MEMBERSHIP PLANE (PwppBatch.member): one bit per slot, written by the R-GPF rounds whose set may be the patch's
+// final ground set, read by k_emit -- the split of a patch costs 1/8 byte per point instead of an index list.  The bits of part p
+// of a frame start at byte  fd.mbase + (first slot of the part) / 8 + PWPP_MEMBER_PAD * p  and are stored chunk by chunk the way a
+// fit row of G lanes sees its points (pwpp_fit.hip, chunk_point): byte  c * G + j  = the 8 points of lane j in chunk c, bit k = its
+// k-th.  A part's bits therefore end at most G <= PWPP_MEMBER_PAD bytes beyond (its points) / 8: hence the pad per part.
+#define PWPP_SLOT_ALIGN 32
+#define PWPP_MEMBER_PAD 64
 #define PWPP_PART_LO(bin) (2 * (bin))
 #define PWPP_PART_HI(bin) (2 * (bin) + 1)
 #define PWPP_NUM_PARTS(B) (2 * (B) + 2)
@@ -62,7 +70,8 @@ struct PwppFrameDesc {
     int32_t pad_;
     int32_t step;      // PWPP_LAYOUT_FIELDS: bytes from one point to the next (sensor_msgs/PointCloud2 point_step) ...
     int32_t off[4];    // ... and the byte offsets of x, y, z, intensity inside a point (intensity < 0: none)
-    int32_t pad2_[3];
+    int32_t pad2_;
+    int64_t mbase;     // first byte of this frame in the membership plane (= sbase / 8 + PWPP_MEMBER_PAD * parts * frame index)
     int64_t sbase;     // first slot of this frame in the part-ordered buffers (sorted_*, plist): compact on the two-pass
                        // path, frame * slots_per_frame on the one-pass path (see cap_off)
 };
@@ -95,6 +104,8 @@ struct PwppPatchRec {  // one per (frame, bin); written by k_patch_fit, finished
     int32_t decision;
     int32_t valid;  // 0: no fit ran in this bin (empty bin let through by num_min_pts <= 0); bit 1: the last pass skipped the
                     // high part (its points are non-ground and have no plist entries: k_emit takes them from sorted_idx);
+                    // bits 3-5: 0 = the split is the patch's plist range; otherwise log2(G) of the fit rows that left it in the
+                    // membership plane (PWPP_SLOT_ALIGN above): k_emit compacts the two lists itself;
                     // bit 2 (alone): the patch's first fit set was empty, so it works with the plane the reference object
                     // fitted LAST (the patch before it, or the frame before): nothing was fitted yet, k_fit_fixup does it
 };
@@ -144,6 +155,7 @@ struct PwppBatch {
     const float2 *bin_origin;    // [B] origin of every bin's fixed-point plane-fit sums (its polar centre rounded to 1/8 m)
     int32_t *plist;              // same slots, per patch (from the first slot of its low part): ground candidates from the front,
                                  // non-ground from the back of the bin's point count
+    uint8_t *member;             // membership plane (see PWPP_SLOT_ALIGN): the final ground set of a patch, one bit per slot
     PwppPatchRec *recs;          // [frames][B]
     uint32_t *dst_a;             // [frames][B+2] output offset of sub-list A (candidates / whole bin)
     uint32_t *dst_b;             // [frames][B+2] output offset of sub-list B (regionwise non-ground)

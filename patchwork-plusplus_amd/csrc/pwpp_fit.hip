@@ -241,7 +241,8 @@ __device__ __forceinline__ void ce(unsigned &a, unsigned &b) {
 enum { ST_VPF = 0, ST_SEED = 1, ST_ITER = 2, ST_LAZY = 3, ST_DONE = 4 };
 
 // hi_skipped: the pass that wrote the split did not read the high part (its points are non-ground and have no plist entries)
-__device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &pl, unsigned n, unsigned n_ground, bool hi_skipped) {
+// member_lg: 0 = the split is the patch's plist range; otherwise log2(G) of the rows that left it in the membership plane (pwpp_dev.h)
+__device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &pl, unsigned n, unsigned n_ground, bool hi_skipped, int member_lg = 0) {
     rec->mean[0] = pl.mean[0];
     rec->mean[1] = pl.mean[1];
     rec->mean[2] = pl.mean[2];
@@ -256,7 +257,7 @@ __device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &
     rec->n_ground = (int)n_ground;
     rec->n_nonground = (int)(n - n_ground);
     rec->decision = 0;
-    rec->valid = hi_skipped ? 3 : 1;
+    rec->valid = (hi_skipped ? 3 : 1) | (member_lg << 3);
 }
 
 // The reference object's plane members survive from patch to patch (and frame to frame): a patch whose FIRST fit set is
@@ -287,12 +288,16 @@ struct PatchRef {
     const float2 *xy;
     const int *idx;
     unsigned off_lo, n_lo, off_hi, n_hi;
+    int bin;  // (names the bits of its two parts in the membership plane: member_offset)
 };
 // Chunks are numbered through the low part and then through the high part; a pass that skips the high part
 // (stage_needs_hi) simply finds no points in the chunks above the low part's.
 struct PartSel {
     unsigned off, n, c;  // first slot and points of the part the chunk lies in, chunk index inside that part
+    unsigned moff;       // first byte of the part's bits in the frame's share of the membership plane (only the passes that write them use it)
 };
+// membership plane (pwpp_dev.h, PWPP_SLOT_ALIGN): where the bits of a part begin, relative to the frame's first byte
+__device__ __forceinline__ unsigned member_offset(unsigned off, int part) { return (off >> 3) + (unsigned)(PWPP_MEMBER_PAD * part); }
 // slot of the i-th point of the patch, low part first (the kernels that walk a patch point by point)
 __device__ __forceinline__ unsigned patch_slot(const PatchRef &p, unsigned i) { return i < p.n_lo ? p.off_lo + i : p.off_hi + (i - p.n_lo); }
 template <int G>
@@ -309,7 +314,16 @@ __device__ __forceinline__ PartSel chunk_sel(const PatchRef &p, unsigned c, bool
     s.off = h ? p.off_hi : p.off_lo;
     s.n = !on ? 0u : (h ? (use_hi ? p.n_hi : 0u) : p.n_lo);
     s.c = h ? c - nc_lo : c;
+    s.moff = member_offset(s.off, h ? PWPP_PART_HI(p.bin) : PWPP_PART_LO(p.bin));
     return s;
+}
+// The membership bits of one chunk of a row of G lanes: lane j's byte = its eight points (bit k = point k of the chunk, set = the
+// point is in the round's ground set; slots beyond the part's end are 0).  `wb` is row-uniform; a chunk beyond the part's last
+// one (the wave runs to its longest row's count) stores nothing, so a part's bits end inside its own share of the plane.
+template <int G>
+__device__ __forceinline__ void store_member(uint8_t *frame_member, const PartSel &sel, unsigned gmask, bool wb) {
+    const unsigned j = (unsigned)lane_id() & (G - 1);
+    if (wb && sel.c * (8u * G) < sel.n) frame_member[sel.moff + sel.c * G + j] = (uint8_t)gmask;
 }
 // R-VPF removes a point from the patch's working set (ref :495-503) by overwriting its z with a NaN whose
 // payload is the R-VPF round (1-based): the coordinates of a removed point are not needed again, and k_czm_*
@@ -615,6 +629,7 @@ __device__ double srow_lpr(const PatchRef &pts, bool need, bool use_cutoff, doub
         sel.off = off;
         sel.n = n;
         sel.c = 0u;
+        sel.moff = 0u;
         ChunkZ cp;
         if (nchunks > 0u) load_chunk_z<G>(cp, pts, sel);
         for (unsigned c = 0; c < nchunks; ++c) {
@@ -792,8 +807,10 @@ __device__ __forceinline__ PatchCtx patch_ctx(const PwppBatch &Bt, int f, unsign
     c.oy = o.y;
     return c;
 }
-__device__ __forceinline__ PatchRef patch_ref(const PwppBatch &Bt, const PwppFrameDesc &fd, unsigned off_lo, unsigned n_lo, unsigned off_hi, unsigned n_hi) {
+__device__ __forceinline__ PatchRef patch_ref(const PwppBatch &Bt, const PwppFrameDesc &fd, unsigned off_lo, unsigned n_lo, unsigned off_hi, unsigned n_hi,
+                                              int bin = 0) {
     PatchRef r;
+    r.bin = bin;
     r.z = Bt.sorted_z + fd.sbase;
     r.xy = Bt.sorted_xy + fd.sbase;
     r.idx = Bt.sorted_idx + fd.sbase;
@@ -804,7 +821,7 @@ __device__ __forceinline__ PatchRef patch_ref(const PwppBatch &Bt, const PwppFra
     return r;
 }
 __device__ __forceinline__ PatchRef patch_ref(const PwppBatch &Bt, const PwppFrameDesc &fd, const PatchCtx &pc) {
-    return patch_ref(Bt, fd, pc.off_lo, pc.n_lo, pc.off_hi, pc.n_hi);
+    return patch_ref(Bt, fd, pc.off_lo, pc.n_lo, pc.off_hi, pc.n_hi, pc.bin);
 }
 
 // Does a pass of this stage have to read the high part of the patch (n_hi points with z >= zs or NaN, x and y inside bb)?
@@ -1028,9 +1045,13 @@ __global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo,
 struct W64Patch {
     unsigned off_lo, n_lo, off_hi, n_hi;  // the two parts of the bin
     int kind;        // stage of the coming points phase; ST_DONE = nothing to do
-    int flags;       // bit0: last R-GPF round (write the split), bit1: zone-0 cut-off applies, bit2: dual seed pass,
+    int flags;       // bit0: last R-GPF round, bit1: zone-0 cut-off applies, bit2: dual seed pass,
                      // bit3: the pass reads the high part too, bit4: an R-VPF strip removed something; bits 8-15: the R-VPF
-                     // round of the strip in progress (reference-order output)
+                     // round of the strip in progress (reference-order output);
+                     // bit5: the pass leaves its set in the membership plane (an R-GPF round whose set may be the final one),
+                     // bit6: its totals may be compared with the totals in LDS (those of the round before, which gave the plane in
+                     // force), bit7 (set by the ROW): they are equal -- the patch has converged (early termination below)
+    int bin;
     float nx, ny, nz;
     float z0;        // z origin of the patch's fixed-point sums
     float ox, oy;    // x, y origin
@@ -1064,6 +1085,7 @@ template <int PW, bool DUAL, int MW>
 struct W64Shared {
     W64Owner o[DUAL ? PW + 1 : 1];  // (slot PW: the lanes that own nothing; they only ever read kind == ST_DONE)
     W64Patch p[PW];
+    unsigned char order[64];  // the patches that take part in the coming points phase, packed (sub-batches without idle rows)
     long long mom[PW][MW];
     long long mom2[DUAL ? PW : 1][MW];  // dual seed pass: moments of the band; then the stashed seed totals of the R-GPF stage
 };
@@ -1099,7 +1121,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(Pwpp
     const int ln = lane_id();
     const int j = ln & (G - 1), row = ln / G;
     const PwppFrameDesc fd = Bt.frames[f];
-    int *frame_plist = Bt.plist + fd.sbase;
+    uint8_t *frame_member = Bt.member + fd.mbase;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;  // ref :90
     const float zs = hi_split_z(P, sensor_height);
@@ -1146,6 +1168,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(Pwpp
         sh.p[ln].n_hi = pc.n_hi;
         sh.p[ln].kind = ST_DONE;
         sh.p[ln].flags = pc.zone == 0 ? 2 : 0;
+        sh.p[ln].bin = pc.bin;
         sh.p[ln].ox = pc.ox;
         sh.p[ln].oy = pc.oy;
         sh.p[ln].z0 = 0.0f;
@@ -1189,6 +1212,14 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(Pwpp
             const PlaneFit pl = O(pl);
             const double lpr = O(lpr);
             const bool last = kind == ST_ITER && O(it) == P.num_iter - 1;
+            // EARLY TERMINATION (exact): the plane is a function of the ten integer totals.  If an R-GPF round's totals equal
+            // those of the round before -- which gave the plane this round tested with -- the next plane is this plane bit for
+            // bit, hence every later round selects this round's set again and the final plane (ref :537-542) is the one in
+            // force: the patch is finished, its split is what this round left in the membership plane.  Every round that can
+            // be the last one that way (from the second on) writes its bits; the totals of 1-3 points are not compared (the
+            // tiny-fit path replaces them in LDS).
+            const bool wbits = kind == ST_ITER && (last || O(it) >= 1);
+            const bool cmp = kind == ST_ITER && !last && O(it) >= 1 && O(cnt) > 3;
             const double th = (kind == ST_VPF || kind == ST_LAZY) ? P.th_seeds_v : P.th_seeds;
             const double thr_seed = lpr + (dual_now ? (v_is_hi ? P.th_seeds : P.th_seeds_v) : th);
             const double thr_band = lpr + (v_is_hi ? P.th_seeds_v : P.th_seeds);
@@ -1197,7 +1228,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(Pwpp
                                 stage_needs_hi(kind, n_hi, dual_now && thr_band > thr_seed ? thr_band : thr_seed, P.th_dist, pl, O(bb), zs);
             if (pub_kind != ST_DONE) O(hi_skipped) = !use_hi && n_hi > 0u;
             sh.p[ln].kind = pub_kind;
-            sh.p[ln].flags = (O(zone) == 0 ? 2 : 0) | (last ? 1 : 0) | (dual_now ? 4 : 0) | (use_hi ? 8 : 0);
+            sh.p[ln].flags = (O(zone) == 0 ? 2 : 0) | (last ? 1 : 0) | (dual_now ? 4 : 0) | (use_hi ? 8 : 0) | (wbits ? 32 : 0) | (cmp ? 64 : 0);
             sh.p[ln].nx = pl.nx;
             sh.p[ln].ny = pl.ny;
             sh.p[ln].nz = pl.nz;
@@ -1207,40 +1238,41 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(Pwpp
                 sh.p[ln].u.thr.t2 = dual_now ? plane_test_threshold(0.0, thr_band) : 0.0f;
             }
         }
+        // the patches of the coming points phase, packed: patches that are finished (early termination), that take their
+        // totals from the stash or that are at another point of their chain leave no idle rows in the sub-batches
+        const unsigned long long act_mask = __ballot(pub_kind != ST_DONE);
+        if (pub_kind != ST_DONE) sh.order[__popcll(act_mask & ((1ull << ln) - 1ull))] = (unsigned char)ln;
+        const int nact = __popcll(act_mask);
         wave_lds_sync();
 
         // ---- C. points phase: R patches at a time, G lanes each
-        const unsigned long long act_mask = __ballot(pub_kind != ST_DONE);
-        for (int sb = 0; sb < NSB; ++sb) {
-            if (((act_mask >> (R * sb)) & ((1ull << R) - 1ull)) == 0ull) continue;
-            const int q = R * sb + row;
+        for (int sb = 0; R * sb < nact; ++sb) {
+            const bool row_on = R * sb + row < nact;
+            const int q = row_on ? (int)sh.order[R * sb + row] : (int)sh.order[0];
             const W64Patch pp = sh.p[q];
-            const bool on = pp.kind != ST_DONE;
+            const bool on = row_on && pp.kind != ST_DONE;
             const bool last = on && (pp.flags & 1);
+            const bool wbits = on && (pp.flags & 32);
             const bool use_hi = (pp.flags & 8) != 0;
             const FxpOrg org = fxp_org(pp.ox, pp.oy, pp.z0, scale, P.fxp_zr);
-            const PatchRef pts = patch_ref(Bt, fd, pp.off_lo, pp.n_lo, pp.off_hi, pp.n_hi);
-            int *plist = frame_plist + pp.off_lo;
-            const unsigned qn = pp.n_lo + pp.n_hi;
+            const PatchRef pts = patch_ref(Bt, fd, pp.off_lo, pp.n_lo, pp.off_hi, pp.n_hi, pp.bin);
             const unsigned nchunk_max = wave_max_u32(on ? patch_chunks<G>(pts, use_hi) : 0u);
             const bool dual = DUAL && on && (pp.flags & 4);
             Moments m, m2;
             m.clear();
             m2.clear();
-            unsigned run_g = 0, run_n = 0;
+            bool clamped = false;  // a height of the round's set lay outside z0 +- ZR (matters if this set is the final one)
             // The loads of chunk c + 1 are issued before chunk c is consumed: a wave is a chain load -> wait -> ~250
             // instructions, and with 3-4 waves per SIMD the waits were not covered (k_fit_w64<64,2> moved its bytes at
             // 4.8 TB/s where a plain read stream reaches 6.3, tools/ubench/read_bw.hip).  The solve phase sets the
             // register allocation of these kernels, so the second chunk in flight costs the points phase nothing.
             constexpr bool kPrefetch = PWPP_FIT_PREFETCH != 0 && G == 64;  // (the 16-lane kernels have no registers to spare: 76 spilled without it)
-            const bool any_last = __any(last);
+            const bool any_wbits = __any(wbits);
             ChunkPts cp;
             if (nchunk_max > 0u) load_chunk<G>(cp, pts, chunk_sel<G>(pts, 0u, use_hi, on));
             for (unsigned c = 0; c < nchunk_max; ++c) {
                 ChunkPts nx;
                 if (kPrefetch && c + 1u < nchunk_max) load_chunk<G>(nx, pts, chunk_sel<G>(pts, c + 1u, use_hi, on));  // (wave-uniform)
-                int w[kPPT];  // (the cloud indices are consumed last in the iteration: fetched here, not a chunk ahead -- registers)
-                if (any_last) load_chunk_idx<G>(w, pts, chunk_sel<G>(pts, c, use_hi, last));
                 const unsigned gmask = lane_stage_accum<G>(cp, pp.kind, pp.u.thr.t, pp.nx, pp.ny, pp.nz, scale, org, m);
                 if constexpr (DUAL) {
                     if (__any(dual)) {  // the band [thr_seed, thr_band) of a dual seed pass: the heights below t2 that are not in the first set
@@ -1250,22 +1282,9 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(Pwpp
                             if ((rest >> k & 1u) & (cp.z[k] < pp.u.thr.t2) & (k_off<G>(k) < cp.rem)) m2.add(cp.x[k], cp.y[k], cp.z[k], scale, org);
                     }
                 }
-                if (any_last) {  // the split is written BEFORE the plane is replaced (ref :529-541)
-                    const unsigned gm = last ? gmask : 0u;
-                    const unsigned ngm = last ? (chunk_valid_bits<G>(cp.rem) & ~gmask) : 0u;
-                    if (__any(chunk_clamped(cp, gm, org)) && ln == 0) flag_clamped(Bt, f);
-                    unsigned tg, tn;
-                    unsigned bg = run_g + Row<G>::excl_scan((unsigned)__popc(gm), tg);
-                    unsigned bn = run_n + Row<G>::excl_scan((unsigned)__popc(ngm), tn);
-                    run_g += tg;
-                    run_n += tn;
-#pragma unroll
-                    for (int k = 0; k < kPPT; ++k) {
-                        if (gm >> k & 1u)
-                            plist[bg++] = w[k];
-                        else if (ngm >> k & 1u)
-                            plist[qn - 1u - (bn++)] = nonground_entry(w[k], cp.z[k]);
-                    }
+                if (any_wbits) {  // the round's set -> membership plane: the split of the patch if this round turns out to be its last
+                    store_member<G>(frame_member, chunk_sel<G>(pts, c, use_hi, on), gmask, wbits);
+                    clamped = clamped || (wbits && chunk_clamped(cp, gmask, org));
                 }
                 if (c + 1u < nchunk_max) {
                     if (kPrefetch)
@@ -1277,13 +1296,17 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(Pwpp
             // the row's totals -> LDS.  64-lane rows: reduce-scatter of sixteen values, each stored by the lane it
             // ends up with; 16-lane rows: ten butterflies (four steps each; the selects of a scatter cost what its
             // fewer exchanges save: 0.868 -> 0.884 ms)
-            auto row_totals = [&](const Moments &mm, long long (*dst)[MW], bool store) {
+            // `same`: does the total this lane stores equal the one it replaces (the lanes that store nothing say yes)?
+            auto row_totals = [&](const Moments &mm, long long (*dst)[MW], bool store, bool &same) {
                 if constexpr (G == 64) {
                     long long v[16];
                     moments_to_16(mm, v);
                     int slot16;
                     const long long mine = Row<G>::reduce16_scatter(v, slot16);
-                    if (store && j < 16) dst[q][slot16] = mine;
+                    if (store && j < 16) {
+                        same = dst[q][slot16] == mine;
+                        dst[q][slot16] = mine;
+                    }
                 } else {
                     long long v[10];
                     v[0] = Row<G>::sum_i64(mm.n);
@@ -1295,22 +1318,30 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(Pwpp
                         long long mine = v[0];
 #pragma unroll
                         for (int k = 1; k < 10; ++k) mine = j == k ? v[k] : mine;
+                        same = dst[q][j] == mine;
                         dst[q][j] = mine;
                     }
                 }
             };
-            row_totals(m, sh.mom, on);
-            if (DUAL && __any(dual)) row_totals(m2, sh.mom2, dual);
+            bool same = true, same2 = true;
+            row_totals(m, sh.mom, on, same);
+            if (DUAL && __any(dual)) row_totals(m2, sh.mom2, dual, same2);
+            // early termination: every total of this round equals the round before's (flags bit 6: comparable) -> bit 7
+            const bool conv = on && (pp.flags & 64) && Row<G>::ballot(!same) == 0ull;  // row-uniform
+            if (conv && j == 0) sh.p[q].flags = pp.flags | 128;
+            if (__any(clamped && (last || conv)) && ln == 0) flag_clamped(Bt, f);  // (only a FINAL ground set counts, pwpp_get_clamped_frames)
         }
         wave_lds_sync();
 
         // ---- D. solve phase: lane p fits patch p (ref :47-75)
         long long cnt = 0;
         bool tiny = false;  // contract v3: a fit set of 1-3 points follows the reference's float arithmetic (tiny_fit_row)
+        bool conv = false;  // early termination: this round's totals repeat the last round's, the plane in force is the final one
         if (O(kind) != ST_DONE) {
             const long long a0 = sh.mom[ln][0], b0 = DUAL ? sh.mom2[DUAL ? ln : 0][0] : 0;
             cnt = from_stash ? b0 : (dual_now ? (v_is_hi ? a0 + b0 : a0) : a0);
             tiny = cnt >= 1 && cnt <= 3;
+            conv = ln < PW && (sh.p[ln < PW ? ln : 0].flags & 128) != 0 && cnt > 3;
         }
         const unsigned long long t_mask = __ballot(tiny);
         if (t_mask) {  // the rows gather the points of those patches again (the stage of phase B is still published)
@@ -1368,7 +1399,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(Pwpp
                     mean_cov_from_totals(cnt, s1, s2, P.fxp_shift, sh.p[ln].ox, sh.p[ln].oy, O(z0), mean, c6);
                 }
             }
-            if (cnt > 0) {  // empty set: the previous plane stays (ref :49)
+            if (cnt > 0 && !conv) {  // empty set: the previous plane stays (ref :49); converged: the solve would return the plane in force
                 PlaneFit npl;
                 plane_from_mean_c6(mean, c6, Bt.debug, npl);
                 O(pl) = npl;
@@ -1447,8 +1478,8 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(Pwpp
             O(kind) = ST_ITER;
         } else if (kind == ST_ITER) {
             const int it = O(it);
-            if (it == P.num_iter - 1) {
-                write_record(Bt.recs + (size_t)f * P.num_bins + O(bin), O(pl), O(n), (unsigned)O(cnt), O(hi_skipped) != 0);
+            if (it == P.num_iter - 1 || conv) {
+                write_record(Bt.recs + (size_t)f * P.num_bins + O(bin), O(pl), O(n), (unsigned)O(cnt), O(hi_skipped) != 0, G == 64 ? 6 : 4);
                 O(kind) = ST_DONE;
             }
             O(it) = it + 1;

@@ -438,8 +438,8 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
             const int p = p0 + j;
             const unsigned c = (j < per && p < NP) ? pcnt[p] : 0u;
             if (j < per && p < NP) s_pc[p] = c;
-            local[j] = (c + 3u) & ~3u;  // every part starts at a multiple of four slots: the fit kernels
-            sum += local[j];            // fetch four points (16 / 32 bytes) per lane and load
+            local[j] = (c + (PWPP_SLOT_ALIGN - 1u)) & ~(PWPP_SLOT_ALIGN - 1u);  // every part starts at a multiple of PWPP_SLOT_ALIGN slots: the fit
+            sum += local[j];  // kernels fetch four points (16 / 32 bytes) per lane and load, and whole bytes of the membership plane
         }
         // inclusive scan inside the wave (DPP), then the four wave totals through LDS: one barrier
         // instead of the sixteen of a Hillis-Steele scan over 256 partials (a single frame waits for this)
@@ -1497,7 +1497,8 @@ constexpr int kEmitBlock = 64;
 // (single frame 13.2 -> 4.8 us together with eight waves per bin).  Big batches keep the early exit of the empty bins
 // in front of the other loads: with 500 k waves the loads of those that have nothing to do cost more (0.23 -> 0.27 ms).
 template <bool EAGER>
-__global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt, bool keep_cat) {
+__global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, bool keep_cat) {
+    __shared__ int s_stage[512];  // (membership-plane path: the two lists of a block of 512 points, compacted before they are written)
     const int f = blockIdx.y, seg = blockIdx.x;
     // the frame's counters are final since K5: hand them to the host through its pinned mirror (eight posted
     // PCIe writes) instead of a copy command behind the pipeline (a dispatch of its own, ~9 us of a single frame)
@@ -1541,6 +1542,135 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(PwppBatch Bt, bool keep_cat
 #pragma unroll
             for (int u = 0; u < kU; ++u)
                 if (i0 + u * kEmitBlock < n) out[da + i0 + u * kEmitBlock] = v[u];
+        }
+        return;
+    }
+    const unsigned n_v = n, n_lo_v = n_lo, off_v = off, off_hi_v = off_hi, da_v = da, db_v = db;
+    const int member_lg = __builtin_amdgcn_readfirstlane((rec_valid >> 3) & 7);
+    if (member_lg) {
+        // (everything about the bin is the same in all lanes: said explicitly, so that counts, offsets and the pointers built
+        // from them live in scalar registers -- the kernel must keep eight waves per SIMD)
+        const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)n_v), n_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)n_lo_v);
+        const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)off_v), off_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)off_hi_v);
+        const unsigned da = (unsigned)__builtin_amdgcn_readfirstlane((int)da_v), db = (unsigned)__builtin_amdgcn_readfirstlane((int)db_v);
+        const int *idx_lo = Bt.sorted_idx + fd.sbase + off, *idx_hi = Bt.sorted_idx + fd.sbase + off_hi;
+        // The split of the patch is in the MEMBERSHIP PLANE (pwpp_dev.h, PWPP_SLOT_ALIGN): one bit per slot, stored the way
+        // the fit rows of G = 2^member_lg lanes saw their chunks (byte c * G + j = the eight points of lane j in chunk c).
+        // This wave compacts the two lists itself, in blocks of 512 points of one part: ground entries go to da + (ground
+        // points before), the others to db + (points before - ground points before).  "Before" a block = the set bits of the
+        // whole chunks in front of it (512 points are whole chunks for every G), counted from the plane; with one wave per
+        // bin the counts simply run along.  A high part the last fit pass skipped (rec.valid bit 1) is non-ground unread.
+        const uint8_t *mb = Bt.member + fd.mbase;
+        const unsigned part_lo = seg < B ? PWPP_PART_LO(seg) : B + seg;
+        const uint8_t *m_lo = mb + (off >> 3) + (unsigned)(PWPP_MEMBER_PAD * part_lo);
+        const uint8_t *m_hi = mb + (off_hi >> 3) + (unsigned)(PWPP_MEMBER_PAD * (part_lo + 1));
+        const bool hi_bits = !(rec_valid & 2);
+        const unsigned n_hi = n - n_lo;
+        const unsigned nb_lo = (n_lo + 511u) >> 9, nb = nb_lo + ((n_hi + 511u) >> 9);
+        const float *z_lo = Bt.sorted_z + fd.sbase + off, *z_hi2 = Bt.sorted_z + fd.sbase + off_hi;
+        const unsigned G = 1u << member_lg, lgG = (unsigned)member_lg;
+        auto count_bits = [&](const uint8_t *area, unsigned nbytes) -> unsigned {  // set bits of nbytes (a multiple of 4) bytes, wave-wide
+            unsigned c = 0;
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(area);
+            for (unsigned i = threadIdx.x; i < (nbytes >> 2); i += kEmitBlock) c += (unsigned)__popc(w[i]);
+            return (unsigned)__builtin_amdgcn_readfirstlane((int)wave_sum_u32(c));
+        };
+        unsigned g_before = 0, next_b = 0;  // ground points in the blocks [0, next_b)
+        for (unsigned b = part; b < nb; b += parts) {
+            const bool hi = b >= nb_lo;
+            const unsigned bb = hi ? b - nb_lo : b;
+            if (b != next_b) {  // (several waves per bin: count what the other waves' blocks hold)
+                if (!hi) {
+                    g_before = count_bits(m_lo, bb * 64u);
+                } else {  // (all of the low part: its bits end with its last chunk -- beyond lies the pad, never written)
+                    g_before = count_bits(m_lo, ((n_lo + (8u << lgG) - 1u) >> (lgG + 3)) << lgG);
+                    if (hi_bits) g_before += count_bits(m_hi, bb * 64u);
+                }
+            }
+            const unsigned pn = hi ? n_hi : n_lo, p_before = hi ? n_lo + bb * 512u : bb * 512u;
+            const int *pidx = hi ? idx_hi : idx_lo;
+            const uint8_t *pm = hi ? m_hi : m_lo;
+            const float *pz = hi ? z_hi2 : z_lo;
+            const bool bits = !hi || hi_bits;
+            // Lane L takes the points 4 L ... 4 L + 3 of each half of the block (16-byte loads of their cloud indices) -- which
+            // is how a 64-lane fit row holds them (one byte per lane and chunk: bit 4 q + b), and for the narrower rows four
+            // points with consecutive lanes j, the same chunk c and the same bit k: ONE aligned word of the plane per half.
+            const unsigned L = threadIdx.x;
+            int4 v[2];
+            unsigned mem4[2] = {0u, 0u};  // bit b = point b of the quad is ground
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned p0 = bb * 512u + 256u * q + 4u * L;
+                v[q] = make_int4(0, 0, 0, 0);
+                if (p0 < pn) {
+                    v[q] = *reinterpret_cast<const int4 *>(pidx + p0);  // (a part's slots are padded to a multiple of PWPP_SLOT_ALIGN)
+                    if (bits) {
+                        if (G == 64u) {
+                            mem4[q] = ((unsigned)pm[bb * 64u + L] >> (4 * q)) & 15u;
+                        } else {
+                            const unsigned c = p0 >> (lgG + 3), j0 = p0 & (G - 1u), k = (p0 >> lgG) & 7u;
+                            const unsigned w = *reinterpret_cast<const uint32_t *>(pm + (c << lgG) + j0) >> k;
+                            mem4[q] = (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u);
+                        }
+                    }
+                    if (keep_cat) {  // the R-VPF round that removed a point, if one did (see nonground_entry, pwpp_fit.hip)
+                        const float4 zz = *reinterpret_cast<const float4 *>(pz + p0);
+                        const unsigned zb[4] = {__float_as_uint(zz.x), __float_as_uint(zz.y), __float_as_uint(zz.z), __float_as_uint(zz.w)};
+                        int *vv = reinterpret_cast<int *>(&v[q]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if ((int)zb[t] > 0x7fc00000) vv[t] |= (int)((zb[t] & 0xffu) << 24);
+                    }
+                }
+            }
+            // ranks inside the block: ground entries from the front of the staging tile, the others from its back
+            const unsigned in0 = bb * 512u + 4u * L < pn ? (pn - (bb * 512u + 4u * L) < 4u ? pn - (bb * 512u + 4u * L) : 4u) : 0u;
+            const unsigned in1 = bb * 512u + 256u + 4u * L < pn ? (pn - (bb * 512u + 256u + 4u * L) < 4u ? pn - (bb * 512u + 256u + 4u * L) : 4u) : 0u;
+            mem4[0] &= (1u << in0) - 1u;
+            mem4[1] &= (1u << in1) - 1u;
+            const unsigned g0 = (unsigned)__popc(mem4[0]), g1 = (unsigned)__popc(mem4[1]);
+            // running sums over the lanes, two per scan (ground points | points inside, 16 bits each: at most 256)
+            unsigned eg0, eg1, ei0, ei1, tg0, tg1, ti0, ti1;
+            {
+                const unsigned a = g0 | (in0 << 16), bq = g1 | (in1 << 16);
+                const unsigned ia = wave_incl_scan(a), ib = wave_incl_scan(bq);
+                const unsigned ta = (unsigned)__builtin_amdgcn_readlane((int)ia, 63), tb = (unsigned)__builtin_amdgcn_readlane((int)ib, 63);
+                eg0 = (ia - a) & 0xffffu;
+                ei0 = (ia - a) >> 16;
+                eg1 = (ib - bq) & 0xffffu;
+                ei1 = (ib - bq) >> 16;
+                tg0 = ta & 0xffffu;
+                ti0 = ta >> 16;
+                tg1 = tb & 0xffffu;
+                ti1 = tb >> 16;
+            }
+            const unsigned gb = tg0 + tg1, nbk = ti0 + ti1;  // ground points / points of this block
+            __syncthreads();  // (the tile of the block before has been copied out)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                unsigned gr = q == 0 ? eg0 : tg0 + eg1;                        // ground entries in front of this quad
+                unsigned nr = q == 0 ? ei0 - eg0 : (ti0 - tg0) + (ei1 - eg1);  // other entries in front of it
+                const int *vv = reinterpret_cast<const int *>(&v[q]);
+                const unsigned inq = q == 0 ? in0 : in1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if ((unsigned)t < inq) {
+                        if (mem4[q] >> t & 1u)
+                            s_stage[gr++] = vv[t];
+                        else
+                            s_stage[511u - (nr++)] = vv[t];
+                    }
+                }
+            }
+            __syncthreads();
+            int *og = out + (da + g_before), *on = out + (db + (p_before - g_before));  // (scalar bases, 32-bit lane offsets)
+            const unsigned nn = nbk - gb;
+#pragma unroll 2
+            for (unsigned t = L; t < gb; t += kEmitBlock) og[t] = s_stage[t];
+#pragma unroll 2
+            for (unsigned t = L; t < nn; t += kEmitBlock) on[t] = s_stage[511u - t];
+            g_before += gb;
+            next_b = b + 1u;
         }
         return;
     }

@@ -1286,6 +1286,7 @@ def test_precleared_counters_under_changing_call_shapes(kitti, oracle):
     between, stream mode, a trimmed workspace, the two-pass path forced, a segment overflow with its redo, a frame that needs
     the serial fix-up -- every result against the oracle."""
     h = pwpp_hip.Handle()
+    h.set_option("debug_flags", 64)  # every call that skips k_clear first reads its counters back: all zero, or PWPP_E_STATE
     refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(k) for k in kitti]
 
     def fresh(idx):
