@@ -8,7 +8,8 @@
 
 #define PWPP_MAX_BINS 2048        // CZM bins per frame (default model: 504)
 #define PWPP_MAX_NEAR_BINS 1024   // bins inside the rings of interest (default: 96)
-#define PWPP_MAX_LPR 64           // num_lpr upper bound (default 20)
+#define PWPP_MAX_LPR 256          // num_lpr upper bound (default 20; the reference has none, patchworkpp.cpp:99-103: beyond ~4 x the lanes of
+                                  // a fit row the lowest-point selection takes its exact, slow path)
 #define PWPP_MAX_ROI 4            // rings of interest (reference keeps update_*_[4])
 #define PWPP_NUM_BUCKETS 96        // patch size buckets (quarter octaves up to 2^24 points)
 #define PWPP_CLS_STRIDE 104       // uint32 per frame in cls_start (PWPP_NUM_BUCKETS + 1, padded)

@@ -1479,7 +1479,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(Pwpp
         } else if (kind == ST_ITER) {
             const int it = O(it);
             if (it == P.num_iter - 1 || conv) {
-                write_record(Bt.recs + (size_t)f * P.num_bins + O(bin), O(pl), O(n), (unsigned)O(cnt), O(hi_skipped) != 0, G == 64 ? 6 : 4);
+                write_record(Bt.recs + (size_t)f * P.num_bins + O(bin), O(pl), O(n), (unsigned)O(cnt), O(hi_skipped) != 0, G == 64 ? 6 : (G == 32 ? 5 : (G == 16 ? 4 : 3)));
                 O(kind) = ST_DONE;
             }
             O(it) = it + 1;
@@ -1681,12 +1681,12 @@ __device__ double block_lpr(FitShared &sh, const PatchRef &pts, bool use_cutoff,
     // wave 0: order the gathered keys (all below the last bucket) and add up, ascending
     if (wv == 0) {
         const unsigned c = sh.sel_count;  // < keff <= PWPP_MAX_LPR
-        if ((unsigned)ln < c) {
-            const unsigned mine = sh.sel_keys[ln];
+        for (unsigned me = (unsigned)ln; me < c; me += 64u) {  // (a key per lane and round: its rank among the gathered keys)
+            const unsigned mine = sh.sel_keys[me];
             unsigned rank = 0;
             for (unsigned j = 0; j < c; ++j) {
                 const unsigned o = sh.sel_keys[j];
-                rank += (o < mine || (o == mine && j < (unsigned)ln)) ? 1u : 0u;
+                rank += (o < mine || (o == mine && j < me)) ? 1u : 0u;
             }
             sh.sel_sorted[rank] = mine;
         }

@@ -170,7 +170,7 @@ def test_synthetic_with_edge_cases(oracle, seed):
 
 PARAM_VARIANTS = [
     dict(enable_RNR=0), dict(enable_RVPF=0), dict(enable_TGR=0), dict(num_min_pts=0),
-    dict(num_iter=1), dict(num_iter=5), dict(num_lpr=1), dict(num_lpr=64), dict(num_min_pts=1), dict(num_min_pts=200),
+    dict(num_iter=1), dict(num_iter=5), dict(num_lpr=1), dict(num_lpr=64), dict(num_lpr=128), dict(num_lpr=256, num_min_pts=300), dict(num_min_pts=1), dict(num_min_pts=200),
     dict(th_dist=0.2, th_seeds=0.3), dict(uprightness_thr=0.9), dict(max_range=50.0, min_range=1.0),
     dict(sensor_height=2.0), dict(num_rings_of_interest=2), dict(adaptive_seed_selection_margin=-0.9),
     dict(sectors=(36, 36, 36, 36)), dict(sectors=(8, 8, 8, 8), rings=(1, 1, 1, 1)), dict(rings=(3, 5, 2, 6)),
@@ -937,7 +937,7 @@ def test_error_reporting_on_the_device(kitti):
         h.estimate_ground_batch_device([t.data_ptr() + 4], [100])
     with pytest.raises(pwpp_hip.PwppError, match="order"):
         h._check(h._L.pwpp_set_output_order(h._h, 7))
-    for bad in (dict(num_zones=3), dict(num_iter=0), dict(num_lpr=65), dict(max_range=1.0, min_range=2.0), dict(max_range=1e7)):
+    for bad in (dict(num_zones=3), dict(num_iter=0), dict(num_lpr=257), dict(max_range=1.0, min_range=2.0), dict(max_range=1e7)):
         p = pwpp_hip.default_params()
         for k, v in bad.items():
             setattr(p, k, v)
