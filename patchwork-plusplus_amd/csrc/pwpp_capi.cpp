@@ -163,7 +163,6 @@ struct pwpp_handle {
     DevBuf<int> d_sorted_idx;
     DevBuf<float2> d_bin_origin;  // [B] origins of the fixed-point plane-fit sums
     DevBuf<float4> d_bin_bbox;    // [B] {xmin, xmax, ymin, ymax} of every bin (the fit kernels' skip test of the high parts)
-    DevBuf<int32_t> d_plist;
     DevBuf<uint8_t> d_member;     // membership plane (pwpp_dev.h, PWPP_SLOT_ALIGN): one bit per slot + PWPP_MEMBER_PAD bytes per part
     DevBuf<int32_t> d_out;
     DevBuf<unsigned long long> d_ord_a, d_ord_b;  // scratch of the reference-order mode (long sub-lists)
@@ -511,7 +510,6 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
     bt.sorted_idx = h->d_sorted_idx.p;
     bt.bin_origin = h->d_bin_origin.p;
     bt.bin_bbox = h->d_bin_bbox.p;
-    bt.plist = h->d_plist.p;
     bt.member = h->d_member.p;
     bt.recs = h->d_recs.p;
     bt.out_idx = h->d_out.p;
@@ -1002,7 +1000,6 @@ int pwpp_destroy(pwpp_handle *h) {
     h->d_bin_max.release();
     h->h_bin_max.release();
     h->d_frames_probe.release();
-    h->d_plist.release();
     h->d_member.release();
     h->d_out.release();
     h->d_ord_a.release();
@@ -1221,9 +1218,9 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
             if ((rc = build_capacity_table(h, max_n + max_n / 8))) return rc;
         const size_t want = (size_t)frames * (size_t)h->slots_per_frame;
         size_t free_b = 0, total_b = 0;
-        const size_t per_slot = 3 * sizeof(float) + 2 * sizeof(int32_t);  // z, {x, y}, cloud index, plist
-        const size_t held = (h->d_sorted_z.cap + h->d_sorted_idx.cap + h->d_plist.cap) * sizeof(int32_t) + h->d_sorted_xy.cap * sizeof(float2);
-        const bool have = h->d_sorted_z.cap >= want + 1024 && h->d_sorted_xy.cap >= want + 1024 && h->d_sorted_idx.cap >= want && h->d_plist.cap >= want;  // already allocated
+        const size_t per_slot = 3 * sizeof(float) + sizeof(int32_t) + 1;  // z, {x, y}, cloud index (+ the slot's bit and its share of the pads in the membership plane)
+        const size_t held = (h->d_sorted_z.cap + h->d_sorted_idx.cap) * sizeof(int32_t) + h->d_sorted_xy.cap * sizeof(float2) + h->d_member.cap;
+        const bool have = h->d_sorted_z.cap >= want + 1024 && h->d_sorted_xy.cap >= want + 1024 && h->d_sorted_idx.cap >= want;  // already allocated
         if (have || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (want + want / 8 + 64) * per_slot * 21 / 20 <= free_b + held &&
                      want < ((size_t)1 << 40))) {
             one_pass = true;
@@ -1232,7 +1229,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     }
 
     // ---- 4. the bin-ordered buffers (slack: the fit kernels fetch whole chunks, up to 512 points beyond a patch's end)
-    if (one_pass && (h->d_sorted_z.ensure(bin_slots + 1024) || h->d_sorted_xy.ensure(bin_slots + 1024) || h->d_sorted_idx.ensure(bin_slots) || h->d_plist.ensure(bin_slots))) {
+    if (one_pass && (h->d_sorted_z.ensure(bin_slots + 1024) || h->d_sorted_xy.ensure(bin_slots + 1024) || h->d_sorted_idx.ensure(bin_slots))) {
         one_pass = false;  // the big allocation failed after all (fragmentation): compact layout, two-pass binning
         bin_slots = compact_slots;
         (void)hipGetLastError();
@@ -1240,7 +1237,6 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     if ((rc = h->d_sorted_z.ensure(bin_slots + 1024))) return rc;
     if ((rc = h->d_sorted_xy.ensure(bin_slots + 1024))) return rc;
     if ((rc = h->d_sorted_idx.ensure(bin_slots))) return rc;
-    if ((rc = h->d_plist.ensure(bin_slots))) return rc;
     if ((rc = h->d_member.ensure(bin_slots / 8 + (size_t)frames * (size_t)NP * PWPP_MEMBER_PAD + 4096))) return rc;
 
     h->frames = frames;
@@ -1689,7 +1685,7 @@ int64_t pwpp_get_workspace_bytes(pwpp_handle *h) {
     auto b = [](size_t cap, size_t elt) { return (int64_t)(cap * elt); };
     return b(h->d_frames.cap, sizeof(PwppFrameDesc)) + b(h->d_frames_probe.cap, sizeof(PwppFrameDesc)) + b(h->d_in.cap, 4) + b(h->d_codes.cap, 2) +
            b(h->d_sorted_z.cap, 4) + b(h->d_sorted_xy.cap, 8) + b(h->d_sorted_idx.cap, 4) + b(h->d_bin_origin.cap, 8) + b(h->d_bin_bbox.cap, 16) +
-           b(h->d_plist.cap, 4) + b(h->d_member.cap, 1) + b(h->d_out.cap, 4) + b(h->d_ord_a.cap, 8) + b(h->d_ord_b.cap, 8) + b(h->d_bins.cap, 4) + b(h->d_parts.cap, 4) +
+           b(h->d_member.cap, 1) + b(h->d_out.cap, 4) + b(h->d_ord_a.cap, 8) + b(h->d_ord_b.cap, 8) + b(h->d_bins.cap, 4) + b(h->d_parts.cap, 4) +
            b(h->d_cls_start.cap, 4) + b(h->d_cap_off.cap, 4) + b(h->d_bin_max.cap, 4) + b(h->d_cls_list.cap, 2) +
            b(h->d_recs.cap, sizeof(PwppPatchRec)) + b(h->d_centers.cap, 4) + b(h->d_normals.cap, 4) + b(h->d_results.cap, sizeof(PwppFrameResult)) +
            b(h->d_xyz.cap, 4) + b(h->d_dbg.cap, 8) + b(h->d_st_stream.cap, sizeof(PwppStateScalar)) + b(h->d_st_fresh.cap, sizeof(PwppStateScalar)) +
@@ -1710,7 +1706,6 @@ int pwpp_trim_workspace(pwpp_handle *h) {
     h->d_sorted_z.release();
     h->d_sorted_xy.release();
     h->d_sorted_idx.release();
-    h->d_plist.release();
     h->d_member.release();
     h->d_out.release();
     h->d_ord_a.release();

@@ -73,7 +73,7 @@ struct PwppFrameDesc {
     int32_t off[4];    // ... and the byte offsets of x, y, z, intensity inside a point (intensity < 0: none)
     int32_t pad2_;
     int64_t mbase;     // first byte of this frame in the membership plane (= sbase / 8 + PWPP_MEMBER_PAD * parts * frame index)
-    int64_t sbase;     // first slot of this frame in the part-ordered buffers (sorted_*, plist): compact on the two-pass
+    int64_t sbase;     // first slot of this frame in the part-ordered buffers (sorted_*): compact on the two-pass
                        // path, frame * slots_per_frame on the one-pass path (see cap_off)
 };
 
@@ -104,9 +104,9 @@ struct PwppPatchRec {  // one per (frame, bin); written by k_patch_fit, finished
     int32_t n_nonground;
     int32_t decision;
     int32_t valid;  // 0: no fit ran in this bin (empty bin let through by num_min_pts <= 0); bit 1: the last pass skipped the
-                    // high part (its points are non-ground and have no plist entries: k_emit takes them from sorted_idx);
-                    // bits 3-5: 0 = the split is the patch's plist range; otherwise log2(G) of the fit rows that left it in the
-                    // membership plane (PWPP_SLOT_ALIGN above): k_emit compacts the two lists itself;
+                    // high part (its points are non-ground, its bits in the membership plane were not written);
+                    // bits 3-5: log2(G) of the fit rows that left the patch's split in the membership plane (PWPP_SLOT_ALIGN
+                    // above), i.e. the layout of its bits: k_emit compacts the two lists from them;
                     // bit 2 (alone): the patch's first fit set was empty, so it works with the plane the reference object
                     // fitted LAST (the patch before it, or the frame before): nothing was fitted yet, k_fit_fixup does it
 };
@@ -154,8 +154,6 @@ struct PwppBatch {
     uint32_t *bin_max;           // [2B+2] largest count every PART has had in any frame so far (k_czm_scan): sizes the one-pass segments
     const float4 *bin_bbox;      // [B] {xmin, xmax, ymin, ymax} of every bin (a little generous): the skip test of the high parts
     const float2 *bin_origin;    // [B] origin of every bin's fixed-point plane-fit sums (its polar centre rounded to 1/8 m)
-    int32_t *plist;              // same slots, per patch (from the first slot of its low part): ground candidates from the front,
-                                 // non-ground from the back of the bin's point count
     uint8_t *member;             // membership plane (see PWPP_SLOT_ALIGN): the final ground set of a patch, one bit per slot
     PwppPatchRec *recs;          // [frames][B]
     uint32_t *dst_a;             // [frames][B+2] output offset of sub-list A (candidates / whole bin)

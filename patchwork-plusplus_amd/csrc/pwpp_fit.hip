@@ -218,6 +218,12 @@ struct Row {
 };
 
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~Row<64>::min_u32(~v); }
+// hand-over through LDS between the lanes of ONE wave (no workgroup barrier)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // compare-exchange of two keys, ascending
 __device__ __forceinline__ void ce(unsigned &a, unsigned &b) {
@@ -240,9 +246,9 @@ __device__ __forceinline__ void ce(unsigned &a, unsigned &b) {
 // ------------------------------------------------------------------------------------------
 enum { ST_VPF = 0, ST_SEED = 1, ST_ITER = 2, ST_LAZY = 3, ST_DONE = 4 };
 
-// hi_skipped: the pass that wrote the split did not read the high part (its points are non-ground and have no plist entries)
-// member_lg: 0 = the split is the patch's plist range; otherwise log2(G) of the rows that left it in the membership plane (pwpp_dev.h)
-__device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &pl, unsigned n, unsigned n_ground, bool hi_skipped, int member_lg = 0) {
+// hi_skipped: the pass that left the split did not read the high part (its points are non-ground, its bits were not written)
+// member_lg: log2(G) of the rows that left the split in the membership plane (pwpp_dev.h)
+__device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &pl, unsigned n, unsigned n_ground, bool hi_skipped, int member_lg) {
     rec->mean[0] = pl.mean[0];
     rec->mean[1] = pl.mean[1];
     rec->mean[2] = pl.mean[2];
@@ -334,12 +340,6 @@ __device__ __forceinline__ void strip_point(const PatchRef &pr, unsigned slot, i
     pr.z[slot] = __uint_as_float(0x7fc00000u | (unsigned)((round + 1) & 0xff));
 }
 __device__ __forceinline__ bool z_stripped(float z) { return (int)__float_as_uint(z) > 0x7fc00000; }
-// what the last R-GPF round writes for a non-ground point: its cloud index, plus in bits 24-31 the
-// R-VPF round that removed it (0: none) -- k_emit masks it off, k_order_sublists sorts by it
-__device__ __forceinline__ int nonground_entry(int idx, float z) {
-    return z_stripped(z) ? (idx | (int)((__float_as_uint(z) & 0xffu) << 24)) : idx;
-}
-
 // One chunk = 8 points per lane of a row of G lanes.  Which lane sees which point is free (the sums are exact
 // integers, the lists are written in scatter order anyway), so the mapping follows the loads:
 //   G = 64 (big bins: every lane busy)  slot k of lane j = point c * 512 + (k / 4) * 256 + 4 j + (k % 4): a lane
@@ -447,30 +447,6 @@ __device__ __forceinline__ void load_chunk(ChunkPts &cp, const PatchRef &pr, con
 // the slot of point k of this lane (what strip_point marks)
 template <int G>
 __device__ __forceinline__ unsigned chunk_slot(const PartSel &sel, int k, unsigned j) { return sel.off + chunk_point<G>(sel.c, k, j); }
-// the cloud indices of a chunk (only the pass that writes the split needs them)
-template <int G>
-__device__ __forceinline__ void load_chunk_idx(int w[kPPT], const PatchRef &pr, const PartSel &sel) {
-    const unsigned j = (unsigned)lane_id() & (G - 1);
-    if constexpr (G == 64) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const unsigned p0 = chunk_point<G>(sel.c, 4 * q, j);
-            int4 v = make_int4(0, 0, 0, 0);
-            if (p0 < sel.n) v = *reinterpret_cast<const int4 *>(pr.idx + sel.off + p0);  // (a part's slots are padded to a multiple of four)
-            w[4 * q] = v.x;
-            w[4 * q + 1] = v.y;
-            w[4 * q + 2] = v.z;
-            w[4 * q + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < kPPT; ++k) {
-            const unsigned i = chunk_point<G>(sel.c, k, j);
-            w[k] = i < sel.n ? pr.idx[sel.off + i] : 0;
-        }
-    }
-}
-
 // per-lane part of one stage: adds the points of one chunk that enter this stage's fit to `m` (ground
 // set of an R-GPF round, seeds of a seed stage) and returns their mask.
 //   One test for every stage: a seed pass (ref :108,145, "z < lpr + th_seeds") is the plane test of ref :525 with normal
@@ -876,7 +852,7 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
     const unsigned n = pc.n;
     const PwppFrameDesc fd = Bt.frames[f];
     const PatchRef pts = patch_ref(Bt, fd, pc);
-    int *plist = Bt.plist + fd.sbase + pc.off_lo;
+    uint8_t *frame_member = Bt.member + fd.mbase;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;
     const float zs = hi_split_z(P, sensor_height);
@@ -884,6 +860,9 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
     const bool use_cutoff = zone == 0;
     const double scale = (double)(1 << P.fxp_shift);
     const bool wide = __any(n > 2047u);  // wave-uniform: some row's second moments may leave int64 in the cross-lane sum
+    // the totals of the row's last R-GPF round (early termination, see k_fit_w64): n, S1[3], S2[6] as two 64-bit halves each
+    __shared__ long long s_prev[kBlock / G][16];
+    long long(&prev)[16] = s_prev[threadIdx.x / G];
 
     PlaneFit pl;
     plane_clear(pl);
@@ -916,37 +895,26 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
         const bool use_hi = on && stage_needs_hi(kind, pc.n_hi, thr_seed, P.th_dist, pl, bb, zs);  // row-uniform
         const unsigned nchunk_max = wave_max_u32(on ? patch_chunks<G>(pts, use_hi) : 0u);
         const float T = stage_threshold(kind, pl.d, P.th_dist, thr_seed);  // the pass's test in float (lane_stage_accum)
+        // (early termination and the membership plane: see k_fit_w64 -- every R-GPF round from the second on, and the last one,
+        // leaves its set in the plane; a round whose totals repeat the round before's ends the patch)
+        const bool wbits = kind == ST_ITER && (last || it >= 1);
         Moments m;
         m.clear();
-        unsigned run_g = 0, run_n = 0;
+        bool clamped = false;
         ChunkPts cp;
         load_chunk<G>(cp, pts, chunk_sel<G>(pts, 0u, use_hi, on));
         for (unsigned c = 0; c < nchunk_max; ++c) {
             ChunkPts nx;  // the next chunk is in flight while this one is accumulated
             load_chunk<G>(nx, pts, chunk_sel<G>(pts, c + 1u, use_hi, on));
-            int w[kPPT];
-            if (__any(last)) load_chunk_idx<G>(w, pts, chunk_sel<G>(pts, c, use_hi, last));
             const unsigned gmask = lane_stage_accum<G>(cp, kind, T, pl.nx, pl.ny, pl.nz, scale, org, m);
-            if (__any(last)) {  // the split is written BEFORE the plane is replaced (ref :529-541)
-                const unsigned gm = last ? gmask : 0u;
-                const unsigned ngm = last ? (chunk_valid_bits<G>(cp.rem) & ~gmask) : 0u;
-                if (__any(chunk_clamped(cp, gm, org)) && lane_id() == 0) flag_clamped(Bt, f);
-                unsigned tg, tn;
-                unsigned bg = run_g + Row<G>::excl_scan((unsigned)__popc(gm), tg);
-                unsigned bn = run_n + Row<G>::excl_scan((unsigned)__popc(ngm), tn);
-                run_g += tg;
-                run_n += tn;
-#pragma unroll
-                for (int k = 0; k < kPPT; ++k) {
-                    if (gm >> k & 1u)
-                        plist[bg++] = w[k];
-                    else if (ngm >> k & 1u)
-                        plist[n - 1u - (bn++)] = nonground_entry(w[k], cp.z[k]);
-                }
+            if (__any(wbits)) {
+                store_member<G>(frame_member, chunk_sel<G>(pts, c, use_hi, on), gmask, wbits);
+                clamped = clamped || (wbits && chunk_clamped(cp, gmask, org));
             }
             cp = nx;
         }
         const long long cnt = Row<G>::sum_i64(m.n);
+        bool conv = false;
         {
             long long s1[3];
             __int128 s2[6];
@@ -960,7 +928,28 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
                 for (int k = 0; k < 6; ++k)
                     s2[k] = join_halves(Row<G>::sum_i64(m.s2[k] & 0xffffffffLL), Row<G>::sum_i64(m.s2[k] >> 32));
             }
-            const bool fit = kind != ST_DONE && cnt > 0;  // empty: ref :49
+            if (__any(kind == ST_ITER)) {  // this round's totals against the last round's, then they take their place (lane 0 of the row keeps them)
+                bool same = prev[0] == cnt;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) same = same && prev[1 + k] == s1[k];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) same = same && prev[4 + k] == (long long)(unsigned long long)s2[k] && prev[10 + k] == (long long)(s2[k] >> 64);
+                conv = kind == ST_ITER && !last && it >= 1 && cnt > 3 && same;  // (1-3 points: the tiny-fit path, never compared)
+                wave_lds_sync();
+                if (kind == ST_ITER && j == 0) {
+                    prev[0] = cnt;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) prev[1 + k] = s1[k];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        prev[4 + k] = (long long)(unsigned long long)s2[k];
+                        prev[10 + k] = (long long)(s2[k] >> 64);
+                    }
+                }
+                wave_lds_sync();
+            }
+            if (__any(clamped && (last || conv)) && lane_id() == 0) flag_clamped(Bt, f);
+            const bool fit = kind != ST_DONE && cnt > 0 && !conv;  // empty: ref :49; converged: the solve would return the plane in force
             const bool tiny = fit && cnt <= 3;            // contract v3: the reference's float arithmetic (row-uniform)
             float mt[3], ct[6];
             if (__any(tiny)) tiny_fit_row<G>(pts, tiny, kind, T, pl.nx, pl.ny, pl.nz, mt, ct);
@@ -1014,8 +1003,9 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
         } else if (kind == ST_LAZY) {
             kind = ST_ITER;
         } else if (kind == ST_ITER) {
-            if (last) {
-                if (j == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt, !use_hi && pc.n_hi > 0u);
+            if (last || conv) {
+                if (j == 0)
+                    write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt, !use_hi && pc.n_hi > 0u, G == 64 ? 6 : (G == 32 ? 5 : (G == 16 ? 4 : 3)));
                 kind = ST_DONE;
             }
             ++it;
@@ -1090,11 +1080,6 @@ struct W64Shared {
     long long mom2[DUAL ? PW : 1][MW];  // dual seed pass: moments of the band; then the stashed seed totals of the R-GPF stage
 };
 
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // G = lanes per patch in the points phases (16: four patches at a time; 64: one at a time, for
 // big bins), PW = patches owned by the wave = lanes active in the solve phase.
@@ -1504,8 +1489,6 @@ struct FitShared {
     unsigned prefix;
     unsigned krem;
     unsigned keff;
-    unsigned cnt_g;
-    unsigned cnt_ng;
     long long last_n;  // points of the set reduce_and_fit saw last
 };
 
@@ -1727,7 +1710,7 @@ struct BRowShared {
     int elig[kWaves];
     double single_sum;   // a patch of one chunk: wave 0's result
     unsigned single_T;
-    unsigned cnt_g, cnt_ng;
+    long long prev_tot[16];      // the totals of the last R-GPF round (early termination)
     long long mom2[kWaves][16];  // dual seed pass: the band between the two seed thresholds
     PlaneFit plane[2];           // R-VPF fit | R-GPF seed fit, solved side by side by different waves
     FitShared fs;  // for block_lpr, the exact fall-back of the lowest-point selection
@@ -1848,7 +1831,7 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
     const unsigned n = pc.n;  // (at most 2047 points per lane, see Moments; pwpp_launch_fit sends larger patches to k_fit_stream)
     const PwppFrameDesc fd = Bt.frames[f];
     const PatchRef pts = patch_ref(Bt, fd, pc);
-    int *plist = Bt.plist + fd.sbase + pc.off_lo;
+    uint8_t *frame_member = Bt.member + fd.mbase;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;
     const float zs = hi_split_z(P, sensor_height);
@@ -1874,11 +1857,6 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
     long long stash_cnt = 0;
     bool fitted = false;  // a plane of this patch's own exists
     PlaneFit pl_seed = pl;
-    if (threadIdx.x == 0) {
-        sh.cnt_g = 0;
-        sh.cnt_ng = 0;
-    }
-    __syncthreads();
     // timing probes (PWPP_DEBUG_FLAGS & 4): the chain of the largest patch of frame 0, (code << 56) | 100 MHz ticks
     // (PWPP_DEBUG_FLAGS = 4 | size << 16 follows the patch of that size instead of the largest one)
     const bool probing = (Bt.debug & 4) && blockIdx.x == 0 && threadIdx.x == 0 && ((Bt.debug >> 16) ? n == (unsigned)(Bt.debug >> 16) : by == 0u);
@@ -1922,15 +1900,14 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         Moments m, m2;
         m.clear();
         m2.clear();
+        // (early termination and the membership plane: see k_fit_w64)
+        const bool wbits = kind == ST_ITER && (last || it >= 1);
+        bool clamped = false;
         ChunkPts cp;
         load_chunk<64>(cp, pts, chunk_sel<64>(pts, (unsigned)wv, use_hi));
-        int w[kPPT];
-        if (last) load_chunk_idx<64>(w, pts, chunk_sel<64>(pts, (unsigned)wv, use_hi));
         for (unsigned c = (unsigned)wv; c < nchunk; c += kWaves) {
-            ChunkPts nx;  // this wave's next chunk (and, in the round that writes the split, its cloud indices) is in flight while this one is accumulated
+            ChunkPts nx;  // this wave's next chunk is in flight while this one is accumulated
             load_chunk<64>(nx, pts, chunk_sel<64>(pts, c + kWaves, use_hi));
-            int wnx[kPPT];
-            if (last) load_chunk_idx<64>(wnx, pts, chunk_sel<64>(pts, c + kWaves, use_hi));
             const unsigned gmask = lane_stage_accum<64>(cp, kind, T, pl.nx, pl.ny, pl.nz, scale, org, m);
             if (dual_now) {  // the band [thr_seed, thr_band)
                 const unsigned rest = ~gmask;
@@ -1938,32 +1915,11 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
                 for (int k = 0; k < kPPT; ++k)
                     if ((rest >> k & 1u) & (cp.z[k] < T_band) & (k_off<64>(k) < cp.rem)) m2.add(cp.x[k], cp.y[k], cp.z[k], scale, org);
             }
-            if (last) {  // the split is written BEFORE the plane is replaced (ref :529-541)
-                const unsigned ngm = chunk_valid_bits<64>(cp.rem) & ~gmask;
-                if (__any(chunk_clamped(cp, gmask, org)) && ln == 0) flag_clamped(Bt, f);
-                unsigned tg, tn;
-                unsigned bg = Row<64>::excl_scan((unsigned)__popc(gmask), tg);
-                unsigned bn = Row<64>::excl_scan((unsigned)__popc(ngm), tn);
-                unsigned base_g = 0, base_n = 0;
-                if (ln == 0) {
-                    base_g = atomicAdd(&sh.cnt_g, tg);
-                    base_n = atomicAdd(&sh.cnt_ng, tn);
-                }
-                bg += (unsigned)__builtin_amdgcn_readfirstlane((int)base_g);
-                bn += (unsigned)__builtin_amdgcn_readfirstlane((int)base_n);
-#pragma unroll
-                for (int k = 0; k < kPPT; ++k) {
-                    if (gmask >> k & 1u)
-                        plist[bg++] = w[k];
-                    else if (ngm >> k & 1u)
-                        plist[n - 1u - (bn++)] = nonground_entry(w[k], cp.z[k]);
-                }
+            if (wbits) {  // the round's set -> membership plane (every wave its own chunks)
+                store_member<64>(frame_member, chunk_sel<64>(pts, c, use_hi), gmask, true);
+                clamped = clamped || chunk_clamped(cp, gmask, org);
             }
             cp = nx;
-            if (last) {
-#pragma unroll
-                for (int k = 0; k < kPPT; ++k) w[k] = wnx[k];
-            }
         }
         probe(3);
         {   // the wave's sums -> LDS (reduce-scatter: each of the sixteen values is stored by the lane it ends up with)
@@ -1982,6 +1938,7 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         long long tot[4];
         __int128 s2[6];
         long long cnt = 0;
+        bool conv = false;  // this R-GPF round's totals repeat the last round's: the plane in force is the final one
         {
             long long t16[16];
 #pragma unroll
@@ -2004,11 +1961,23 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
             for (int k = 0; k < 4; ++k) tot[k] = t16[k];
 #pragma unroll
             for (int k = 0; k < 6; ++k) s2[k] = join_halves(t16[4 + k], t16[10 + k]);
+            if (kind == ST_ITER) {  // (every lane holds the same sixteen totals)
+                bool same = true;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) same = same && sh.prev_tot[k] == t16[k];
+                conv = !last && it >= 1 && cnt > 3 && same;
+            }
+            __syncthreads();
+            if (kind == ST_ITER && threadIdx.x == 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sh.prev_tot[k] = t16[k];
+            }
         }
+        if (clamped && (last || conv)) flag_clamped(Bt, f);  // (only a FINAL ground set counts)
         __syncthreads();
         probe(4);
         PlaneFit fitted_pl = pl;
-        if (tot[0] > 0) {  // empty: ref :49
+        if (tot[0] > 0 && !conv) {  // empty: ref :49; converged: the solve would return the plane in force
             float mean[3], c6[6];
             if (tot[0] <= 3) {  // contract v3 (wave-uniform): this wave gathers the 1-3 points of its set itself
                 const float thr_t = dual_now ? ((spec == v_is_hi) ? T : T_band) : T;
@@ -2066,8 +2035,8 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         } else if (kind == ST_LAZY) {
             kind = ST_ITER;
         } else if (kind == ST_ITER) {
-            if (last) {
-                if (threadIdx.x == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt, !use_hi && pc.n_hi > 0u);
+            if (last || conv) {
+                if (threadIdx.x == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt, !use_hi && pc.n_hi > 0u, 6);
                 kind = ST_DONE;
             }
             ++it;
@@ -2106,7 +2075,7 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
     PwppPatchRec *rec = Bt.recs + (size_t)f * P.num_bins + bin;
     const PwppFrameDesc fd = Bt.frames[f];
     const PatchRef pts = patch_ref(Bt, fd, pc);  // (always both parts: a patch this large is rare)
-    int *plist = Bt.plist + fd.sbase + pc.off_lo;
+    uint8_t *frame_member = Bt.member + fd.mbase;
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const double cutoff = P.margin * sensor_height;  // ref :90
     const bool use_cutoff = zone == 0;
@@ -2119,8 +2088,6 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
             sh.sv[k] = init ? init->sv[k] : 0.0f;
         }
         sh.d = init ? init->d : 0.0;
-        sh.cnt_g = 0;
-        sh.cnt_ng = 0;
     }
     __syncthreads();
     bool fitted = init != nullptr;  // (with the plane fitted before this patch in hand nothing is missing)
@@ -2203,6 +2170,15 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
         return;
     }
     const int ln = lane_id();
+    // The split goes to the membership plane in the layout of a 64-lane fit row (pwpp_dev.h: byte c * 64 + j, bit k = point
+    // c * 512 + (k / 4) * 256 + 4 j + k % 4 of the part).  This kernel walks a patch point by point, so the last round sets single
+    // bits (atomicOr on the word around the byte) in areas zeroed first -- slow, and irrelevant: the path is rare.
+    const unsigned mo[2] = {member_offset(pc.off_lo, PWPP_PART_LO(bin)), member_offset(pc.off_hi, PWPP_PART_HI(bin))};
+    const unsigned mwords[2] = {((pc.n_lo + 511u) >> 9) * 16u, ((pc.n_hi + 511u) >> 9) * 16u};
+    for (int h = 0; h < 2; ++h)
+        for (unsigned wd = threadIdx.x; wd < mwords[h]; wd += kBlock) reinterpret_cast<uint32_t *>(frame_member + mo[h])[wd] = 0u;
+    __threadfence_block();
+    __syncthreads();
     for (int it = 0; it < P.num_iter; ++it) {
         const bool last = it == P.num_iter - 1;
         const float nx = sh.normal[0], ny = sh.normal[1], nz = sh.normal[2];
@@ -2227,23 +2203,12 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
             if (g) m.add(xy.x, xy.y, z, scale, org);
             if (last) {
                 if (__any(g && !(z >= org.zlo && z <= org.zhi)) && ln == 0) flag_clamped(Bt, f);
-                // regionwise_ground_ from the front, regionwise_nonground_ (R-VPF strips included,
-                // ref :500,532) from the back of this patch's slot range
-                const int idx = in ? pts.idx[sl] : 0;
-                const unsigned long long mg = __ballot(g);
-                const unsigned long long mn = __ballot(in && !g);
-                const unsigned long long lt = (1ull << ln) - 1ull;
-                unsigned bg = 0, bn = 0;
-                if (ln == 0) {
-                    if (mg) bg = atomicAdd(&sh.cnt_g, (unsigned)__popcll(mg));
-                    if (mn) bn = atomicAdd(&sh.cnt_ng, (unsigned)__popcll(mn));
+                if (g) {  // regionwise_ground_ (ref :529): the point's bit
+                    const bool hi = i >= pc.n_lo;
+                    const unsigned ip = hi ? i - pc.n_lo : i, r = ip & 511u;
+                    const unsigned byte = mo[hi ? 1 : 0] + (ip >> 9) * 64u + ((r >> 2) & 63u), k = ((r >> 8) << 2) | (r & 3u);
+                    atomicOr(reinterpret_cast<unsigned *>(frame_member + (byte & ~3u)), 1u << (8u * (byte & 3u) + k));
                 }
-                bg = __shfl(bg, 0, 64);
-                bn = __shfl(bn, 0, 64);
-                if (g)
-                    plist[bg + (unsigned)__popcll(mg & lt)] = idx;
-                else if (in)
-                    plist[n - 1u - (bn + (unsigned)__popcll(mn & lt))] = nonground_entry(idx, z);
             }
         }
         reduce_and_fit(sh, m, P.fxp_shift, pc.ox, pc.oy, z0, pts, true, P.th_dist, Bt.debug);  // ref :537-542
@@ -2261,10 +2226,10 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
         rec->sv[2] = sh.sv[2];
         rec->d = sh.d;
         rec->n_points = (int)n;
-        rec->n_ground = (int)sh.cnt_g;
-        rec->n_nonground = (int)(n - sh.cnt_g);
+        rec->n_ground = (int)sh.last_n;  // (the set the final plane was fitted on: the last round's ground set)
+        rec->n_nonground = (int)(n - (unsigned)sh.last_n);
         rec->decision = 0;
-        rec->valid = 1;
+        rec->valid = 1 | (6 << 3);  // the split is in the membership plane, 64-lane layout
     }
 }
 

@@ -1519,7 +1519,6 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, bool keep_
         off_hi = Bt.part_off[(size_t)f * PWPP_NUM_PARTS(B) + (seg < B ? PWPP_PART_HI(seg) : B + seg)];
     }
     const PwppPatchRec *rec = Bt.recs + (size_t)f * B + (seg < B ? seg : 0);
-    const unsigned ng = (unsigned)rec->n_ground;
     const int rec_valid = rec->valid;
     if (n == 0) return;
     if (da == kAwaitsFixup) return;  // K5 left the frame alone: the host sees the flag in the mirror and finishes it (k_fit_fixup)
@@ -1547,7 +1546,8 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, bool keep_
     }
     const unsigned n_v = n, n_lo_v = n_lo, off_v = off, off_hi_v = off_hi, da_v = da, db_v = db;
     const int member_lg = __builtin_amdgcn_readfirstlane((rec_valid >> 3) & 7);
-    if (member_lg) {
+    if (member_lg == 0) return;  // (no fit kernel leaves a patch without the layout of its bits)
+    {
         // (everything about the bin is the same in all lanes: said explicitly, so that counts, offsets and the pointers built
         // from them live in scalar registers -- the kernel must keep eight waves per SIMD)
         const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)n_v), n_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)n_lo_v);
@@ -1671,42 +1671,6 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, bool keep_
             for (unsigned t = L; t < nn; t += kEmitBlock) on[t] = s_stage[511u - t];
             g_before += gb;
             next_b = b + 1u;
-        }
-        return;
-    }
-    // A patch: the last fit pass left the ground candidates at the front of the bin's plist range and the others at its
-    // back.  If that pass skipped the high part (rec.valid bit 1), the n - n_lo entries in between were never written:
-    // they are the high part's points, all of them non-ground, taken from the part itself.
-    const int *src = Bt.plist + fd.sbase + off;
-    const unsigned n_gap = (rec_valid & 2) ? n - n_lo : 0u;
-    const float *z_hi = Bt.sorted_z + fd.sbase + off_hi;
-    for (unsigned i0 = part * (kU * kEmitBlock) + threadIdx.x; i0 < n; i0 += parts * (kU * kEmitBlock)) {
-        int v[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const unsigned i = i0 + u * kEmitBlock;
-            v[u] = 0;
-            if (i < n) {
-                if (i - ng < n_gap) {  // (i >= ng and i < ng + n_gap)
-                    v[u] = idx_hi[i - ng];
-                    if (keep_cat) {  // the R-VPF round that removed the point, if one did (see nonground_entry, pwpp_fit.hip)
-                        const unsigned zb = __float_as_uint(z_hi[i - ng]);
-                        if ((int)zb > 0x7fc00000) v[u] |= (int)((zb & 0xffu) << 24);
-                    }
-                } else {
-                    v[u] = src[i];
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const unsigned i = i0 + u * kEmitBlock;
-            if (i < n) {
-                if (i < ng)
-                    out[da + i] = v[u];
-                else
-                    out[db + (i - ng)] = keep_cat ? v[u] : (v[u] & 0x00ffffff);  // bits 24-31: R-VPF round (k_order_sublists)
-            }
         }
     }
 }
