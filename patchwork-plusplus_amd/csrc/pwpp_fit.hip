@@ -44,6 +44,9 @@ constexpr int kPPT = 8;  // points per lane held in registers
 #ifndef PWPP_W64_OCC
 #define PWPP_W64_OCC 3  // waves per SIMD the 64-lane fit kernel is compiled for
 #endif
+#ifndef PWPP_W16_OCC
+#define PWPP_W16_OCC 4  // waves per SIMD the 16-lane fit kernel is compiled for (3: no spills, slower -- profiles/r04_experiments.txt)
+#endif
 #ifndef PWPP_FIT_PREFETCH
 #define PWPP_FIT_PREFETCH 0
 #endif
@@ -1086,7 +1089,7 @@ struct W64Shared {
 // Moments per patch in LDS: rows of 16 lanes only see patches below 2048 points, whose ten totals fit
 // int64; 64-lane rows leave sixteen values (second moments as 32-bit halves, Row<64>::reduce16_scatter).
 template <int G, int PW>
-__global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : 4) void k_fit_w64(PwppBatch Bt, int b_lo, int b_hi) {
+__global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : PWPP_W16_OCC) void k_fit_w64(PwppBatch Bt, int b_lo, int b_hi) {
     // ONE WAVE PER WORKGROUP: the waves never talk to each other, and a workgroup of four only starts when a CU has
     // room for all four at once -- with waves of very different lifetimes the slots of the early finishers stood empty
     // (27 % of the wave slots of k_fit_w64<64,2>, profiles/).

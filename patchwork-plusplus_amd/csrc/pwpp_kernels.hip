@@ -32,6 +32,8 @@
 // the result does not depend on thread count, wave scheduling or the order the scatter
 // atomics happened to produce, and oracle/pwpp_oracle.cpp (PWO_ARITH_FXP) reproduces it
 // bit for bit on the CPU.
+#include <type_traits>
+
 #include "pwpp_common.hpp"
 
 namespace {
@@ -1496,9 +1498,11 @@ constexpr int kEmitBlock = 64;
 // and unconditionally -- nine independent loads, one round trip; a load behind a branch is a round trip of its own
 // (single frame 13.2 -> 4.8 us together with eight waves per bin).  Big batches keep the early exit of the empty bins
 // in front of the other loads: with 500 k waves the loads of those that have nothing to do cost more (0.23 -> 0.27 ms).
-template <bool EAGER>
-__global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, bool keep_cat) {
+template <bool EAGER, bool KEYS>
+__global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, unsigned long long *keys /* reference-order mode: the sort keys of k_order_sublists, indexed like out_idx; else null */) {
     __shared__ int s_stage[512];  // (membership-plane path: the two lists of a block of 512 points, compacted before they are written)
+    __shared__ unsigned s_zk[KEYS ? 512 : 1];  // reference-order mode: the height keys of the staged entries
+    constexpr bool keep_cat = KEYS;  // (an instantiation of its own: the default path keeps its registers)
     const int f = blockIdx.y, seg = blockIdx.x;
     // the frame's counters are final since K5: hand them to the host through its pinned mirror (eight posted
     // PCIe writes) instead of a copy command behind the pipeline (a dispatch of its own, ~9 us of a single frame)
@@ -1597,6 +1601,7 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, bool keep_
             // points with consecutive lanes j, the same chunk c and the same bit k: ONE aligned word of the plane per half.
             const unsigned L = threadIdx.x;
             int4 v[2];
+            unsigned zk[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};  // reference-order mode: z_key of every point's height
             unsigned mem4[2] = {0u, 0u};  // bit b = point b of the quad is ground
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -1613,13 +1618,25 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, bool keep_
                             mem4[q] = (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u);
                         }
                     }
-                    if (keep_cat) {  // the R-VPF round that removed a point, if one did (see nonground_entry, pwpp_fit.hip)
+                    if (keep_cat) {
+                        // Reference-order mode: this kernel hands k_order_sublists complete sort keys -- (R-VPF round, height, cloud
+                        // index) -- from the z plane it can read in 16-byte pieces; gathered from the cloud entry by entry in the sort
+                        // kernel they were most of its time.  A point R-VPF removed carries the round in place of its height
+                        // (strip_point, pwpp_fit.hip): its true height is fetched from the cloud (rare).
                         const float4 zz = *reinterpret_cast<const float4 *>(pz + p0);
-                        const unsigned zb[4] = {__float_as_uint(zz.x), __float_as_uint(zz.y), __float_as_uint(zz.z), __float_as_uint(zz.w)};
+                        const float zf[4] = {zz.x, zz.y, zz.z, zz.w};
                         int *vv = reinterpret_cast<int *>(&v[q]);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if ((int)zb[t] > 0x7fc00000) vv[t] |= (int)((zb[t] & 0xffu) << 24);
+                        for (int t = 0; t < 4; ++t) {
+                            const unsigned zb = __float_as_uint(zf[t]);
+                            float zt = zf[t];
+                            if ((int)zb > 0x7fc00000) {
+                                float x, y, w;
+                                if (p0 + (unsigned)t < pn) load_point(fd, vv[t], x, y, zt, w);
+                                vv[t] |= (int)((zb & 0xffu) << 24);
+                            }
+                            zk[q][t] = z_key(zt);
+                        }
                     }
                 }
             }
@@ -1655,20 +1672,33 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, bool keep_
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if ((unsigned)t < inq) {
-                        if (mem4[q] >> t & 1u)
+                        if (mem4[q] >> t & 1u) {
+                            if (keep_cat) s_zk[gr] = zk[q][t];
                             s_stage[gr++] = vv[t];
-                        else
+                        } else {
+                            if (keep_cat) s_zk[511u - nr] = zk[q][t];
                             s_stage[511u - (nr++)] = vv[t];
+                        }
                     }
                 }
             }
             __syncthreads();
             int *og = out + (da + g_before), *on = out + (db + (p_before - g_before));  // (scalar bases, 32-bit lane offsets)
             const unsigned nn = nbk - gb;
+            if (!keep_cat) {
 #pragma unroll 2
-            for (unsigned t = L; t < gb; t += kEmitBlock) og[t] = s_stage[t];
+                for (unsigned t = L; t < gb; t += kEmitBlock) og[t] = s_stage[t];
 #pragma unroll 2
-            for (unsigned t = L; t < nn; t += kEmitBlock) on[t] = s_stage[511u - t];
+                for (unsigned t = L; t < nn; t += kEmitBlock) on[t] = s_stage[511u - t];
+            } else {  // key = category (0 for ground; the R-VPF round, or 255 for the points of the final split) | height | cloud index
+                unsigned long long *kg = keys + fd.base + (da + g_before), *kn = keys + fd.base + (db + (p_before - g_before));
+                // (out_idx itself is written by k_order_sublists, which sorts every one of these lists)
+                for (unsigned t = L; t < gb; t += kEmitBlock) kg[t] = ((unsigned long long)s_zk[t] << 24) | (unsigned long long)(unsigned)s_stage[t];
+                for (unsigned t = L; t < nn; t += kEmitBlock) {
+                    const unsigned e = (unsigned)s_stage[511u - t], round = e >> 24;
+                    kn[t] = ((unsigned long long)(round ? round : 255u) << 56) | ((unsigned long long)s_zk[511u - t] << 24) | (unsigned long long)(e & 0x00ffffffu);
+                }
+            }
             g_before += gb;
             next_b = b + 1u;
         }
@@ -1778,11 +1808,126 @@ __device__ __forceinline__ void ord_tile_sort(unsigned long long *s_key, int len
         }
     }
 }
+// The lists above 256 entries (the ~100 ground / non-ground lists of a frame's big bins: 3.4 of the 3.9 ms the mode added to
+// a 1024-frame batch while every one of them went through the bitonic network, padded to 2048 or 4096 keys) are first offered
+// to a DISTRIBUTION sort: the heights of a list spread over a narrow range fairly evenly, so 1024 buckets by height --
+// floor((z - zmin) * 1024 / (zmax - zmin)), a chain of monotone float operations, hence consistent with the key order -- hold a
+// key or two each; count, scan, scatter, then every bucket is put in order by insertion on the full 64-bit key.  O(n) instead of
+// O(n log^2 n) compare-exchanges.  Declined (the network takes the tile as before) when the list mixes R-VPF categories,
+// holds a non-finite height, has one height only, or some bucket gets more than kOrdMaxBucket keys -- cloud-order lists
+// (small bins, pseudo-bins: one "height") always are.
+#ifndef PWPP_ORDER_BUCKETS
+#define PWPP_ORDER_BUCKETS 1
+#endif
+constexpr int kOrdBuckets = 1024, kOrdMaxBucket = 32;
+// load(i): key i of the tile (from global memory: read three times, coalesced); store(pos, key): the key's final place.
+// lds_out[len], cnt / start[kOrdBuckets], red[4][4]: LDS.  Returns false (nothing stored) when the tile is declined.
+template <int BLOCK, class Load, class Store>
+__device__ __forceinline__ bool ord_bucket_sort(Load load, Store store, unsigned long long *lds_out, unsigned *cnt, unsigned *start, unsigned (*red)[4], int len) {
+    static_assert(BLOCK == 256 && kOrdBuckets == 4 * BLOCK, "four buckets per thread in the scan");
+    const int t = threadIdx.x;
+    unsigned zlo = 0xffffffffu, zhi = 0u, clo = 255u, chi = 0u;
+#pragma unroll 4
+    for (int i = t; i < len; i += BLOCK) {
+        const unsigned long long k = load(i);
+        const unsigned zk = (unsigned)(k >> 24), c = (unsigned)(k >> 56);
+        zlo = zk < zlo ? zk : zlo;
+        zhi = zk > zhi ? zk : zhi;
+        clo = c < clo ? c : clo;
+        chi = c > chi ? c : chi;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned a = (unsigned)__shfl_xor((int)zlo, o, 64), b = (unsigned)__shfl_xor((int)zhi, o, 64);
+        const unsigned c = (unsigned)__shfl_xor((int)clo, o, 64), d = (unsigned)__shfl_xor((int)chi, o, 64);
+        zlo = a < zlo ? a : zlo;
+        zhi = b > zhi ? b : zhi;
+        clo = c < clo ? c : clo;
+        chi = d > chi ? d : chi;
+    }
+    if (lane_id() == 0) {
+        red[wave_id()][0] = zlo;
+        red[wave_id()][1] = zhi;
+        red[wave_id()][2] = clo;
+        red[wave_id()][3] = chi;
+    }
+    for (int i = t; i < kOrdBuckets; i += BLOCK) cnt[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        zlo = red[w][0] < zlo ? red[w][0] : zlo;
+        zhi = red[w][1] > zhi ? red[w][1] : zhi;
+        clo = red[w][2] < clo ? red[w][2] : clo;
+        chi = red[w][3] > chi ? red[w][3] : chi;
+    }
+    __syncthreads();  // (red is used again below)
+    // (everything below is the same in every thread)
+    if (clo != chi) return false;                                    // several R-VPF categories
+    if (zlo <= 0x007fffffu || zhi >= 0xff800000u || zlo == zhi) return false;  // a non-finite height (z_key of -inf / +inf, NaN beyond) or one height
+    const float fz0 = key_z(zlo), range = key_z(zhi) - fz0;
+    const float scale = (float)kOrdBuckets / range;
+    if (!(scale <= FLT_MAX) || !(scale > 0.0f)) return false;
+    auto bucket = [&](unsigned long long k) -> int {  // monotone in the height: rounded subtraction, product with a positive constant, truncation
+        const float v = (key_z((unsigned)(k >> 24)) - fz0) * scale;
+        const int b = (int)v;
+        return b < 0 ? 0 : (b > kOrdBuckets - 1 ? kOrdBuckets - 1 : b);
+    };
+#pragma unroll 4
+    for (int i = t; i < len; i += BLOCK) atomicAdd(&cnt[bucket(load(i))], 1u);
+    __syncthreads();
+    const unsigned c0 = cnt[4 * t], c1 = cnt[4 * t + 1], c2 = cnt[4 * t + 2], c3 = cnt[4 * t + 3];
+    const unsigned mine = c0 + c1 + c2 + c3;
+    const unsigned incl = wave_incl_scan(mine);
+    if (lane_id() == 63) red[wave_id()][0] = incl;
+    const int skew = c0 > (unsigned)kOrdMaxBucket || c1 > (unsigned)kOrdMaxBucket || c2 > (unsigned)kOrdMaxBucket || c3 > (unsigned)kOrdMaxBucket;
+    if (__syncthreads_or(skew)) return false;
+    unsigned before = 0;
+    for (int w = 0; w < wave_id(); ++w) before += red[w][0];
+    unsigned run = before + incl - mine;
+    start[4 * t] = run;
+    start[4 * t + 1] = run + c0;
+    start[4 * t + 2] = run + c0 + c1;
+    start[4 * t + 3] = run + c0 + c1 + c2;
+    cnt[4 * t] = cnt[4 * t + 1] = cnt[4 * t + 2] = cnt[4 * t + 3] = 0u;  // (now the buckets' cursors)
+    __syncthreads();
+#pragma unroll 4
+    for (int i = t; i < len; i += BLOCK) {
+        const unsigned long long k = load(i);
+        const int b = bucket(k);
+        lds_out[start[b] + atomicAdd(&cnt[b], 1u)] = k;
+    }
+    __syncthreads();
+    // order inside the buckets: every key counts the smaller keys of its bucket (independent reads, a thread per KEY -- an
+    // insertion sort per bucket by one thread is a chain of dependent LDS round trips as long as the fullest bucket squared)
+    // and goes straight to its final place.  Keys are distinct (they end in the cloud index).
+#pragma unroll 2
+    for (int i = t; i < len; i += BLOCK) {
+        const unsigned long long k = lds_out[i];
+        const int b = bucket(k);
+        const unsigned lo = start[b], n = cnt[b];
+        unsigned rank = 0;
+        for (unsigned j = 0; j < n; ++j) rank += lds_out[lo + j] < k ? 1u : 0u;
+        store(lo + rank, k);
+    }
+    __syncthreads();
+    return true;
+}
 // Two instantiations: <64, 256, 0> one wave per bin for the short lists (most of them: ~250 points),
 // <256, 4096, 256> a workgroup for the lists above 256 entries.  Each handles the lists in ITS range.
 template <int BLOCK, int kOrdTile, int kMinLen>
 __global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned long long *scr_a, unsigned long long *scr_b) {
-    __shared__ unsigned long long s_key[kOrdTile + kOrdTile / 16];  // (padded: ord_at)
+    constexpr bool kBuckets = PWPP_ORDER_BUCKETS && BLOCK == 256 && kOrdTile == 4096;  // the workgroup instantiation tries the distribution sort first
+    // ONE piece of LDS for both sorts (40 KB: four workgroups per CU): the network's padded tile (ord_at), or the distribution
+    // sort's scatter array + bucket counters + bucket starts -- it reads its keys from global memory
+    constexpr int kOutSlots = 4096 - 48;  // (40 KB less the few hundred bytes the compiler's own LDS takes: FOUR workgroups per CU, not three)
+    constexpr int kRaw = kBuckets ? kOutSlots + kOrdBuckets : kOrdTile + kOrdTile / 16;
+    static_assert(kRaw >= kOrdTile + kOrdTile / 16, "the network's tile fits");
+    __shared__ unsigned long long s_raw[kRaw];
+    unsigned long long *s_key = s_raw;
+    // (the distribution sort takes tiles of up to kBucketTile keys: the last sixteen slots of its scatter array hold the four waves'
+    // partial results -- 40 KB exactly, not a byte more, or only three workgroups fit a CU)
+    constexpr int kBucketTile = kOutSlots - 16;
+    unsigned(*s_red)[4] = reinterpret_cast<unsigned(*)[4]>(s_raw + kBucketTile);
     const int f = blockIdx.y, seg = blockIdx.x;
     const PwppDevParams &P = Bt.P;
     const int B = P.num_bins, NB = B + 2;
@@ -1797,23 +1942,21 @@ __global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned
         const unsigned start = which == 0 ? Bt.dst_a[(size_t)f * NB + seg] : Bt.dst_b[(size_t)f * NB + seg];
         const int len = (int)(which == 0 ? ng : n - ng);
         if (len < 1 || len <= kMinLen || (kMinLen == 0 && len > kOrdTile)) continue;  // not this instantiation's range
-        auto make_key = [&](int entry) -> unsigned long long {
-            const int idx = entry & 0x00ffffff;
-            if (whole) return (unsigned long long)(unsigned)idx;  // cloud order
-            float x, y, z, w;
-            load_point(fd, idx, x, y, z, w);
-            unsigned cat = 0;
-            if (which == 1) {
-                cat = (unsigned)entry >> 24;      // R-VPF round (1-based) or 0
-                cat = cat ? cat : 255u;           // the points of the final split come last
-            }
-            return ((unsigned long long)cat << 56) | ((unsigned long long)z_key(z) << 24) | (unsigned long long)(unsigned)idx;
-        };
+        // the keys: k_emit left (category, height, cloud index) of every patch entry in scr_a, indexed like out_idx; a small bin or
+        // pseudo-bin is in cloud order: its key is the index itself
+        const unsigned long long *keys = scr_a + fd.base + start;
+        auto load_key = [&](int i) -> unsigned long long { return whole ? (unsigned long long)(unsigned)(out[start + i] & 0x00ffffff) : keys[i]; };
         if (len <= kOrdTile) {
-            for (int i = threadIdx.x; i < len; i += BLOCK) s_key[ord_at(i)] = make_key(out[start + i]);
-            __syncthreads();
-            ord_tile_sort<BLOCK>(s_key, len);
-            for (int i = threadIdx.x; i < len; i += BLOCK) out[start + i] = (int)(s_key[ord_at(i)] & 0x00ffffffull);
+            bool done = false;
+            if constexpr (kBuckets)
+                if (len <= kBucketTile) done = ord_bucket_sort<256>(load_key, [&](unsigned pos, unsigned long long k) { out[start + pos] = (int)(k & 0x00ffffffull); }, s_raw,
+                                            reinterpret_cast<unsigned *>(s_raw + kOutSlots), reinterpret_cast<unsigned *>(s_raw + kOutSlots) + kOrdBuckets, s_red, len);
+            if (!done) {
+                for (int i = threadIdx.x; i < len; i += BLOCK) s_key[ord_at(i)] = load_key(i);
+                __syncthreads();
+                ord_tile_sort<BLOCK>(s_key, len);
+                for (int i = threadIdx.x; i < len; i += BLOCK) out[start + i] = (int)(s_key[ord_at(i)] & 0x00ffffffull);
+            }
             __syncthreads();
             continue;
         }
@@ -1821,10 +1964,16 @@ __global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned
         unsigned long long *a = scr_a + fd.base + start, *b = scr_b + fd.base + start;
         for (int t0 = 0; t0 < len; t0 += kOrdTile) {
             const int tl = len - t0 < kOrdTile ? len - t0 : kOrdTile;
-            for (int i = threadIdx.x; i < tl; i += BLOCK) s_key[ord_at(i)] = make_key(out[start + t0 + i]);
-            __syncthreads();
-            ord_tile_sort<BLOCK>(s_key, tl);
-            for (int i = threadIdx.x; i < tl; i += BLOCK) a[t0 + i] = s_key[ord_at(i)];
+            bool done = false;
+            if constexpr (kBuckets)
+                if (tl <= kBucketTile) done = ord_bucket_sort<256>([&](int i) { return load_key(t0 + i); }, [&](unsigned pos, unsigned long long k) { a[t0 + pos] = k; }, s_raw,
+                                            reinterpret_cast<unsigned *>(s_raw + kOutSlots), reinterpret_cast<unsigned *>(s_raw + kOutSlots) + kOrdBuckets, s_red, tl);
+            if (!done) {
+                for (int i = threadIdx.x; i < tl; i += BLOCK) s_key[ord_at(i)] = load_key(t0 + i);
+                __syncthreads();
+                ord_tile_sort<BLOCK>(s_key, tl);
+                for (int i = threadIdx.x; i < tl; i += BLOCK) a[t0 + i] = s_key[ord_at(i)];
+            }
             __syncthreads();
         }
         for (int width = kOrdTile; width < len; width <<= 1) {
@@ -1977,8 +2126,10 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
     }
     if (stages & 4) {
         const dim3 egrid(NB, F, B.emit_parts > 1 ? B.emit_parts : 1);
-        if (F <= 64) hipLaunchKernelGGL(k_emit<true>, egrid, dim3(kEmitBlock), 0, stream, B, order_a != nullptr);
-        else hipLaunchKernelGGL(k_emit<false>, egrid, dim3(kEmitBlock), 0, stream, B, order_a != nullptr);
+        if (F <= 64 && order_a) hipLaunchKernelGGL((k_emit<true, true>), egrid, dim3(kEmitBlock), 0, stream, B, order_a);
+        else if (F <= 64) hipLaunchKernelGGL((k_emit<true, false>), egrid, dim3(kEmitBlock), 0, stream, B, order_a);
+        else if (order_a) hipLaunchKernelGGL((k_emit<false, true>), egrid, dim3(kEmitBlock), 0, stream, B, order_a);
+        else hipLaunchKernelGGL((k_emit<false, false>), egrid, dim3(kEmitBlock), 0, stream, B, order_a);
         if (ev) (void)hipEventRecord(ev[11], stream);
         if (order_a) {
             hipLaunchKernelGGL((k_order_sublists<64, 256, 0>), dim3(NB, F), dim3(64), 0, stream, B, order_a, order_b);
