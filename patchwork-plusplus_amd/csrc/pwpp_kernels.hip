@@ -413,6 +413,11 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     __shared__ unsigned s_pc[PWPP_NUM_PARTS(PWPP_MAX_BINS)], s_po[PWPP_NUM_PARTS(PWPP_MAX_BINS)];
     const int f = blockIdx.x;
     const int B = Bt.P.num_bins, NB = B + 2, NP = PWPP_NUM_PARTS(B);
+    int probe_i = 16;  // timing probes (debug_flags & 8): slots 16.. of the probe array (tools/k5_chain.py)
+    auto probe = [&]() {
+        if ((Bt.debug & 8) && blockIdx.x == 0 && threadIdx.x == 0 && probe_i < 32) Bt.dbg[probe_i++] = wall_clock64();
+    };
+    probe();
     unsigned *pcnt = Bt.part_count + (size_t)f * NP;
     unsigned *poff = Bt.part_off + (size_t)f * NP;
     if (Bt.cap_off) {  // one-pass binning: fixed segments; a part never reports more points than its segment holds
@@ -462,6 +467,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
         }
     }
     __syncthreads();
+    probe();  // 1: part counts and offsets
     // what the host sizes the one-pass segments of the NEXT batches from (an overflowed part reports its clamped
     // count here; the exact redo that follows reports the true one)
     for (int p = threadIdx.x; p < NP; p += kBlock)
@@ -481,6 +487,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
         Bt.results[f].n_oor = (int)s_pc[2 * B + 1];
     }
     __syncthreads();
+    probe();  // 2: observed maxima, bin counts
     // patches of this frame sorted by size bucket (work lists of the K4 kernels)
     __shared__ unsigned s_cnt[PWPP_NUM_BUCKETS], s_start[PWPP_NUM_BUCKETS + 1], s_cur[PWPP_NUM_BUCKETS];
     if (threadIdx.x < PWPP_NUM_BUCKETS) {
@@ -502,6 +509,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
         atomicAdd(&s_cnt[pwpp_size_bucket(n)], 1u);
     }
     __syncthreads();
+    probe();  // 3: bucket histogram
     if (threadIdx.x < 64) {  // exclusive prefix over the 96 buckets by one wave, two buckets per lane (a serial loop of 96 LDS
                              // round trips by one thread was 1.4 us of a single frame's chain)
         static_assert(PWPP_NUM_BUCKETS <= 128, "two buckets per lane");
@@ -521,6 +529,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
         const int c = pwpp_size_bucket(n);
         Bt.cls_list[(size_t)f * B + s_start[c] + atomicAdd(&s_cur[c], 1u)] = (uint16_t)b;
     }
+    probe();  // 4: end
 }
 
 // ------------------------------------------------------------------------------------------
@@ -956,7 +965,15 @@ __global__ __launch_bounds__(64) void k_gle_tgr_seq(PwppBatch Bt) {
 // traversal order plus a 4-iteration loop over the rings of interest.
 // Every double sum keeps the reference's summation order (sequential over <= one ring).
 // ------------------------------------------------------------------------------------------
-constexpr int kGlePer = PWPP_MAX_BINS / kBlock;  // consecutive bins per thread
+constexpr int kGlePer = PWPP_MAX_BINS / kBlock;  // consecutive bins per thread, largest model
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
 
 template <int K>
 __device__ __forceinline__ void block_excl_scan(unsigned v[K], unsigned (*s_wave)[K], unsigned total[K]) {
@@ -986,14 +1003,25 @@ __device__ __forceinline__ void block_excl_scan(unsigned v[K], unsigned (*s_wave
 // LAT (a few dozen frames: every workgroup has a CU and its 160 KB of LDS to itself): the staging tile of
 // the threshold statistics holds a whole 1000-entry history per row, so each of the two passes is ONE
 // stage instead of three; otherwise the tile lives in the retired prefix arrays (32 KB).
-template <bool LAT>
+// PER: consecutive bins per thread the kernel is compiled for (2 covers the default 504-bin model: every per-bin loop, and the
+// registers of the patch records, four times shorter than for the largest model)
+template <bool LAT, int PER>
 __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
+    // timing probes (debug_flags & 8): 100 MHz ticks along the chain of frame 0, slots 32.. of the probe array (tools/k5_chain.py)
+    int probe_i = 32;
+    auto probe = [&]() {
+        if ((Bt.debug & 8) && blockIdx.x == 0 && threadIdx.x == 0 && probe_i < 60) Bt.dbg[probe_i++] = wall_clock64();
+    };
+    probe();
     clear_next_counters(Bt, blockIdx.x, kBlock);
+    probe();
     __shared__ uint8_t s_dec[PWPP_MAX_BINS];
     __shared__ __attribute__((aligned(16))) unsigned s_e[4][PWPP_MAX_BINS + 1];   // exclusive prefixes: gmain, gtail, nmain, ntail;
                                                                                 // later the staging tile of the histories
     __shared__ unsigned s_epush[PWPP_MAX_NEAR_BINS + 1];
     __shared__ double s_pseq[PWPP_MAX_NEAR_BINS];     // flatness of the pushed patches, in push order
+    __shared__ double s_pelev[LAT ? PWPP_MAX_NEAR_BINS : 1];  // their elevations (latency variant: a frame that starts from empty histories
+                                                              // takes its threshold statistics from these two arrays, see below)
     __shared__ int s_dropped;                         // a history slab was full (never, unless the host failed to grow it)
     __shared__ unsigned s_wave[kBlock / 64][4];
     __shared__ PwppStateScalar s_st;
@@ -1053,11 +1081,11 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     // unconditionally: the kernel is a latency chain, every dependent round trip costs ~1 us.
     const int per = (B + kBlock - 1) / kBlock;
     const int b0 = threadIdx.x * per;
-    unsigned nn[kGlePer];
-    PwppPatchRec rr[kGlePer];
+    unsigned nn[PER];
+    PwppPatchRec rr[PER];
     int awaits = 0;
 #pragma unroll
-    for (int j = 0; j < kGlePer; ++j) {
+    for (int j = 0; j < PER; ++j) {
         const int bin = b0 + j;
         const bool have = j < per && bin < B;
         nn[j] = have ? cnt[bin] : 0u;
@@ -1068,6 +1096,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         for (int b = threadIdx.x; b < NB; b += kBlock) dst_a[b] = kAwaitsFixup;
         return;
     }
+    probe();  // 2: records and counts are in
     if (fd.state_in >= 0 && fd.state_in != fd.state_out) {  // carry the histories over
         const double *hist_in = Bt.st_hist + (size_t)fd.state_in * 8 * P.hist_cap;
         for (int w = 0; w < 8; ++w) {
@@ -1079,17 +1108,18 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
 
     // ---- pass 1: per-bin GLE (ref :217-282) ------------------------------------------------
     unsigned a_patch = 0, a_push = 0;
-    uint8_t dec[kGlePer];
-    int ci_of[kGlePer];
+    int my_last = -1;  // this thread's last fitted bin -> s_last_patch: one LDS atomic per WAVE (256 on one address serialise: 1.5 us)
+    uint8_t dec[PER];
+    int ci_of[PER];
 #pragma unroll
-    for (int j = 0; j < kGlePer; ++j) {
+    for (int j = 0; j < PER; ++j) {
         const int bin = b0 + j;
         dec[j] = 0;
         ci_of[j] = 0;
         if (j >= per || bin >= B) continue;
         const unsigned n = nn[j];
         if ((uint64_t)n < P.min_pts) continue;  // small bin
-        atomicMax(&s_last_patch, bin);  // (an LDS atomic per fitted bin: two per thread with the default model)
+        my_last = bin > my_last ? bin : my_last;  // (bins ascend with j)
         // concentric index of the bin
         const int zone = bin < P.bin_base[1] ? 0 : (bin < P.bin_base[2] ? 1 : (bin < P.bin_base[3] ? 2 : 3));
         int ci = (bin - P.bin_base[zone]) / P.sectors[zone];
@@ -1130,11 +1160,13 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         if ((d & 0x7f) == 5) s_ring_cand[ci] = 1u;  // benign race: all writers store 1
     }
     {
+        const int wave_last = (int)wave_max_i32(my_last);
+        if (lane_id() == 0 && wave_last >= 0) atomicMax(&s_last_patch, wave_last);
         unsigned v[2] = {a_patch, a_push}, tot[2];
         block_excl_scan<2>(v, reinterpret_cast<unsigned(*)[2]>(&s_wave[0][0]), tot);
         unsigned p_patch = v[0], p_push = v[1];
 #pragma unroll
-        for (int j = 0; j < kGlePer; ++j) {
+        for (int j = 0; j < PER; ++j) {
             const int bin = b0 + j;
             if (j >= per) continue;
             if (bin < near_end) s_epush[bin] = p_push;
@@ -1151,6 +1183,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
                 if (r.sv[1] < fmin3) fmin3 = r.sv[1];
                 if (r.sv[2] < fmin3) fmin3 = r.sv[2];
                 s_pseq[p_push] = (double)fmin3;
+                if (LAT) s_pelev[p_push] = (double)r.mean[2];
                 ++p_push;
             }
         }
@@ -1160,9 +1193,10 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         }
     }
     __syncthreads();
+    probe();  // 3: decisions, first scan, centres / normals written
     // history pushes in sector order (ref :255-256): position inside the ring = prefix difference
 #pragma unroll
-    for (int j = 0; j < kGlePer; ++j) {
+    for (int j = 0; j < PER; ++j) {
         const int bin = b0 + j;
         if (!(dec[j] & 0x80)) continue;
         const int ci = ci_of[j];
@@ -1199,6 +1233,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         s_ring_std[threadIdx.x] = sd;
     }
     __syncthreads();
+    probe();  // 4: history pushes, ring statistics
 
     // The histories are complete now (this frame's pushes included): start fetching their first tile
     // for the threshold statistics at the end of the kernel, the loads fly while TGR and the list
@@ -1216,6 +1251,12 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     }
     const int my_len = threadIdx.x < 8 ? len_w[threadIdx.x & 7] : 0;
     const int ntiles = (maxlen + kHistTile - 1) / kHistTile;
+    // A frame that starts from EMPTY histories (fresh state: a single frame, the first frame of a stream) has just written all
+    // their entries itself, and they are still in LDS in push order (s_pelev, s_pseq): the threshold statistics take them from
+    // there -- no read-back of the histories from global memory, no staging tiles (5 of 22 us of a single frame).
+    bool fresh_hist = LAT && s_dropped == 0;
+#pragma unroll
+    for (int k = 0; k < PWPP_MAX_ROI; ++k) fresh_hist = fresh_hist && s_len0[0][k] == 0 && s_len0[1][k] == 0;
     double v[8][kHistPer];
     auto fetch = [&](int base) {  // unconditional loads (clamped), all in flight together
 #pragma unroll
@@ -1227,13 +1268,13 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
                 v[w][q] = hist_out[(size_t)w * P.hist_cap + (i < len_w[w] ? i : 0)];
             }
     };
-    if (ntiles > 0) fetch(0);
+    if (ntiles > 0 && !fresh_hist) fetch(0);
 
     // ---- pass 2: TGR (ref :416-461) and what each bin appends to which list -----------------
     unsigned q4[4] = {0, 0, 0, 0};  // gmain, gtail, nmain, ntail of this thread's bins
-    unsigned gm[kGlePer], gt[kGlePer], nm[kGlePer], nt[kGlePer];
+    unsigned gm[PER], gt[PER], nm[PER], nt[PER];
 #pragma unroll
-    for (int j = 0; j < kGlePer; ++j) {
+    for (int j = 0; j < PER; ++j) {
         const int bin = b0 + j;
         gm[j] = gt[j] = nm[j] = nt[j] = 0;
         if (j >= per || bin >= B) continue;
@@ -1278,7 +1319,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     {
         unsigned run[4] = {q4[0], q4[1], q4[2], q4[3]};
 #pragma unroll
-        for (int j = 0; j < kGlePer; ++j) {
+        for (int j = 0; j < PER; ++j) {
             const int bin = b0 + j;
             if (j >= per || bin >= B) continue;
             for (int q = 0; q < 4; ++q) s_e[q][bin] = run[q];
@@ -1291,11 +1332,12 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
             for (int q = 0; q < 4; ++q) s_e[q][B] = tot4[q];
     }
     __syncthreads();
+    probe();  // 5: TGR, second scan
     const unsigned total_ground = tot4[0] + tot4[1];
     const unsigned n_rnr = cnt[B], n_oor = cnt[B + 1];
     const unsigned ng_base = total_ground + n_rnr + n_oor;  // non-ground list follows the ground list
 #pragma unroll
-    for (int j = 0; j < kGlePer; ++j) {
+    for (int j = 0; j < PER; ++j) {
         const int bin = b0 + j;
         if (j >= per || bin >= B) continue;
         const int d = dec[j];
@@ -1333,6 +1375,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     }
     __threadfence_block();
     __syncthreads();
+    probe();  // 6: list offsets written
 
     // ---- adaptive thresholds for the next frame of this stream (ref :338-375) ---------------
     // lanes 0..3: elevation history of ring i, lanes 4..7: flatness history; sequential sums
@@ -1342,7 +1385,15 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     // Everything else is taken off that chain: all threads stage the histories through LDS in tiles
     // (the next tile's loads are in flight while the current one is summed), and for the second pass
     // they also square the deviations, so the summing lanes execute one add per value.
-    {
+    if (fresh_hist) {
+        if (threadIdx.x < 8) {  // the same sequential sums (ref :557-566) over the same values, in push order
+            const int ring = (int)threadIdx.x & 3;
+            double m = 0.0, sd = 0.0;
+            if (ring < roi) mean_stdev_lds((threadIdx.x < 4 ? s_pelev : s_pseq) + s_epush[s_ring_first[ring]], 1, my_len, m, sd);
+            s_mean[threadIdx.x] = m;
+            s_std[threadIdx.x] = sd;
+        }
+    } else {
         double *tile = LAT ? s_tile_lat : reinterpret_cast<double *>(&s_e[0][0]);
         double acc = 0.0, mean = 0.0;
         for (int step = 0; step < 2 * ntiles; ++step) {
@@ -1401,6 +1452,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         }
     }
     __syncthreads();
+    probe();  // 7: threshold statistics
     __shared__ int s_shift[8];
     if (threadIdx.x == 0) {
         for (int i = 0; i < 8; ++i) s_shift[i] = 0;
@@ -1457,6 +1509,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         Bt.results[f].hist_state = (mx << 1) | s_dropped;  // the host grows the slabs before they run out (pwpp_capi.cpp)
     }
     __syncthreads();
+    probe();  // 8: state written
     {  // erase(begin, begin + exceed), ref :354-355,372-373: every history at once, loads before stores
         constexpr int kErasePer = 4;
         int sh_w[8], new_w[8], maxnew = 0;
@@ -1486,6 +1539,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
             __syncthreads();
         }
     }
+    probe();  // 9: end
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2118,10 +2172,13 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
         if (frc) return frc;
         if (B.P.min_pts == 0)
             hipLaunchKernelGGL(k_gle_tgr_seq, dim3(F), dim3(64), 0, stream, B);  // empty bins inherit planes: serial
-        else if (F <= 64)  // every workgroup alone on a CU: the big-LDS variant
-            hipLaunchKernelGGL(k_gle_tgr<true>, dim3(F), dim3(kBlock), 0, stream, B);
-        else
-            hipLaunchKernelGGL(k_gle_tgr<false>, dim3(F), dim3(kBlock), 0, stream, B);
+        else if (F <= 64) {  // every workgroup alone on a CU: the big-LDS variant
+            if (B.P.num_bins <= 2 * kBlock) hipLaunchKernelGGL((k_gle_tgr<true, 2>), dim3(F), dim3(kBlock), 0, stream, B);
+            else hipLaunchKernelGGL((k_gle_tgr<true, kGlePer>), dim3(F), dim3(kBlock), 0, stream, B);
+        } else {
+            if (B.P.num_bins <= 2 * kBlock) hipLaunchKernelGGL((k_gle_tgr<false, 2>), dim3(F), dim3(kBlock), 0, stream, B);
+            else hipLaunchKernelGGL((k_gle_tgr<false, kGlePer>), dim3(F), dim3(kBlock), 0, stream, B);
+        }
         if (ev) (void)hipEventRecord(ev[10], stream);
     }
     if (stages & 4) {
