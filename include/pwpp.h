@@ -97,7 +97,9 @@ typedef struct pwpp_patch_record {
     float mean[3];          /* pc_mean_            (patchworkpp.cpp:59-60) */
     float normal[3];        /* normal_             (patchworkpp.cpp:66-68) */
     float sv[3];            /* singular_values_    (patchworkpp.cpp:63)    */
-    float pad_;
+    int32_t rounds;         /* diagnostic, no reference counterpart: R-GPF rounds the fit ran -- num_iter, or fewer when a round's
+                             * integer totals repeated the round before's (early termination: the remaining rounds and the final fit
+                             * of patchworkpp.cpp:516-543 provably reproduce this round's set and plane) */
     double d;               /* d_                  (patchworkpp.cpp:74)    */
 } pwpp_patch_record;
 

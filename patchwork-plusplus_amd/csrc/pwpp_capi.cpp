@@ -1357,6 +1357,7 @@ int pwpp_get_patch_records(pwpp_handle *h, int frame, pwpp_patch_record *out, in
                     o.n_ground = r.n_ground;
                     o.n_nonground = r.n_nonground;
                     o.decision = r.decision;
+                    o.rounds = (r.valid >> 8) & 0xff;
                     for (int i = 0; i < 3; ++i) {
                         o.mean[i] = r.mean[i];
                         o.normal[i] = r.normal[i];

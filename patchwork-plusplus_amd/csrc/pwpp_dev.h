@@ -106,7 +106,8 @@ struct PwppPatchRec {  // one per (frame, bin); written by k_patch_fit, finished
     int32_t valid;  // 0: no fit ran in this bin (empty bin let through by num_min_pts <= 0); bit 1: the last pass skipped the
                     // high part (its points are non-ground, its bits in the membership plane were not written);
                     // bits 3-5: log2(G) of the fit rows that left the patch's split in the membership plane (PWPP_SLOT_ALIGN
-                    // above), i.e. the layout of its bits: k_emit compacts the two lists from them;
+                    // above), i.e. the layout of its bits: k_emit compacts the two lists from them; bits 8-15: the R-GPF rounds
+                    // the fit ran (num_iter, or fewer: early termination -- a diagnostic, pwpp_patch_record.rounds);
                     // bit 2 (alone): the patch's first fit set was empty, so it works with the plane the reference object
                     // fitted LAST (the patch before it, or the frame before): nothing was fitted yet, k_fit_fixup does it
 };

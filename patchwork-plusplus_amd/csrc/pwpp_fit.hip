@@ -251,7 +251,7 @@ enum { ST_VPF = 0, ST_SEED = 1, ST_ITER = 2, ST_LAZY = 3, ST_DONE = 4 };
 
 // hi_skipped: the pass that left the split did not read the high part (its points are non-ground, its bits were not written)
 // member_lg: log2(G) of the rows that left the split in the membership plane (pwpp_dev.h)
-__device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &pl, unsigned n, unsigned n_ground, bool hi_skipped, int member_lg) {
+__device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &pl, unsigned n, unsigned n_ground, bool hi_skipped, int member_lg, int rounds) {
     rec->mean[0] = pl.mean[0];
     rec->mean[1] = pl.mean[1];
     rec->mean[2] = pl.mean[2];
@@ -266,7 +266,7 @@ __device__ __forceinline__ void write_record(PwppPatchRec *rec, const PlaneFit &
     rec->n_ground = (int)n_ground;
     rec->n_nonground = (int)(n - n_ground);
     rec->decision = 0;
-    rec->valid = (hi_skipped ? 3 : 1) | (member_lg << 3);
+    rec->valid = (hi_skipped ? 3 : 1) | (member_lg << 3) | ((rounds & 0xff) << 8);
 }
 
 // The reference object's plane members survive from patch to patch (and frame to frame): a patch whose FIRST fit set is
@@ -1008,7 +1008,7 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
         } else if (kind == ST_ITER) {
             if (last || conv) {
                 if (j == 0)
-                    write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt, !use_hi && pc.n_hi > 0u, G == 64 ? 6 : (G == 32 ? 5 : (G == 16 ? 4 : 3)));
+                    write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt, !use_hi && pc.n_hi > 0u, G == 64 ? 6 : (G == 32 ? 5 : (G == 16 ? 4 : 3)), it + 1);
                 kind = ST_DONE;
             }
             ++it;
@@ -1467,7 +1467,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : PWPP_W16_OCC) void k_f
         } else if (kind == ST_ITER) {
             const int it = O(it);
             if (it == P.num_iter - 1 || conv) {
-                write_record(Bt.recs + (size_t)f * P.num_bins + O(bin), O(pl), O(n), (unsigned)O(cnt), O(hi_skipped) != 0, G == 64 ? 6 : (G == 32 ? 5 : (G == 16 ? 4 : 3)));
+                write_record(Bt.recs + (size_t)f * P.num_bins + O(bin), O(pl), O(n), (unsigned)O(cnt), O(hi_skipped) != 0, G == 64 ? 6 : (G == 32 ? 5 : (G == 16 ? 4 : 3)), it + 1);
                 O(kind) = ST_DONE;
             }
             O(it) = it + 1;
@@ -2039,7 +2039,7 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
             kind = ST_ITER;
         } else if (kind == ST_ITER) {
             if (last || conv) {
-                if (threadIdx.x == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt, !use_hi && pc.n_hi > 0u, 6);
+                if (threadIdx.x == 0) write_record(Bt.recs + (size_t)f * P.num_bins + bin, pl, n, (unsigned)cnt, !use_hi && pc.n_hi > 0u, 6, it + 1);
                 kind = ST_DONE;
             }
             ++it;
@@ -2232,7 +2232,7 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
         rec->n_ground = (int)sh.last_n;  // (the set the final plane was fitted on: the last round's ground set)
         rec->n_nonground = (int)(n - (unsigned)sh.last_n);
         rec->decision = 0;
-        rec->valid = 1 | (6 << 3);  // the split is in the membership plane, 64-lane layout
+        rec->valid = 1 | (6 << 3) | ((P.num_iter & 0xff) << 8);  // the split is in the membership plane, 64-lane layout; every round ran
     }
 }
 

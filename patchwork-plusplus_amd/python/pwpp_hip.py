@@ -46,7 +46,7 @@ class State(ctypes.Structure):
 
 RECORD_DTYPE = np.dtype([("bin", "<i4"), ("concentric_idx", "<i4"), ("n_points", "<i4"), ("n_ground", "<i4"),
                          ("n_nonground", "<i4"), ("decision", "<i4"), ("mean", "<f4", 3), ("normal", "<f4", 3),
-                         ("sv", "<f4", 3), ("pad_", "<f4"), ("d", "<f8")])
+                         ("sv", "<f4", 3), ("rounds", "<i4"), ("d", "<f8")])
 
 
 class DeviceView(ctypes.Structure):
