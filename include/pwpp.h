@@ -185,6 +185,11 @@ PWPP_API int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32
  *     of a threshold now and then (measured: 0-2 of 480 000 indices on dense synthetic clouds, none on the KITTI
  *     samples; plane normals agree to 1e-4 except for ill-conditioned patches, where a float build departs from exact
  *     arithmetic by more than this library does).
+ *     Measured on 208 synthetic 64-beam frames against all three builds of the reference (float sums in two orders, exact
+ *     sums; tests/test_ref_consensus.py, profiles/r04_ref_consensus.json): the builds are unanimous on 204 frames; this
+ *     library returns exactly their ground set on 203 of them and differs by ONE index (of 128 075) on one -- the 2^-21 m grid
+ *     of the z sums moved a plane normal by a few float ulps and a point 1e-7 m from th_dist with it; on the 4 frames where
+ *     the float builds differ from the exact build (by 1, 1, 8, 129 indices) it equals the exact build.
  * (NaN heights are undefined in the reference itself: it sorts bins with `a.z < b.z`.)
  * The order inside a list is not the reference's unless pwpp_set_output_order asks for it. */
 PWPP_API int pwpp_get_ground_indices(pwpp_handle *h, int frame, int32_t *out);
