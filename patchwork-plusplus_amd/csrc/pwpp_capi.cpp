@@ -1067,7 +1067,7 @@ int pwpp_estimate_ground_fields_batch(pwpp_handle *h, const void *const *data, c
     }
     // the fields are read in place as float32 (host: merged copies computed in units of floats; device: aligned loads): a
     // blob that does not start on a 4-byte boundary cannot be read that way
-    if (!h || !data || !n) return fail(PWPP_E_ARG, "null argument");
+    if (!data || !n) return fail(PWPP_E_ARG, "null argument");  // (the handle is checked by estimate_batch: the alignment check needs none)
     if (frames < 1 || frames > 65535) return fail(PWPP_E_ARG, "frames=%d: 1 ... 65535 per call expected", frames);  // (before n[] / data[] are walked)
     for (int i = 0; i < frames; ++i)
         if (n[i] > 0 && (reinterpret_cast<uintptr_t>(data[i]) & 3u) != 0)
