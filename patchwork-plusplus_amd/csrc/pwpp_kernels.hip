@@ -1870,6 +1870,9 @@ __device__ __forceinline__ void ord_tile_sort(unsigned long long *s_key, int len
 // O(n log^2 n) compare-exchanges.  Declined (the network takes the tile as before) when the list mixes R-VPF categories,
 // holds a non-finite height, has one height only, or some bucket gets more than kOrdMaxBucket keys -- cloud-order lists
 // (small bins, pseudo-bins: one "height") always are.
+#ifndef PWPP_ORDER_BLOCK
+#define PWPP_ORDER_BLOCK 256  // threads of the workgroup that sorts a long list
+#endif
 #ifndef PWPP_ORDER_BUCKETS
 #define PWPP_ORDER_BUCKETS 1
 #endif
@@ -1878,7 +1881,8 @@ constexpr int kOrdBuckets = 1024, kOrdMaxBucket = 32;
 // lds_out[len], cnt / start[kOrdBuckets], red[4][4]: LDS.  Returns false (nothing stored) when the tile is declined.
 template <int BLOCK, class Load, class Store>
 __device__ __forceinline__ bool ord_bucket_sort(Load load, Store store, unsigned long long *lds_out, unsigned *cnt, unsigned *start, unsigned (*red)[4], int len) {
-    static_assert(BLOCK == 256 && kOrdBuckets == 4 * BLOCK, "four buckets per thread in the scan");
+    constexpr int kPerT = kOrdBuckets / BLOCK;  // buckets per thread in the scan
+    static_assert(kPerT * BLOCK == kOrdBuckets && BLOCK <= 512, "whole buckets per thread; the waves' partial results fit sixteen slots");
     const int t = threadIdx.x;
     unsigned zlo = 0xffffffffu, zhi = 0u, clo = 255u, chi = 0u;
 #pragma unroll 4
@@ -1929,20 +1933,26 @@ __device__ __forceinline__ bool ord_bucket_sort(Load load, Store store, unsigned
 #pragma unroll 4
     for (int i = t; i < len; i += BLOCK) atomicAdd(&cnt[bucket(load(i))], 1u);
     __syncthreads();
-    const unsigned c0 = cnt[4 * t], c1 = cnt[4 * t + 1], c2 = cnt[4 * t + 2], c3 = cnt[4 * t + 3];
-    const unsigned mine = c0 + c1 + c2 + c3;
+    unsigned cb[kPerT], mine = 0;
+    int skew = 0;
+#pragma unroll
+    for (int q = 0; q < kPerT; ++q) {
+        cb[q] = cnt[kPerT * t + q];
+        mine += cb[q];
+        skew |= cb[q] > (unsigned)kOrdMaxBucket;
+    }
     const unsigned incl = wave_incl_scan(mine);
     if (lane_id() == 63) red[wave_id()][0] = incl;
-    const int skew = c0 > (unsigned)kOrdMaxBucket || c1 > (unsigned)kOrdMaxBucket || c2 > (unsigned)kOrdMaxBucket || c3 > (unsigned)kOrdMaxBucket;
     if (__syncthreads_or(skew)) return false;
     unsigned before = 0;
     for (int w = 0; w < wave_id(); ++w) before += red[w][0];
     unsigned run = before + incl - mine;
-    start[4 * t] = run;
-    start[4 * t + 1] = run + c0;
-    start[4 * t + 2] = run + c0 + c1;
-    start[4 * t + 3] = run + c0 + c1 + c2;
-    cnt[4 * t] = cnt[4 * t + 1] = cnt[4 * t + 2] = cnt[4 * t + 3] = 0u;  // (now the buckets' cursors)
+#pragma unroll
+    for (int q = 0; q < kPerT; ++q) {
+        start[kPerT * t + q] = run;
+        run += cb[q];
+        cnt[kPerT * t + q] = 0u;  // (now the bucket's cursor)
+    }
     __syncthreads();
 #pragma unroll 4
     for (int i = t; i < len; i += BLOCK) {
@@ -1970,7 +1980,7 @@ __device__ __forceinline__ bool ord_bucket_sort(Load load, Store store, unsigned
 // <256, 4096, 256> a workgroup for the lists above 256 entries.  Each handles the lists in ITS range.
 template <int BLOCK, int kOrdTile, int kMinLen>
 __global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned long long *scr_a, unsigned long long *scr_b) {
-    constexpr bool kBuckets = PWPP_ORDER_BUCKETS && BLOCK == 256 && kOrdTile == 4096;  // the workgroup instantiation tries the distribution sort first
+    constexpr bool kBuckets = PWPP_ORDER_BUCKETS && BLOCK >= 256 && kOrdTile == 4096;  // the workgroup instantiation tries the distribution sort first
     // ONE piece of LDS for both sorts (40 KB: four workgroups per CU): the network's padded tile (ord_at), or the distribution
     // sort's scatter array + bucket counters + bucket starts -- it reads its keys from global memory
     constexpr int kOutSlots = 4096 - 48;  // (40 KB less the few hundred bytes the compiler's own LDS takes: FOUR workgroups per CU, not three)
@@ -2003,7 +2013,7 @@ __global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned
         if (len <= kOrdTile) {
             bool done = false;
             if constexpr (kBuckets)
-                if (len <= kBucketTile) done = ord_bucket_sort<256>(load_key, [&](unsigned pos, unsigned long long k) { out[start + pos] = (int)(k & 0x00ffffffull); }, s_raw,
+                if (len <= kBucketTile) done = ord_bucket_sort<BLOCK>(load_key, [&](unsigned pos, unsigned long long k) { out[start + pos] = (int)(k & 0x00ffffffull); }, s_raw,
                                             reinterpret_cast<unsigned *>(s_raw + kOutSlots), reinterpret_cast<unsigned *>(s_raw + kOutSlots) + kOrdBuckets, s_red, len);
             if (!done) {
                 for (int i = threadIdx.x; i < len; i += BLOCK) s_key[ord_at(i)] = load_key(i);
@@ -2020,7 +2030,7 @@ __global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned
             const int tl = len - t0 < kOrdTile ? len - t0 : kOrdTile;
             bool done = false;
             if constexpr (kBuckets)
-                if (tl <= kBucketTile) done = ord_bucket_sort<256>([&](int i) { return load_key(t0 + i); }, [&](unsigned pos, unsigned long long k) { a[t0 + pos] = k; }, s_raw,
+                if (tl <= kBucketTile) done = ord_bucket_sort<BLOCK>([&](int i) { return load_key(t0 + i); }, [&](unsigned pos, unsigned long long k) { a[t0 + pos] = k; }, s_raw,
                                             reinterpret_cast<unsigned *>(s_raw + kOutSlots), reinterpret_cast<unsigned *>(s_raw + kOutSlots) + kOrdBuckets, s_red, tl);
             if (!done) {
                 for (int i = threadIdx.x; i < tl; i += BLOCK) s_key[ord_at(i)] = load_key(t0 + i);
@@ -2190,7 +2200,7 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
         if (ev) (void)hipEventRecord(ev[11], stream);
         if (order_a) {
             hipLaunchKernelGGL((k_order_sublists<64, 256, 0>), dim3(NB, F), dim3(64), 0, stream, B, order_a, order_b);
-            hipLaunchKernelGGL((k_order_sublists<256, 4096, 256>), dim3(NB, F), dim3(256), 0, stream, B, order_a, order_b);
+            hipLaunchKernelGGL((k_order_sublists<PWPP_ORDER_BLOCK, 4096, 256>), dim3(NB, F), dim3(PWPP_ORDER_BLOCK), 0, stream, B, order_a, order_b);
         }
     }
     return (int)hipGetLastError();
