@@ -38,7 +38,7 @@ def random_params(rng):
     if rng.random() < 0.5:
         p.num_iter = int(rng.integers(1, 6))
     if rng.random() < 0.5:
-        p.num_lpr = int(rng.choice([3, 5, 10, 20, 40, 64]))
+        p.num_lpr = int(rng.choice([3, 5, 10, 20, 40, 64, 100, 200]))
     if rng.random() < 0.5:
         p.num_min_pts = int(rng.choice([0, 0, 1, 3, 5, 10, 20, 50, 200]))  # (0: empty bins are processed and report the plane fitted last)
     if rng.random() < 0.5:
