@@ -392,8 +392,10 @@ __global__ __launch_bounds__(BLOCK, 8) void k_czm_bin_scatter(PwppBatch Bt, int 
             const unsigned seg = s_seg[code], cap = s_seg[code + 1] - seg;
             const unsigned r = s_cnt[code] + (pc[j] >> 16);
             if (r < cap) {
-                sorted_z[seg + r] = pz[j];
-                sorted_xy[seg + r] = make_float2(px[j], py[j]);
+                if (code < (unsigned)NB - 2u) {  // (a pseudo-bin -- RNR hit, out of range -- is never fitted: only its cloud indices are read again)
+                    sorted_z[seg + r] = pz[j];
+                    sorted_xy[seg + r] = make_float2(px[j], py[j]);
+                }
                 sorted_idx[seg + r] = first + j * kBlock + (int)threadIdx.x;
             } else {
                 over = true;
@@ -579,8 +581,10 @@ __global__ __launch_bounds__(kBlock) void k_czm_scatter(PwppBatch Bt) {
     for (int j = 0; j < kPer; ++j) {
         if (code[j] != PWPP_CODE_DROP) {
             const unsigned slot = off[code[j]] + s_base[code[j]] + rank[j];
-            sorted_z[slot] = pz[j];
-            sorted_xy[slot] = make_float2(px[j], py[j]);
+            if (code[j] < (unsigned)NB - 2u) {  // (pseudo-bins: indices only, see k_czm_bin_scatter)
+                sorted_z[slot] = pz[j];
+                sorted_xy[slot] = make_float2(px[j], py[j]);
+            }
             sorted_idx[slot] = first + j * kBlock + (int)threadIdx.x;
         }
     }
