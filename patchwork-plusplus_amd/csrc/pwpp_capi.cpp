@@ -166,6 +166,7 @@ struct pwpp_handle {
     DevBuf<uint8_t> d_member;     // membership plane (pwpp_dev.h, PWPP_SLOT_ALIGN): one bit per slot + PWPP_MEMBER_PAD bytes per part
     DevBuf<int32_t> d_out;
     DevBuf<unsigned long long> d_ord_a, d_ord_b;  // scratch of the reference-order mode (long sub-lists)
+    DevBuf<uint32_t> d_ord_work;                  // ... and its work lists: the sub-lists above 256 entries of every frame
     int output_order = PWPP_ORDER_SCATTER;
     DevBuf<uint32_t> d_bins;   // 4 slabs of frames*(B+2): bin_count, bin_off, dst_a, dst_b
     DevBuf<uint32_t> d_parts;  // TWO copies of 3 slabs of frames*(2B+2): part_count, part_off, part_cursor (pwpp_dev.h: a bin is stored in two
@@ -511,6 +512,7 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
     bt.bin_origin = h->d_bin_origin.p;
     bt.bin_bbox = h->d_bin_bbox.p;
     bt.member = h->d_member.p;
+    bt.order_work = h->output_order == PWPP_ORDER_REFERENCE ? h->d_ord_work.p : nullptr;
     bt.recs = h->d_recs.p;
     bt.out_idx = h->d_out.p;
     bt.centers = h->d_centers.p;
@@ -557,6 +559,7 @@ PwppBatch frame_range(const pwpp_handle *h, const PwppBatch &bt, int f0, int nf)
     v.normals += (size_t)f0 * B * 3;
     v.results += f0;
     v.results_host += f0;
+    if (v.order_work) v.order_work += (size_t)f0 * (size_t)(1 + 2 * NB);
     v.next_part_count += (size_t)f0 * NP;  // (the other copy: same frame, same slab stride)
     v.next_results += f0;
     return v;
@@ -1004,6 +1007,7 @@ int pwpp_destroy(pwpp_handle *h) {
     h->d_out.release();
     h->d_ord_a.release();
     h->d_ord_b.release();
+    h->d_ord_work.release();
     h->d_bins.release();
     h->d_recs.release();
     h->d_cls_start.release();
@@ -1127,6 +1131,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     if (h->output_order == PWPP_ORDER_REFERENCE) {
         if ((rc = h->d_ord_a.ensure(tp))) return rc;
         if ((rc = h->d_ord_b.ensure(tp))) return rc;
+        if ((rc = h->d_ord_work.ensure((size_t)frames * (size_t)(1 + 2 * NB)))) return rc;
     }
     if ((rc = h->d_bins.ensure((size_t)frames * NB * 4))) return rc;
     if ((rc = h->d_parts.ensure(2 * counters_copy_words((size_t)frames * NP)))) return rc;  // two copies
@@ -1686,7 +1691,7 @@ int64_t pwpp_get_workspace_bytes(pwpp_handle *h) {
     auto b = [](size_t cap, size_t elt) { return (int64_t)(cap * elt); };
     return b(h->d_frames.cap, sizeof(PwppFrameDesc)) + b(h->d_frames_probe.cap, sizeof(PwppFrameDesc)) + b(h->d_in.cap, 4) + b(h->d_codes.cap, 2) +
            b(h->d_sorted_z.cap, 4) + b(h->d_sorted_xy.cap, 8) + b(h->d_sorted_idx.cap, 4) + b(h->d_bin_origin.cap, 8) + b(h->d_bin_bbox.cap, 16) +
-           b(h->d_member.cap, 1) + b(h->d_out.cap, 4) + b(h->d_ord_a.cap, 8) + b(h->d_ord_b.cap, 8) + b(h->d_bins.cap, 4) + b(h->d_parts.cap, 4) +
+           b(h->d_member.cap, 1) + b(h->d_out.cap, 4) + b(h->d_ord_a.cap, 8) + b(h->d_ord_b.cap, 8) + b(h->d_ord_work.cap, 4) + b(h->d_bins.cap, 4) + b(h->d_parts.cap, 4) +
            b(h->d_cls_start.cap, 4) + b(h->d_cap_off.cap, 4) + b(h->d_bin_max.cap, 4) + b(h->d_cls_list.cap, 2) +
            b(h->d_recs.cap, sizeof(PwppPatchRec)) + b(h->d_centers.cap, 4) + b(h->d_normals.cap, 4) + b(h->d_results.cap, sizeof(PwppFrameResult)) +
            b(h->d_xyz.cap, 4) + b(h->d_dbg.cap, 8) + b(h->d_st_stream.cap, sizeof(PwppStateScalar)) + b(h->d_st_fresh.cap, sizeof(PwppStateScalar)) +
@@ -1711,6 +1716,7 @@ int pwpp_trim_workspace(pwpp_handle *h) {
     h->d_out.release();
     h->d_ord_a.release();
     h->d_ord_b.release();
+    h->d_ord_work.release();
     h->d_xyz.release();
     h->d_frames.release();
     h->d_frames_probe.release();

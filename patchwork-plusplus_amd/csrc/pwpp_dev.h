@@ -155,6 +155,8 @@ struct PwppBatch {
     uint32_t *bin_max;           // [2B+2] largest count every PART has had in any frame so far (k_czm_scan): sizes the one-pass segments
     const float4 *bin_bbox;      // [B] {xmin, xmax, ymin, ymax} of every bin (a little generous): the skip test of the high parts
     const float2 *bin_origin;    // [B] origin of every bin's fixed-point plane-fit sums (its polar centre rounded to 1/8 m)
+    uint32_t *order_work;        // reference-order mode: per frame [1 + 2 (B + 2)] words -- the number of sub-lists above 256 entries, then
+                                 // bin | which << 16 of each (k_order_worklist -> k_order_sublists); null otherwise
     uint8_t *member;             // membership plane (see PWPP_SLOT_ALIGN): the final ground set of a patch, one bit per slot
     PwppPatchRec *recs;          // [frames][B]
     uint32_t *dst_a;             // [frames][B+2] output offset of sub-list A (candidates / whole bin)

@@ -1996,9 +1996,21 @@ __global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned
     // partial results -- 40 KB exactly, not a byte more, or only three workgroups fit a CU)
     constexpr int kBucketTile = kOutSlots - 16;
     unsigned(*s_red)[4] = reinterpret_cast<unsigned(*)[4]>(s_raw + kBucketTile);
-    const int f = blockIdx.y, seg = blockIdx.x;
+    const int f = blockIdx.y;
     const PwppDevParams &P = Bt.P;
     const int B = P.num_bins, NB = B + 2;
+    // The wave instantiation (kMinLen == 0) takes bin blockIdx.x and both of its sub-lists.  The workgroup instantiation takes ONE
+    // sub-list from the frame's work list (k_order_worklist: the sub-lists above kMinLen entries, ~100 of a KITTI frame's ~1000):
+    // a workgroup without an item leaves after one load that its whole frame shares, instead of three dependent loads per bin.
+    int seg = blockIdx.x, which_lo = 0, which_hi = 2;
+    if constexpr (kMinLen > 0) {
+        const uint32_t *work = Bt.order_work + (size_t)f * (size_t)(1 + 2 * NB);
+        if (blockIdx.x >= work[0]) return;
+        const uint32_t item = work[1 + blockIdx.x];
+        seg = (int)(item & 0xffffu);
+        which_lo = (int)(item >> 16);
+        which_hi = which_lo + 1;
+    }
     const unsigned n = Bt.bin_count[(size_t)f * NB + seg];
     if (n < 1) return;
     if (Bt.dst_a[(size_t)f * NB + seg] == kAwaitsFixup) return;  // (the frame awaits k_fit_fixup)
@@ -2006,7 +2018,7 @@ __global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned
     int *out = Bt.out_idx + fd.base;
     const bool whole = seg >= B || (uint64_t)n < P.min_pts;
     const unsigned ng = whole ? n : (unsigned)Bt.recs[(size_t)f * B + seg].n_ground;
-    for (int which = 0; which < 2; ++which) {
+    for (int which = which_lo; which < which_hi; ++which) {
         const unsigned start = which == 0 ? Bt.dst_a[(size_t)f * NB + seg] : Bt.dst_b[(size_t)f * NB + seg];
         const int len = (int)(which == 0 ? ng : n - ng);
         if (len < 1 || len <= kMinLen || (kMinLen == 0 && len > kOrdTile)) continue;  // not this instantiation's range
@@ -2072,6 +2084,29 @@ __global__ __launch_bounds__(BLOCK) void k_order_sublists(PwppBatch Bt, unsigned
         for (int i = threadIdx.x; i < len; i += BLOCK) out[start + i] = (int)(a[i] & 0x00ffffffull);
         __syncthreads();
     }
+}
+
+// the sub-lists above `min_len` entries of every frame, for the workgroup instantiation of k_order_sublists
+__global__ __launch_bounds__(kBlock) void k_order_worklist(PwppBatch Bt, int min_len) {
+    __shared__ unsigned s_n;
+    const int f = blockIdx.x;
+    const PwppDevParams &P = Bt.P;
+    const int B = P.num_bins, NB = B + 2;
+    uint32_t *work = Bt.order_work + (size_t)f * (size_t)(1 + 2 * NB);
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (Bt.dst_a[(size_t)f * NB] != kAwaitsFixup) {  // (a frame that awaits k_fit_fixup has no lists yet)
+        for (int seg = threadIdx.x; seg < NB; seg += kBlock) {
+            const unsigned n = Bt.bin_count[(size_t)f * NB + seg];
+            if (n <= (unsigned)min_len) continue;
+            const bool whole = seg >= B || (uint64_t)n < P.min_pts;
+            const unsigned ng = whole ? n : (unsigned)Bt.recs[(size_t)f * B + seg].n_ground;
+            if (ng > (unsigned)min_len) work[1 + atomicAdd(&s_n, 1u)] = (uint32_t)seg;
+            if (n - ng > (unsigned)min_len) work[1 + atomicAdd(&s_n, 1u)] = (uint32_t)seg | (1u << 16);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) work[0] = s_n;
 }
 
 // getGround()/getNonground() rows (ref :8-16): xyz of the listed points, gathered on the device
@@ -2204,7 +2239,10 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
         if (ev) (void)hipEventRecord(ev[11], stream);
         if (order_a) {
             hipLaunchKernelGGL((k_order_sublists<64, 256, 0>), dim3(NB, F), dim3(64), 0, stream, B, order_a, order_b);
-            hipLaunchKernelGGL((k_order_sublists<PWPP_ORDER_BLOCK, 4096, 256>), dim3(NB, F), dim3(PWPP_ORDER_BLOCK), 0, stream, B, order_a, order_b);
+            // the lists above 256 entries: a work list per frame, then one workgroup per item (at most points / 257 + the two a bin can add)
+            const unsigned max_items = (unsigned)(B.max_n / 257 + 2) < 2u * (unsigned)NB ? (unsigned)(B.max_n / 257 + 2) : 2u * (unsigned)NB;
+            hipLaunchKernelGGL(k_order_worklist, dim3(F), dim3(kBlock), 0, stream, B, 256);
+            hipLaunchKernelGGL((k_order_sublists<PWPP_ORDER_BLOCK, 4096, 256>), dim3(max_items, F), dim3(PWPP_ORDER_BLOCK), 0, stream, B, order_a, order_b);
         }
     }
     return (int)hipGetLastError();
