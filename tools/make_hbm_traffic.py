@@ -11,7 +11,8 @@ out = {}
 for k, e in d["kernels"].items():
     name = k.replace(", ", ",")
     name = "k_fit_w64<64,p>" if name.startswith("k_fit_w64<64,") else name
-    name = name.replace("<256>", "").replace("<false>", "").replace("<true>", "")
+    if not name.startswith("k_fit_w64"):
+        name = name.split("<")[0]  # (the other kernels under their plain names, as bench.py's kernel_ms has them)
     out[name] = int(round((2.0 * e.get("FETCH_SIZE_kb_raw", 0.0) + e.get("WRITE_SIZE_kb_raw", 0.0)) * 1024.0))
 out["_total"] = sum(v for k, v in out.items() if not k.startswith("_") and k != "k_czm_bin" and k != "k_clear")
 out["source"] = src + " (tools/profile_r04.sh r04 --no-overlap: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py's 1024-frame KITTI batch)"
