@@ -45,7 +45,7 @@ constexpr int kPPT = 8;  // points per lane held in registers
 #define PWPP_W64_OCC 3  // waves per SIMD the 64-lane fit kernel is compiled for
 #endif
 #ifndef PWPP_W16_OCC
-#define PWPP_W16_OCC 4  // waves per SIMD the 16-lane fit kernel is compiled for (3: no spills, slower -- profiles/r04_experiments.txt)
+#define PWPP_W16_OCC 4  // waves per SIMD the 16-lane fit kernel is compiled for (3: 2 spilled registers instead of 77, 18 % slower alone -- profiles/r04_experiments.txt)
 #endif
 #ifndef PWPP_FIT_PREFETCH
 #define PWPP_FIT_PREFETCH 0
