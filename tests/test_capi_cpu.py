@@ -365,3 +365,26 @@ def test_field_blobs_must_be_float_aligned(lib):
     ptrs = (ctypes.c_void_p * 1)(base)  # aligned: the call gets as far as the missing handle
     assert lib.pwpp_estimate_ground_fields_batch(None, ptrs, n, 1, 16, 0, 4, 8, -1, 0, 0) == -1
     assert b"aligned" not in lib.pwpp_last_error()
+
+
+def test_ros_node_core_compiles_without_ros():
+    """The ROS 2 node's logic (ros/include/patchworkpp_ros/segmentation_core.hpp) is plain C++17 over the class mirror: it must
+    compile where there is no ROS, and its parameter mapping must name exactly the parameters the reference's node declares
+    (ros/src/GroundSegmentationServer.cpp:28-44 there).  The rclcpp glue (ros/src/ground_segmentation_server.cpp) is checked
+    for the topic and parameter names only -- it cannot be compiled here."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "patchwork-plusplus_amd")
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(pkg, "ros", "include"), "-I", os.path.join(pkg, "include"),
+                    "-I", os.path.join(root, "include"), os.path.join(pkg, "examples", "ros_core_demo.cpp")], check=True)
+    core = open(os.path.join(pkg, "ros", "include", "patchworkpp_ros", "segmentation_core.hpp")).read()
+    names = set(re.findall(r'get_(?:double|int|bool)\("([a-z_]+)"', core))
+    assert names == {"sensor_height", "num_iter", "num_lpr", "num_min_pts", "th_seeds", "th_dist", "th_seeds_v", "th_dist_v", "max_range",
+                     "min_range", "uprightness_thr", "verbose"}
+    glue = open(os.path.join(pkg, "ros", "src", "ground_segmentation_server.cpp")).read()
+    for topic in ('"pointcloud_topic"', '"/patchworkpp/cloud"', '"/patchworkpp/ground"', '"/patchworkpp/nonground"', '"base_frame"', '"patchworkpp_node"'):
+        assert topic in glue
+    launch = open(os.path.join(pkg, "ros", "launch", "patchworkpp.launch.py")).read()
+    for k, v in (("sensor_height", "1.88"), ("num_min_pts", "0"), ("th_seeds", "0.3"), ("uprightness_thr", "0.101"), ("min_range", "1.0")):
+        assert re.search(r'"%s": %s[,}\s]' % (k, re.escape(v)), launch), k

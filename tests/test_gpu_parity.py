@@ -1111,6 +1111,63 @@ def test_ros_wrapper_parameters_and_pointcloud2_input(kitti, oracle):
             h4.estimate_ground_fields(np.zeros(64, np.uint8), 1, *bad)
 
 
+def test_ros_node_core(kitti, oracle, tmp_path):
+    """the ROS 2 node's logic -- patchwork-plusplus_amd/ros/include/patchworkpp_ros/segmentation_core.hpp, everything
+    between "a PointCloud2 arrived" and "three PointCloud2 payloads are ready" -- built and run WITHOUT ROS
+    (examples/ros_core_demo.cpp): three KITTI frames as 32-byte-per-point message payloads with x, y, z between other fields,
+    one long-lived node core with the launch file's parameter set.  The payloads it would publish (cloud, ground, non-ground:
+    x, y, z float32 + 4 bytes, the reference's CreatePointCloud2Msg layout) are compared -- the cloud byte for byte, the two
+    lists as multisets of points, through checksums -- with what the oracle (stateful, same parameters, N x 3 input as PointCloud2ToEigenMat gives) implies.
+    The rclcpp component around the core (ros/src/ground_segmentation_server.cpp) needs ROS 2 and is not built here."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "patchwork-plusplus_amd", "examples", "ros_core_demo")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "patchwork-plusplus_amd"), "examples/ros_core_demo"], check=True)
+    paths = []
+    for k in range(3):
+        p = tmp_path / ("%06d.bin" % k)
+        kitti[k].tofile(p)
+        paths.append(str(p))
+    out = subprocess.run([exe] + paths, capture_output=True, text=True, check=True).stdout
+    lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 3, out
+
+    def fnv1a(b):
+        h = 1469598103934665603
+        for x in b:
+            h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return "%016x" % h
+
+    def point_sum(b):  # the lists as multisets of 16-byte points (their order inside a patch is the scatter order: not reproducible)
+        h = np.full(len(b) // 16, 1469598103934665603, np.uint64)
+        a = np.frombuffer(b, np.uint8).reshape(-1, 16).astype(np.uint64)
+        with np.errstate(over="ignore"):
+            for j in range(16):
+                h = (h ^ a[:, j]) * np.uint64(1099511628211)
+            return "%016x" % int(h.sum(dtype=np.uint64))
+
+    def payload(xyz):  # CreatePointCloud2Msg: point_step 16
+        a = np.zeros((xyz.shape[0], 4), np.float32)
+        a[:, :3] = xyz
+        return a.tobytes()
+
+    prm = apply_variant(pwpp_hip.default_params(), ROS_LAUNCH)
+    h = pwpp_hip.Handle(prm)  # the same sequence through the C-ABI: the lists' ORDER inside a patch is the library's own, so
+    est = ol.Estimator(oracle, to_oracle_params(prm), arith=ol.ARITH_FXP)  # the payload bytes are compared with the library, the sets with the oracle
+    for k, line in enumerate(lines):
+        c3 = np.ascontiguousarray(kitti[k][:, :3])
+        h.estimate_ground(c3)
+        ref = est.run(c3)
+        assert_frame_equal(h, 0, ref, c3.shape[0], state_index=0)
+        assert line["points"] == c3.shape[0] and line["cloud"] == [c3.shape[0], 16, fnv1a(payload(c3))]
+        g, ng = h.ground(0), h.nonground(0)
+        assert line["ground"][:2] == [len(ref.ground_idx), 16] and line["nonground"][:2] == [len(ref.nonground_idx), 16]
+        assert line["ground"][2] == point_sum(payload(g)) and line["nonground"][2] == point_sum(payload(ng))
+
+
 def test_plane_members_carry_over_between_frames(kitti, oracle):
     """The reference object's plane members (normal_, pc_mean_, singular_values_, d_) survive from call to call, and with
     num_min_pts = 0 (the ROS launch file) a bin without points is "processed" and reports them: for a sensor with a
