@@ -123,8 +123,8 @@ struct PwppFrameResult {
 
 // everything a launch needs, by value in the kernarg segment
 // The fit passes re-read a patch 5-6 times and are bound by that traffic, so the bin-ordered records are
-// planes: z (all a lowest-point pass needs, 4 B), {x, y} (8 B) and the cloud index (4 B, read by the pass
-// that writes the split only).
+// planes: z (all a lowest-point pass needs, 4 B), {x, y} (8 B) and the cloud index (4 B, read by k_emit and the tiny-fit
+// gather only; the fit passes leave the split of a patch in the membership plane, a bit per slot).
 
 struct PwppBatch {
     PwppDevParams P;
@@ -151,7 +151,7 @@ struct PwppBatch {
     float *sorted_z;             // [total points | frames x slots per frame] z of the points grouped by part.  A NaN z of the cloud is
                                  // stored as 0x7fc00000; 0x7fc00000 | (round + 1) marks a point an R-VPF round removed
     float2 *sorted_xy;           // same slots: {x, y}
-    int *sorted_idx;             // same slots: cloud index of the point (read by the last fit pass and K6 only)
+    int *sorted_idx;             // same slots: cloud index of the point (read by K6, and by the tiny-fit gather of K4)
     uint32_t *bin_max;           // [2B+2] largest count every PART has had in any frame so far (k_czm_scan): sizes the one-pass segments
     const float4 *bin_bbox;      // [B] {xmin, xmax, ymin, ymax} of every bin (a little generous): the skip test of the high parts
     const float2 *bin_origin;    // [B] origin of every bin's fixed-point plane-fit sums (its polar centre rounded to 1/8 m)

@@ -22,7 +22,9 @@
 //                           the reference's order: they start from the plane the object fitted last
 //
 // The bin-ordered records are planes (pwpp_dev.h): the lowest-point pass streams z alone (4 B per
-// point), every other pass z and {x, y} (12 B), the pass that writes the split also the cloud index.
+// point), every other pass z and {x, y} (12 B); the cloud-index plane is k_emit's (and the tiny-fit gather's), not the passes'.
+// The split of a patch is a bit per slot in the MEMBERSHIP PLANE (pwpp_dev.h), left by every R-GPF round that can be the last, and
+// a patch whose integer totals repeat from one round to the next stops there (exact early termination: k_fit_w64, phase B).
 // A near-zone bin is stored in two parts, below and above a split height: every pass skips the high part
 // when it can prove that none of its points can enter (stage_needs_hi).
 // DESIGN.md section 3 has the measurements that led here (and the variants that were dropped: points
@@ -244,7 +246,7 @@ __device__ __forceinline__ void ce(unsigned &a, unsigned &b) {
 //   ST_LAZY  the R-VPF plane of a zone 1-3 bin, needed only if ST_SEED found no seed: ref :49
 //            then leaves that plane in force.  (The reference always fits it, :486-487, and the
 //            next fit overwrites it; skipping it changes nothing observable.)
-//   ST_ITER  R-GPF round: keep dist < th_dist -> plane; the last round also writes the split
+//   ST_ITER  R-GPF round: keep dist < th_dist -> plane; from the second round on the set also goes to the membership plane,
 //            and the final plane is fitted on the ground set                       (ref :516-543)
 // ------------------------------------------------------------------------------------------
 enum { ST_VPF = 0, ST_SEED = 1, ST_ITER = 2, ST_LAZY = 3, ST_DONE = 4 };
@@ -505,7 +507,7 @@ __device__ __forceinline__ unsigned lane_strip(const ChunkPts &cp, bool on, floa
 }
 
 // Did a height of the FINAL ground set of a patch lie outside z0 +- ZR (its quantised value was clamped, Moments)?  Checked in
-// the pass that writes the split only; the frame is flagged (PwppFrameResult.overflow bit 2, pwpp_get_clamped_frames): the
+// the passes that leave a set in the membership plane, and counted only if that set is final; the frame is flagged (PwppFrameResult.overflow bit 2, pwpp_get_clamped_frames): the
 // plane of such a patch -- more than 32 m tall with the default CZM -- is the plane of the clamped heights (include/pwpp.h).
 __device__ __forceinline__ bool chunk_clamped(const ChunkPts &cp, unsigned gm, const FxpOrg &org) {
     bool hit = false;
