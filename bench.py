@@ -141,7 +141,7 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def dense_leg(pwpp_hip, torch, dev, gpu_index, frames=64, steps=5):
+def dense_leg(pwpp_hip, torch, dev, gpu_index, frames=256, steps=5):
     """BASELINE.json configs[4] on this GPU, outside the timed region: dense synthetic 128-beam ~480k-point frames, 36-sector CZM."""
     import pwpp_synth
     src = [pwpp_synth.make_dense_cloud(1000 + k) for k in range(4)]
@@ -178,7 +178,7 @@ def dense_leg(pwpp_hip, torch, dev, gpu_index, frames=64, steps=5):
                         % (frames, int(np.mean(ns))),
             "frames": frames, "steps": steps, "frames_per_s": frames / dt, "ms_per_step": 1000.0 * dt,
             "algorithmic_bytes_per_step": b_alg, "pipeline_achieved_GBps": b_alg / dt / 1e9, "pipeline_frac": b_alg / dt / 1e9 / HBM_PEAK_GBS,
-            "workspace_gb": ws, "note": "a 64-frame batch does not fill the chip the way 1024 frames do (profiles/: 1024 dense frames per batch)"}
+            "workspace_gb": ws, "note": "a batch of a few hundred dense frames does not fill the chip the way 1024 do (profiles/r04_bench_dense_1024.json)"}
 
 
 def main():
@@ -195,7 +195,7 @@ def main():
                          "as two frame ranges on two streams")
     ap.add_argument("--overlap", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of the separate single-stream pass that measures per-kernel times")
-    ap.add_argument("--dense-frames", type=int, default=64, help="frames of the configs[4] leg (outside the timed region, N = 1 only)")
+    ap.add_argument("--dense-frames", type=int, default=256, help="frames of the configs[4] leg (outside the timed region, N = 1 only)")
     ap.add_argument("--skip-latency", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="no parity_check / reference_order / ingest legs (all of them run outside the timed region)")
     args = ap.parse_args()
