@@ -509,8 +509,7 @@ __device__ __forceinline__ float plane_test_threshold(double d, double thr) {
 // bucket(n) = 4*floor(log2 n) + next two mantissa bits, n >= 1; monotone in n.
 __host__ __device__ __forceinline__ int pwpp_size_bucket(unsigned n) {
     if (n < 4u) return (int)n;  // 1,2,3 -> 1,2,3 (0 unused)
-    int e = 31;
-    while (!((n >> e) & 1u)) --e;
+    const int e = 31 - __builtin_clz(n);  // (n >= 4)
     const int b = 4 * e + (int)((n >> (e - 2)) & 3u) - 4;  // n=4 -> 4
     return b < PWPP_NUM_BUCKETS - 1 ? b : PWPP_NUM_BUCKETS - 1;
 }

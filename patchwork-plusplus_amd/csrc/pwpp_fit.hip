@@ -1708,6 +1708,11 @@ __device__ double block_lpr(FitShared &sh, const PatchRef &pts, bool use_cutoff,
 // their integer moments through LDS (exact, so the split over waves changes nothing) and all
 // solve the same 3x3 problem; the lowest points are selected per wave and merged.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long readlane_i64(long long v, int lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)v, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), lane);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 struct BRowShared {
     long long mom[kWaves][16];   // per wave: n, S1[3], lower and upper halves of S2[6] (Row<64>::reduce16_scatter)
     unsigned cand[kWaves][5][64];  // every lane's four smallest keys + the smallest it dropped, pooled lane by lane
@@ -1715,7 +1720,7 @@ struct BRowShared {
     int elig[kWaves];
     double single_sum;   // a patch of one chunk: wave 0's result
     unsigned single_T;
-    long long prev_tot[16];      // the totals of the last R-GPF round (early termination)
+    long long prev_tot[2][16];   // the totals of the last R-GPF round (early termination), double-buffered by round parity
     long long mom2[kWaves][16];  // dual seed pass: the band between the two seed thresholds
     PlaneFit plane[2];           // R-VPF fit | R-GPF seed fit, solved side by side by different waves
     FitShared fs;  // for block_lpr, the exact fall-back of the lowest-point selection
@@ -1944,38 +1949,31 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         __int128 s2[6];
         long long cnt = 0;
         bool conv = false;  // this R-GPF round's totals repeat the last round's: the plane in force is the final one
-        {
+        {   // lane k (mod 16) adds up slot k of the waves' sums; the sixteen totals then go to every lane through v_readlane
+            // (scalar registers: the solve's integer part below is scalar work) -- 4 LDS reads per lane instead of 64
+            const int k16 = ln & 15;
+            long long a = 0, b = 0;  // a: below the smaller threshold, a + b: below the larger one
+#pragma unroll
+            for (int w2 = 0; w2 < kWaves; ++w2) {
+                a += sh.mom[w2][k16];
+                if (dual_now) b += sh.mom2[w2][k16];
+            }
+            const long long t_vpf = dual_now ? (v_is_hi ? a + b : a) : a;
+            const long long t_seed = v_is_hi ? a : a + b;
+            const long long mine = spec ? t_seed : t_vpf;
+            cnt = readlane_i64(t_vpf, 0);
+            if (dual_now) stash_cnt = readlane_i64(t_seed, 0);
             long long t16[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                long long a = 0, b = 0;  // a: below the smaller threshold, a + b: below the larger one
-#pragma unroll
-                for (int w2 = 0; w2 < kWaves; ++w2) {
-                    a += sh.mom[w2][k];
-                    if (dual_now) b += sh.mom2[w2][k];
-                }
-                const long long t_vpf = dual_now ? (v_is_hi ? a + b : a) : a;
-                const long long t_seed = v_is_hi ? a : a + b;
-                t16[k] = spec ? t_seed : t_vpf;
-                if (k == 0) {
-                    cnt = t_vpf;
-                    if (dual_now) stash_cnt = t_seed;
-                }
-            }
+            for (int k = 0; k < 16; ++k) t16[k] = readlane_i64(mine, k);
 #pragma unroll
             for (int k = 0; k < 4; ++k) tot[k] = t16[k];
 #pragma unroll
             for (int k = 0; k < 6; ++k) s2[k] = join_halves(t16[4 + k], t16[10 + k]);
-            if (kind == ST_ITER) {  // (every lane holds the same sixteen totals)
-                bool same = true;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) same = same && sh.prev_tot[k] == t16[k];
-                conv = !last && it >= 1 && cnt > 3 && same;
-            }
-            __syncthreads();
-            if (kind == ST_ITER && threadIdx.x == 0) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) sh.prev_tot[k] = t16[k];
+            if (kind == ST_ITER) {  // (prev_tot is double-buffered by round: no barrier between its read and its write)
+                const bool differs = sh.prev_tot[(it & 1) ^ 1][k16] != mine;
+                conv = !last && it >= 1 && cnt > 3 && __ballot(differs) == 0ull;
+                if (wv == 0 && ln < 16) sh.prev_tot[it & 1][ln] = mine;
             }
         }
         if (clamped && (last || conv)) flag_clamped(Bt, f);  // (only a FINAL ground set counts)

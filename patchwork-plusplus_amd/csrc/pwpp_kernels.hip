@@ -423,17 +423,39 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     unsigned *pcnt = Bt.part_count + (size_t)f * NP;
     unsigned *poff = Bt.part_off + (size_t)f * NP;
     if (Bt.cap_off) {  // one-pass binning: fixed segments; a part never reports more points than its segment holds
-        for (int p = threadIdx.x; p < NP; p += kBlock) {
-            const unsigned seg = Bt.cap_off[p], cap = Bt.cap_off[p + 1] - seg;
-            unsigned c = pcnt[p];
-            poff[p] = seg;
-            if (c > cap) {
-                c = cap;
-                pcnt[p] = cap;
-                Bt.results[f].overflow = 1;
+        // four parts per thread at a time, their loads (segment table, count, observed maximum) all in flight before the first
+        // is used: as a plain loop every iteration was an L2 round trip of its own (4 x 0.3 us of a single frame's chain, and
+        // as much again for the maxima, which are now part of this loop)
+        for (int p0 = 0; p0 < NP; p0 += 4 * kBlock) {
+            unsigned seg[4], nxt[4], c[4], mx[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = p0 + q * kBlock + (int)threadIdx.x;
+                seg[q] = nxt[q] = c[q] = mx[q] = 0u;
+                if (p < NP) {
+                    seg[q] = Bt.cap_off[p];
+                    nxt[q] = Bt.cap_off[p + 1];
+                    c[q] = pcnt[p];
+                    mx[q] = Bt.bin_max[p];
+                }
             }
-            s_pc[p] = c;
-            s_po[p] = seg;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = p0 + q * kBlock + (int)threadIdx.x;
+                if (p >= NP) continue;
+                const unsigned cap = nxt[q] - seg[q];
+                poff[p] = seg[q];
+                if (c[q] > cap) {
+                    c[q] = cap;
+                    pcnt[p] = cap;
+                    Bt.results[f].overflow = 1;
+                }
+                s_pc[p] = c[q];
+                s_po[p] = seg[q];
+                // what the host sizes the segments of the NEXT batches from (an overflowed part reports its clamped count
+                // here; the exact redo that follows reports the true one)
+                if (c[q] > mx[q]) atomicMax(&Bt.bin_max[p], c[q]);
+            }
         }
     } else {
         // as few consecutive parts per thread as cover the model (4 for the default 1010 parts): all four waves busy
@@ -470,10 +492,9 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     }
     __syncthreads();
     probe();  // 1: part counts and offsets
-    // what the host sizes the one-pass segments of the NEXT batches from (an overflowed part reports its clamped
-    // count here; the exact redo that follows reports the true one)
-    for (int p = threadIdx.x; p < NP; p += kBlock)
-        if (s_pc[p] > Bt.bin_max[p]) atomicMax(&Bt.bin_max[p], s_pc[p]);
+    if (!Bt.cap_off)  // the exact path's counts enter the observed maxima too (one-pass: done above)
+        for (int p = threadIdx.x; p < NP; p += kBlock)
+            if (s_pc[p] > Bt.bin_max[p]) atomicMax(&Bt.bin_max[p], s_pc[p]);
     // the bins: a bin's points = its two parts, its slots begin where its low part begins
     unsigned *cnt = Bt.bin_count + (size_t)f * NB;
     unsigned *off = Bt.bin_off + (size_t)f * NB;
@@ -491,30 +512,57 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     __syncthreads();
     probe();  // 2: observed maxima, bin counts
     // patches of this frame sorted by size bucket (work lists of the K4 kernels)
-    __shared__ unsigned s_cnt[PWPP_NUM_BUCKETS], s_start[PWPP_NUM_BUCKETS + 1], s_cur[PWPP_NUM_BUCKETS];
-    if (threadIdx.x < PWPP_NUM_BUCKETS) {
-        s_cnt[threadIdx.x] = 0;
-        s_cur[threadIdx.x] = 0;
-    }
+    // One round of LDS atomics places a patch: the lanes of a wave that hold the same bucket find each other with seven
+    // ballots (one per bit of the bucket number), the first of them adds the group's size to the bucket's counter and hands
+    // the old value to the others, a lane's place in the bucket is that value + its rank in the group.  (Round 3 counted
+    // with one atomic per patch and placed with a second one: ~60 patches of a frame share a bucket, and the atomics on
+    // one counter are served one after the other -- 2.4 + 2.4 us of a single frame's chain.  A loop over the wave's
+    // distinct buckets instead of the ballots was slower still, profiles/r04_latency_trace.txt.)
+    __shared__ unsigned s_cnt[PWPP_NUM_BUCKETS], s_start[PWPP_NUM_BUCKETS + 1];
+    __shared__ unsigned s_place[PWPP_MAX_BINS];  // bucket << 16 | place in the bucket; ~0u: no patch
+    static_assert(PWPP_NUM_BUCKETS <= 128, "seven ballots; two buckets per lane in the prefix below");
+    if (threadIdx.x < PWPP_NUM_BUCKETS) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (int b = threadIdx.x; b < B; b += kBlock) {
-        const unsigned n = s_bc[b];
-        if ((uint64_t)n < Bt.P.min_pts) continue;  // small bin (ref :191-195)
-        PwppPatchRec *rec = Bt.recs + (size_t)f * B + b;
-        rec->valid = 0;
-        if (n == 0) {  // only with num_min_pts <= 0: no fit runs (ref :49); K5 inherits the previous plane
-            rec->n_points = 0;
-            rec->n_ground = 0;
-            rec->n_nonground = 0;
-            continue;
+    for (int b0 = 0; b0 < B; b0 += kBlock) {  // (workgroup-uniform trip count: every lane takes part in the ballots)
+        const int b = b0 + (int)threadIdx.x;
+        bool live = false;
+        unsigned n = 0;
+        if (b < B) {
+            n = s_bc[b];
+            if ((uint64_t)n >= Bt.P.min_pts) {  // else: small bin (ref :191-195)
+                PwppPatchRec *rec = Bt.recs + (size_t)f * B + b;
+                rec->valid = 0;
+                if (n == 0) {  // only with num_min_pts <= 0: no fit runs (ref :49); K5 inherits the previous plane
+                    rec->n_points = 0;
+                    rec->n_ground = 0;
+                    rec->n_nonground = 0;
+                } else {
+                    live = true;
+                }
+            }
         }
-        atomicAdd(&s_cnt[pwpp_size_bucket(n)], 1u);
+        const unsigned c = live ? (unsigned)pwpp_size_bucket(n) : 0u;
+        unsigned long long peers = __ballot(live);
+#pragma unroll
+        for (int bit = 0; bit < 7; ++bit) {
+            const bool one = (c >> bit & 1u) != 0u;
+            const unsigned long long m = __ballot(one);
+            peers &= one ? m : ~m;
+        }
+        unsigned place = ~0u;
+        if (live) {  // (peers holds this lane)
+            const int ln = lane_id(), leader = __ffsll((long long)peers) - 1;
+            unsigned base = 0;
+            if (ln == leader) base = atomicAdd(&s_cnt[c], (unsigned)__popcll(peers));
+            base = __shfl(base, leader);
+            place = c << 16 | (base + (unsigned)__popcll(peers & ((1ull << ln) - 1ull)));
+        }
+        if (b < B) s_place[b] = place;
     }
     __syncthreads();
-    probe();  // 3: bucket histogram
+    probe();  // 3: bucket histogram, places
     if (threadIdx.x < 64) {  // exclusive prefix over the 96 buckets by one wave, two buckets per lane (a serial loop of 96 LDS
                              // round trips by one thread was 1.4 us of a single frame's chain)
-        static_assert(PWPP_NUM_BUCKETS <= 128, "two buckets per lane");
         const int c0 = 2 * (int)threadIdx.x, c1 = c0 + 1;
         const unsigned a = c0 < PWPP_NUM_BUCKETS ? s_cnt[c0] : 0u, b = c1 < PWPP_NUM_BUCKETS ? s_cnt[c1] : 0u;
         const unsigned incl = wave_incl_scan(a + b);
@@ -526,10 +574,8 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     __syncthreads();
     for (int c = threadIdx.x; c <= PWPP_NUM_BUCKETS; c += kBlock) Bt.cls_start[(size_t)f * PWPP_CLS_STRIDE + c] = s_start[c];
     for (int b = threadIdx.x; b < B; b += kBlock) {
-        const unsigned n = s_bc[b];
-        if ((uint64_t)n < Bt.P.min_pts || n == 0) continue;
-        const int c = pwpp_size_bucket(n);
-        Bt.cls_list[(size_t)f * B + s_start[c] + atomicAdd(&s_cur[c], 1u)] = (uint16_t)b;
+        const unsigned place = s_place[b];
+        if (place != ~0u) Bt.cls_list[(size_t)f * B + s_start[place >> 16] + (place & 0xffffu)] = (uint16_t)b;
     }
     probe();  // 4: end
 }
