@@ -315,16 +315,25 @@ __global__ __launch_bounds__(BLOCK, 8) void k_czm_bin_scatter(PwppBatch Bt, int 
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and the
     // scattered 12-byte / 4-byte records of a bin merge into full lines only if the workgroups that write
     // that bin share an L2.  So XCD k takes the frames k, k + 8, ..., all tiles of a frame in a row.
+    // Fewer than 8 frames (tiles_per_frame < 0): latency, not write merging, is what counts, and a frame confined to one
+    // XCD would have 32 of the 256 CUs -- its tiles are dealt over all XCDs instead.
+    const bool spread = tiles_per_frame < 0;
+    if (spread) tiles_per_frame = -tiles_per_frame;
     const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
-    const int f = xcd + 8 * (slot / tiles_per_frame);
+    const int f = spread ? lin / tiles_per_frame : xcd + 8 * (slot / tiles_per_frame);
     if (f >= Bt.num_frames) return;
     const PwppFrameDesc fd = Bt.frames[f];
-    const int first = (slot % tiles_per_frame) * kOnePassPts;
+    const int first = ((spread ? lin : slot) % tiles_per_frame) * kOnePassPts;
     if (first >= fd.n) return;
     const PwppDevParams &P = Bt.P;
     constexpr int kPer = kOnePassPts / kBlock;
     unsigned pc[kPer];  // code | rank inside the workgroup << 16
     float px[kPer], py[kPer], pz[kPer], pw[kPer];
+    int probe_i = 0;  // timing probes (debug_flags & 8): slots 0.. of the probe array, workgroup 0; slot 8 = the latest end of any workgroup
+    auto probe = [&]() {
+        if ((Bt.debug & 8) && blockIdx.x == 0 && threadIdx.x == 0 && probe_i < 8) Bt.dbg[probe_i++] = wall_clock64();
+    };
+    probe();
     // the points first: their loads are under way while the tables are set up (the kernel is a latency chain per
     // workgroup -- at half its occupancy it takes 1.4 x as long -- and the barrier below would otherwise stand
     // between the table loads and these)
@@ -335,9 +344,22 @@ __global__ __launch_bounds__(BLOCK, 8) void k_czm_bin_scatter(PwppBatch Bt, int 
         if (i < fd.n) load_point(fd, i, px[j], py[j], pz[j], pw[j]);
     }
     for (int b = threadIdx.x; b < NB; b += kBlock) s_cnt[b] = 0;
-    for (int b = threadIdx.x; b <= NB; b += kBlock) s_seg[b] = Bt.cap_off[b];
+    for (int b0 = 0; b0 <= NB; b0 += 4 * kBlock) {  // (four table entries per thread in flight: not one L2 round trip per iteration)
+        unsigned sv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + q * kBlock + (int)threadIdx.x;
+            sv[q] = b <= NB ? Bt.cap_off[b] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + q * kBlock + (int)threadIdx.x;
+            if (b <= NB) s_seg[b] = sv[q];
+        }
+    }
     fill_zone_table(P, s_zt);
     __syncthreads();
+    probe();  // 1: tables in LDS
     const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
     const float rnr_z_guard = (float)(-sensor_height - 0.8) + 1e-3f;
     const float zs = hi_split_z(P, sensor_height);
@@ -357,6 +379,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_czm_bin_scatter(PwppBatch Bt, int 
         pc[j] = code | ((old + pos) << 16);
     }
     __syncthreads();
+    probe();  // 2: points in, codes and ranks
     unsigned *gcount = Bt.part_count + (size_t)f * NB;
     // histogram and range reservation in one: a global atomic per non-empty part.  Four parts per thread at a time, all
     // four atomics in flight before the first result is needed (as a plain loop every atomic waited for the one before)
@@ -381,6 +404,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_czm_bin_scatter(PwppBatch Bt, int 
     dropped = wave_sum_u32(dropped);
     if (lane_id() == 0 && dropped) atomicAdd((unsigned *)&Bt.results[f].n_dropped, dropped);
     __syncthreads();
+    probe();  // 3: ranges reserved
     float *sorted_z = Bt.sorted_z + fd.sbase;
     float2 *sorted_xy = Bt.sorted_xy + fd.sbase;
     int *sorted_idx = Bt.sorted_idx + fd.sbase;
@@ -403,6 +427,8 @@ __global__ __launch_bounds__(BLOCK, 8) void k_czm_bin_scatter(PwppBatch Bt, int 
         }
     }
     if (__any(over) && lane_id() == 0) Bt.results[f].overflow = 1;
+    probe();  // 4: stores issued
+    if ((Bt.debug & 8) && threadIdx.x == 0) atomicMax(&Bt.dbg[8], wall_clock64());
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2243,12 +2269,14 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
         if (B.cap_off) {  // one-pass binning (fixed bin segments)
             const int bb = B.bin_block == 1024 ? 1024 : (B.bin_block == 512 ? 512 : (B.bin_block == 128 ? 128 : 256));
             const unsigned gx1 = (unsigned)((B.max_n + 4 * bb - 1) / (4 * bb));
-            const dim3 grid(gx1 * (unsigned)((F + 7) / 8 * 8));
+            const bool spread = F < 8;  // (see the kernel: a few frames are dealt over all XCDs)
+            const dim3 grid(gx1 * (unsigned)(spread ? F : (F + 7) / 8 * 8));
+            const int tpf = spread ? -(int)gx1 : (int)gx1;
             if (gx1 > 0) {
-                if (bb == 128) hipLaunchKernelGGL(k_czm_bin_scatter<128>, grid, dim3(128), binning_lds_bytes(B, 2), stream, B, (int)gx1);
-                else if (bb == 256) hipLaunchKernelGGL(k_czm_bin_scatter<256>, grid, dim3(256), binning_lds_bytes(B, 2), stream, B, (int)gx1);
-                else if (bb == 512) hipLaunchKernelGGL(k_czm_bin_scatter<512>, grid, dim3(512), binning_lds_bytes(B, 2), stream, B, (int)gx1);
-                else hipLaunchKernelGGL(k_czm_bin_scatter<1024>, grid, dim3(1024), binning_lds_bytes(B, 2), stream, B, (int)gx1);
+                if (bb == 128) hipLaunchKernelGGL(k_czm_bin_scatter<128>, grid, dim3(128), binning_lds_bytes(B, 2), stream, B, tpf);
+                else if (bb == 256) hipLaunchKernelGGL(k_czm_bin_scatter<256>, grid, dim3(256), binning_lds_bytes(B, 2), stream, B, tpf);
+                else if (bb == 512) hipLaunchKernelGGL(k_czm_bin_scatter<512>, grid, dim3(512), binning_lds_bytes(B, 2), stream, B, tpf);
+                else hipLaunchKernelGGL(k_czm_bin_scatter<1024>, grid, dim3(1024), binning_lds_bytes(B, 2), stream, B, tpf);
             }
             if (ev) (void)hipEventRecord(ev[1], stream);
             hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);

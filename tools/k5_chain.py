@@ -27,3 +27,6 @@ for k in range(1, len(names)):
 print("total %.2f us" % (sum(acc) / 20.0))
 v = [out[16 + k] for k in range(5)]
 print("k_czm_scan (last call):", " ".join("+%.2f" % ((v[k] - v[k - 1]) / 100.0) for k in range(1, 5)), "us  [counts+offsets | maxima, bin counts | bucket histogram | lists]")
+v = [out[k] for k in range(5)]
+print("k_czm_bin_scatter, workgroup 0 (last call):", " ".join("+%.2f" % ((v[k] - v[k - 1]) / 100.0) for k in range(1, 5)),
+      "us  [tables in LDS | points in, codes, ranks | ranges reserved | stores issued]; last workgroup ends %.2f us after workgroup 0 starts; scan starts %.2f us after that" % ((out[8] - v[0]) / 100.0, (out[16] - out[8]) / 100.0))
