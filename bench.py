@@ -208,6 +208,11 @@ def main():
     if os.environ.get("PWPP_BENCH_ECHO_RANK"):  # (tests/test_dist_cpu.py: which ranks were started, and by whom)
         print("bench rank %s of %s%s" % (os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1"),
                                          " (self-spawned)" if os.environ.get("PWPP_BENCH_SELF_SPAWNED") else ""), file=sys.stderr, flush=True)
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:  # every rank has said so before any goes on (without a GPU the first rank to
+            import torch.distributed as dist             # fail makes the launcher stop the others -- possibly before their line)
+            dist.init_process_group("gloo")
+            dist.barrier()
+            dist.destroy_process_group()
 
     import torch
 
@@ -255,8 +260,7 @@ def main():
         h.launch_device_batch(batch, cols=4, mode=pwpp_hip.MODE_FRESH)
         h.synchronize()
 
-    for _ in range(max(args.warmup, 1)):
-        step()
+    step()  # (one step for the checks below; the W warm-up steps run right in front of the timed region, after the host-side checks)
     # self-check: replays of the same source frame must produce identical counts, and
     # ground + non-ground must partition the frame (no reference data needed on the GPU box)
     counts = h.all_counts()
@@ -296,6 +300,8 @@ def main():
     # The timed region runs the library's default schedule (overlap mode for batches of 128+ frames) with no
     # profiling events in it; the per-kernel times and the roofline line come from a SEPARATE single-stream pass
     # after the timed region (HIP events around every launch would serialise the two frame ranges).
+    for _ in range(max(args.warmup, 1)):  # W untimed warm-up steps (the checks above leave the GPU idle for a while: warm up AFTER them)
+        step()
     pwpp_dist.barrier(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
