@@ -476,6 +476,7 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
     bt.max_n = h->max_n;
     bt.debug = h->debug_flags;
     bt.fit_plan = h->fit_plan.empty() ? nullptr : h->fit_plan.c_str();
+    bt.plan_frames = 0;
     bt.fit_concurrent = h->fit_concurrent ? 1 : 0;
     bt.bin_block = h->bin_block;
     if (h->mode == PWPP_MODE_FRESH) {
@@ -640,8 +641,7 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
         while (R > 2 && frames / R < 64) --R;
         // big bins per wave: four on scans of KITTI density (+2 % over two in interleaved end-to-end runs), two where the
         // bins are several times larger (dense 128-beam frames, 36-sector CZM: 110.9 k against 106.8 k frames/s)
-        const double eff = (double)frames * (double)h->max_n / 125000.0;
-        if (!bt.fit_plan && eff > 640.0) bt.fit_plan = pwpp_big_batch_plan(h->max_n, h->dp.num_bins);
+        bt.plan_frames = frames;  // (pwpp_launch_fit picks the plan; round 4: also below 640 frames -- the ranges used to pick one for their own size)
         std::vector<int> first((size_t)R + 1, 0);
         for (int r = 1; r <= R; ++r) {
             int f1 = r == R ? frames : (int)(((int64_t)frames * r / R + 7) / 8 * 8);

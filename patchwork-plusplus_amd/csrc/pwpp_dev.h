@@ -169,6 +169,7 @@ struct PwppBatch {
     unsigned long long *dbg;     // [64] timing probes, only written when debug & 4
     // host side only (the kernels never read these)
     const char *fit_plan;        // option "fit_plan": overrides the plan pwpp_launch_fit would choose; null or empty = automatic
+    int32_t plan_frames;         // frames the automatic fit plan is chosen for: the WHOLE call's when this batch is one of its frame ranges (0: num_frames)
     int32_t fit_concurrent;      // option "fit_concurrent": the classes of a plan side by side on two streams
     int32_t emit_parts;          // waves per bin in k_emit (1..8, from the largest bin seen so far)
     int32_t bin_block;           // option "bin_block": threads per workgroup of k_czm_bin_scatter (256, 512, 1024; four points each)

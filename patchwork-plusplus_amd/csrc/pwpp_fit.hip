@@ -2343,20 +2343,27 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     //           tools/small_batches.py: 1 / 2 / 4 / 8 frames 128 / 133 / 201 / 218 us per call, against
     //           174 / 184 / 229 / 229 us with the next plan and 134 / 167 / 225 / 323 us with four waves for
     //           every patch, "B64:65535"; from 12 frames on the next plan wins, 236 vs 307 us)
-    //   <= 48   one prefetching wave per patch, every patch at once
+    //   <= 15   the same with four waves only above 2047 points
+    //   <= 76   one prefetching wave per patch, every patch at once
     //   <= 320  16 small patches per wave; big bins one wave each         (8 -> 32 waves per frame)
-    //   <= 448  16 small patches per wave; big bins two per wave
-    //   <= 640  32 small patches per wave; big bins two per wave
-    //   more    64 small patches per wave; big bins two per wave          (fewest solve instances)
+    //   <= 576  16 small patches per wave; big bins two per wave
+    //   <= 704  32 small patches per wave; big bins two per wave
+    //   <= 896  32 small patches per wave; big bins four per wave
+    //   more    64 small patches per wave; big bins four per wave         (fewest solve instances)
     // e.g. 1 frame: 0.128 ms instead of 0.174 with the second plan; 32 frames: 93 k frames/s instead of
-    // 44 k with the last plan; 256 frames: 237 k instead of 208 k.
+    // 44 k with the last plan; 256 frames: 237 k instead of 208 k.  Round 4 (tools/plans_by_frames.py, profiles/
+    // r04_plans_by_frames.txt): the thresholds re-measured with early termination in every kernel, and a frame range of
+    // the overlap schedule takes the plan of the WHOLE call (B.plan_frames) -- the ranges share the machine, and choosing
+    // by their own size gave 512 / 640 frames a plan 10-12 % slower than the best.
     if (!plan || !*plan) {
-        const double eff = (double)F * (double)B.max_n / 125000.0;
+        const double eff = (double)(B.plan_frames > 0 ? B.plan_frames : F) * (double)B.max_n / 125000.0;
         plan = eff <= 9.0 ? PWPP_LATENCY_FIT_PLAN
-             : eff <= 48.0 ? "S64:65535"
+             : eff <= 15.0 ? "H64:2047"  // (10 / 12 frames: 169 / 184 us per call against 215 / 217 with the next plan; 16: equal)
+             : eff <= 76.0 ? "S64:65535"
              : eff <= 320.0 ? "W16.16:1023,S64:65535"
-             : eff <= 448.0 ? "W16.16:1023,W64.2:65535"
-             : eff <= 640.0 ? "W16.32:1023,W64.2:65535"
+             : eff <= 576.0 ? "W16.16:1023,W64.2:65535"
+             : eff <= 704.0 ? "W16.32:1023,W64.2:65535"
+             : eff <= 896.0 ? (B.max_n / (nb > 0 ? nb : 1) >= 500 ? "W16.32:1023,W64.2:65535" : "W16.32:1023,W64.4:65535")
                             : pwpp_big_batch_plan(B.max_n, nb);
     }
     int k_lo = 0, slot = 0;
