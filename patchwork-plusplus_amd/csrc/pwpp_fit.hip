@@ -2337,7 +2337,7 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     // for tuning experiments (the environment variable PWPP_FIT_PLAN sets that option at pwpp_create).
     const char *plan = B.fit_plan;
     // The right granularity depends on how much work there is to spread over 1024 SIMDs (measured with
-    // tools/plan_by_frames.sh on KITTI frames; "frames" below = points of the batch / 125 000):
+    // tools/plan_by_frames.sh on KITTI frames; "frames" below = frames x sqrt(points per frame / 125 000)):
     //   <= 9    k_fit_hybrid: four waves per patch above 1023 points, one wave per smaller patch, one launch,
     //           one workgroup per CU                                         (chain latency is what counts;
     //           tools/small_batches.py: 1 / 2 / 4 / 8 frames 128 / 133 / 201 / 218 us per call, against
@@ -2356,7 +2356,10 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     // the overlap schedule takes the plan of the WHOLE call (B.plan_frames) -- the ranges share the machine, and choosing
     // by their own size gave 512 / 640 frames a plan 10-12 % slower than the best.
     if (!plan || !*plan) {
-        const double eff = (double)(B.plan_frames > 0 ? B.plan_frames : F) * (double)B.max_n / 125000.0;
+        // (frames of KITTI size; denser frames count by the square root of their size -- their patches are larger, not more:
+        // 256 / 384 / 512 dense 486 k-point frames are best served by the plans of 505 / 757 / 1010 KITTI frames, bench.py
+        // --workload dense with every plan, profiles/r04_plans_by_frames.txt)
+        const double eff = (double)(B.plan_frames > 0 ? B.plan_frames : F) * std::sqrt((double)B.max_n / 125000.0);
         plan = eff <= 9.0 ? PWPP_LATENCY_FIT_PLAN
              : eff <= 15.0 ? "H64:2047"  // (10 / 12 frames: 169 / 184 us per call against 215 / 217 with the next plan; 16: equal)
              : eff <= 76.0 ? "S64:65535"
