@@ -6,7 +6,7 @@ import numpy as np, conftest, torch
 torch.cuda.init()
 import pwpp_hip
 h = pwpp_hip.Handle()
-a = conftest.load_kitti(0); t = torch.from_numpy(a).cuda()
+a = conftest.load_kitti(int(sys.argv[1]) if len(sys.argv) > 1 else 0); t = torch.from_numpy(a).cuda()
 b = h.make_device_batch([t.data_ptr()], [a.shape[0]])
 for i in range(10):
     h.launch_device_batch(b, cols=4, mode=pwpp_hip.MODE_FRESH); h.synchronize()

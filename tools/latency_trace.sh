@@ -2,7 +2,7 @@
 # single frame: kernel durations and the gaps between them from a rocprofv3 kernel trace (no per-kernel events in the stream)
 export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf /tmp/lat_tr
-rocprofv3 --kernel-trace --output-format csv -d /tmp/lat_tr -o t -- python tools/latency_kernels.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/lat_tr -o t -- python tools/latency_kernels.py $1 > /dev/null 2>&1
 python3 - <<'PY'
 import csv,glob,collections,statistics
 f=glob.glob('/tmp/lat_tr/**/t_kernel_trace.csv',recursive=True)[0]
