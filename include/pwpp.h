@@ -326,7 +326,9 @@ PWPP_API int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *
  *                         (default 0.6; 1e30 = no high parts): the fit passes skip a high part whenever they can
  *                         prove that none of its points can enter the pass
  *   "hi_split_zones"      how many zones' bins are stored in two parts (0..4, default 1: the near zone)
- *   "debug_flags"         4: timing probes of the fit chain; 16: exact binning arithmetic only;
+ *   "debug_flags"         4: timing probes of the fit chain; 8: timing probes of the binning, scan and GLE kernels;
+ *                         16: exact binning arithmetic only;
+ *                         128: the first pass of the history statistics always as the reference's sequential sum (no exact shortcut);
  *                         64: before a call that skips the clearing kernel (the last call's K5 zeroed this call's counters),
  *                         read the counters back and fail with PWPP_E_STATE unless every word is zero;
  *                         16384 / 32768: force the fall-back paths of the lowest-point selection

@@ -1042,6 +1042,39 @@ __global__ __launch_bounds__(64) void k_gle_tgr_seq(PwppBatch Bt) {
 // Every double sum keeps the reference's summation order (sequential over <= one ring).
 // ------------------------------------------------------------------------------------------
 constexpr int kGlePer = PWPP_MAX_BINS / kBlock;  // consecutive bins per thread, largest model
+// the largest of the lanes' values in 0..255: a binary search over the bits with ballots (scalar work, no cross-lane data path)
+__device__ __forceinline__ int wave_max_u8(int v) {
+    int cur = 0;
+#pragma unroll
+    for (int bit = 7; bit >= 0; --bit) {
+        const int cand = cur | (1 << bit);
+        if (__ballot(v >= cand)) cur = cand;
+    }
+    return cur;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+// Sum over the wave in butterfly order (quad_perm xor 1, xor 2, row_half_mirror, row_mirror, then the four rows): ONLY for sums
+// that are exact in every order (k_gle_tgr's first pass over a history).  The result is wave-uniform.
+__device__ __forceinline__ double wave_sum_f64_any_order(double v) {
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 16 * k), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 16 * k);
+        r[k] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1455,7 +1488,8 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
 
     // ---- adaptive thresholds for the next frame of this stream (ref :338-375) ---------------
     // lanes 0..3: elevation history of ring i, lanes 4..7: flatness history; sequential sums
-    __shared__ double s_mean[8], s_std[8];
+    __shared__ double s_mean[8], s_std[8], s_psum[8];
+    __shared__ int s_pexact[8];
     // The eight histories (up to max_*_storage + one frame's pushes each) live in global memory, and the
     // reference's sums over them are sequential: one lane per history, ~2 x 1000 dependent f64 adds.
     // Everything else is taken off that chain: all threads stage the histories through LDS in tiles
@@ -1487,10 +1521,63 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
                 }
             }
             __syncthreads();
-            if (step + 1 < 2 * ntiles) fetch(((step + 1) % ntiles) * kHistTile);
+            if (step + 1 < 2 * ntiles && ntiles > 1) fetch(((step + 1) % ntiles) * kHistTile);  // (one tile: the second pass stages the same registers)
+            // Pass 0 without the chain, where that is exact.  The entries of a history are float values held as doubles
+            // (a patch's mean height / smallest singular value, ref :325-326).  If every entry IS a float and the exponents of
+            // the non-zero ones span at most 18 binades, any sum of any of up to 2^11 of them is a multiple of the smallest
+            // entry's last bit and below 2^11 times the largest: 24 + 18 + 11 = 53 bits -- it is exact in a double, so the
+            // reference's sequential sum never rounds and equals the sum taken in any other order: two histories per wave,
+            // seventeen adds per lane and a butterfly.  (A history restored from a checkpoint with arbitrary doubles, a
+            // flatness of 1e-9 beside 1e-2: the lane keeps its sequential loop.)  Only where one tile holds the history (LAT).
+            bool fast0 = false;
+            if (LAT && ntiles == 1 && pass == 0 && !(Bt.debug & 128)) {  // (debug flag 128: always the sequential sum, for the tests)
+                const int wv = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int w = 2 * wv + hh;  // (kBlock = 256: four waves, eight histories)
+                    int n = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) n = q == w ? len_w[q] : n;  // (len_w lives in registers)
+                    // every load in flight at once, four independent partial sums (any order is exact here), the exponent
+                    // range by ballots (eight steps of a binary search each, scalar work), the sum by DPP
+                    constexpr int kPerLane = (kHistTile + 63) / 64;
+                    double xs[kPerLane];
+#pragma unroll
+                    for (int q = 0; q < kPerLane; ++q) {
+                        const int i = ln + 64 * q;
+                        xs[q] = i < n ? tile[w * kHistStride + (i < kHistTile ? i : 0)] : 0.0;
+                    }
+                    double p4[4] = {0.0, 0.0, 0.0, 0.0};
+                    int emax = 0, emin_inv = 0;  // largest exponent, 255 - the smallest one, over this lane's non-zero entries
+                    bool rep = true;
+#pragma unroll
+                    for (int q = 0; q < kPerLane; ++q) {
+                        const double x = xs[q];
+                        p4[q & 3] += x;
+                        const float xf = (float)x;
+                        int e = (int)((__float_as_uint(xf) >> 23) & 0xffu);
+                        rep = rep && (double)xf == x && e != 255;
+                        e = e < 1 ? 1 : e;  // (a denormal's last bit is that of the smallest normal binade)
+                        if (x != 0.0) {
+                            emax = e > emax ? e : emax;
+                            emin_inv = 255 - e > emin_inv ? 255 - e : emin_inv;
+                        }
+                    }
+                    const double ps = wave_sum_f64_any_order((p4[0] + p4[1]) + (p4[2] + p4[3]));
+                    emax = wave_max_u8(emax);
+                    emin_inv = wave_max_u8(emin_inv);
+                    const bool ok = __all(rep) && (emax == 0 || emax - (255 - emin_inv) <= 18);
+                    if (ln == 0 && w < 8) {
+                        s_psum[w] = ps;
+                        s_pexact[w] = ok ? 1 : 0;
+                    }
+                }
+                __syncthreads();
+                fast0 = threadIdx.x < 8 && s_pexact[threadIdx.x & 7] != 0;
+            }
             if (threadIdx.x < 8) {
                 const int left = my_len - base;
-                const int cnt_here = left < 0 ? 0 : (left < kHistTile ? left : kHistTile);
+                const int cnt_here = fast0 ? 0 : (left < 0 ? 0 : (left < kHistTile ? left : kHistTile));
                 const double *row = tile + threadIdx.x * kHistStride;
                 int i = 0;
                 for (; i + 16 <= cnt_here; i += 16) {
@@ -1511,6 +1598,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
                     for (int k2 = 0; k2 < 16; ++k2) acc = i + k2 < cnt_here ? acc + t[k2] : acc;
                 }
                 if (step == ntiles - 1) {  // ref :561
+                    if (fast0) acc = s_psum[threadIdx.x];
                     mean = my_len > 0 ? acc / my_len : 0.0;
                     s_mean[threadIdx.x] = mean;
                     acc = 0.0;

@@ -768,12 +768,16 @@ def test_size_extremes(oracle):
         assert_frame_equal(h2, i, ol.Estimator(oracle, arith=ol.ARITH_FXP).run(mix[i]), mix[i].shape[0])
 
 
-def test_long_sequence_history_trimming(kitti, oracle):
+@pytest.mark.parametrize("flags", [0, 128])
+def test_long_sequence_history_trimming(kitti, oracle, flags):
     """60 consecutive frames on one stateful object and on six lock-step streams: the A-GLE histories
     outgrow max_elevation_storage / max_flatness_storage (1000) after ~25 frames, so the front of the
     history is erased every frame from then on (ref :354-355, :372-373); thresholds, sensor height and
-    the histories themselves must keep following the sequential oracle bit for bit."""
+    the histories themselves must keep following the sequential oracle bit for bit.  flags = 128: the first
+    pass of the history statistics as the reference's sequential sum; 0: its exact shortcut (k_gle_tgr: the
+    entries are float values a few binades apart, so no order of summation rounds) -- both are the oracle's."""
     h = pwpp_hip.Handle()
+    h.set_option("debug_flags", flags)
     est = ol.Estimator(oracle, arith=ol.ARITH_FXP)
     for t in range(60):
         pts = kitti[t % 6]
@@ -788,6 +792,7 @@ def test_long_sequence_history_trimming(kitti, oracle):
     assert max(len(a) for a in ref.hist_elev) == 1000   # the trimming really happened
     S = 6
     hs = pwpp_hip.Handle()
+    hs.set_option("debug_flags", flags)
     hs.set_num_streams(S)
     ests = [ol.Estimator(oracle, arith=ol.ARITH_FXP) for _ in range(S)]
     for t in range(45):
@@ -797,6 +802,31 @@ def test_long_sequence_history_trimming(kitti, oracle):
         if t % 11 == 0 or t > 41:
             for s in range(S):
                 assert_frame_equal(hs, s, refs[s], frames[s].shape[0], state_index=s)
+
+
+def test_history_statistics_shortcut_only_where_it_is_exact(kitti):
+    """k_gle_tgr sums a history in parallel where that cannot round (float-valued entries a few binades apart) and as the
+    reference's sequential sum everywhere else.  Histories restored from a checkpoint may hold anything: here a sum that
+    cancels (1e16 + 1 - 1e16 + 1 ... depends on its order), entries that are no floats (0.1) and a flatness history that
+    spans 40 binades.  The kernel must notice and sum them in order: the state after the next frame equals that of a handle
+    whose shortcut is switched off (debug flag 128)."""
+    elev = np.array([1e16, 1.0, -1e16, 1.0] * 200 + [0.1] * 100)
+    flat = np.array([1e-12, 3.0, 0.1, 2.5e-7] * 225)
+    seen = []
+    for flags in (0, 128):
+        h = pwpp_hip.Handle()
+        h.set_option("debug_flags", flags)
+        h.set_num_streams(1)
+        h.estimate_ground_batch([kitti[0]], mode=pwpp_hip.MODE_STREAMS)
+        for ring in range(4):
+            h.set_history(0, 0, ring, elev[ring:])
+            h.set_history(0, 1, ring, flat[:len(flat) - 3 * ring])
+        for t in (1, 2):
+            h.estimate_ground_batch([kitti[t]], mode=pwpp_hip.MODE_STREAMS)
+        st = h.state(0)
+        seen.append((st.sensor_height, list(st.elevation_thr), list(st.flatness_thr),
+                     [h.history(0, w, r).tobytes() for w in range(2) for r in range(4)], np.sort(h.ground_indices(0)).tobytes()))
+    assert seen[0] == seen[1]
 
 
 def test_handle_reuse_across_modes_and_sizes(kitti, oracle):
