@@ -314,8 +314,8 @@ PWPP_API int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *
  *   "fit_plan"            which fit kernel handles which patch sizes, e.g. "W16:1023,W64.2:65535"; "" = automatic
  *   "fit_concurrent"      "1": the classes of a plan side by side on two streams
  *   "one_pass"            "0": always the two-pass binning
- *   "one_pass_min_frames" smallest batch that takes the one-pass binning (default: 1 for PWPP_MODE_FRESH batches, 5 for
- *                         stream batches, whose state must be copied aside for a redo; setting it sets both)
+ *   "one_pass_min_frames" smallest batch that takes the one-pass binning (default 1; rounds 1-3: 5 for stream batches, whose state
+ *                         must be copied aside for a redo -- the binning pipeline now copies it itself, off the chain)
  *   "one_pass_scale"      segment size of a bin in multiples of its even share of a frame (default 4)
  *   "overlap_ranges"      frame ranges of the overlap mode (default 2; more were slower: 3.38 ms vs 2.86 ms with 4)
  *   "overlap_mode"        "1" (default): binning and lists on the main stream, the ranges' fits on "fit_streams" more;

@@ -121,8 +121,9 @@ struct pwpp_handle {
     std::string fit_plan;
     bool fit_concurrent = false;
     bool no_one_pass = false;
-    int one_pass_min_frames = 5;
-    int one_pass_min_fresh = 1;      // ... and for batches of FRESH frames (no stream state to snapshot: a single frame already gains, 118 -> 107 us)
+    int one_pass_min_frames = 1;     // stream batches (round 4: the state a redo starts from is copied by extra workgroups of k_czm_scan, no
+                                     // copy commands in front of the pipeline any more: one stream 112.8 -> 106.9 us of GPU time, 139 -> 131 us per call)
+    int one_pass_min_fresh = 1;      // ... and batches of FRESH frames (a single frame: 118 -> 107 us in round 3)
     double one_pass_scale = 4.0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     hipEvent_t ev_k[PWPP_NUM_KERNELS + 1] = {};
@@ -605,6 +606,11 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     bt.no_clear = pre_cleared ? 1 : 0;
 
     bt.cap_off = one_pass ? h->d_cap_off.p : nullptr;
+    if (one_pass && h->mode == PWPP_MODE_STREAMS) {  // what a redo after a segment overflow starts from: copied by the binning kernel
+        bt.snap_scalar = h->d_st_snap.p;
+        bt.snap_hist = h->d_hist_snap.p;
+        bt.snap_plane = h->d_pl_snap.p;
+    }
     if (pre_cleared && (bt.debug & 64)) {
         // the pre-cleared path rests on every K5 variant zeroing the OTHER copy of the counters for every frame.
         // Debug option: read this call's copy back before the binning touches it; anything but zeros is a broken invariant.
@@ -1256,9 +1262,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
         if ((rc = h->d_st_snap.ensure((size_t)frames))) return rc;
         if ((rc = h->d_hist_snap.ensure((size_t)frames * slab))) return rc;
         if ((rc = h->d_pl_snap.ensure((size_t)frames))) return rc;
-        HIPCHK(hipMemcpyAsync(h->d_pl_snap.p, h->d_pl_stream.p, (size_t)frames * sizeof(PwppPlaneState), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_st_snap.p, h->d_st_stream.p, (size_t)frames * sizeof(PwppStateScalar), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_hist_snap.p, h->d_hist_stream.p, (size_t)frames * slab * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        // (the copies themselves are made by the binning kernel: PwppBatch.snap_*, set in launch_prepared)
     }
     if ((rc = launch_prepared(h, one_pass))) return rc;
     h->pending = true;

@@ -140,6 +140,13 @@ struct PwppBatch {
     PwppStateScalar *st_scalar;  // [num_states]
     double *st_hist;             // [num_states][2][4][hist_cap]
     PwppPlaneState *st_plane;    // [num_states] the plane members after the state's last frame (zero for a new object)
+    // One-pass binning of stateful streams: what a redo on the exact path must start from (a segment overflow is only known when
+    // the batch has landed, and K5 has updated the streams by then).  Written by one extra workgroup per frame of the binning
+    // kernel -- the CUs are there, a copy command in front of the pipeline costs the host and the stream more than the binning
+    // saves (round 4).  Null: no snapshot (fresh frames, two-pass binning).
+    PwppStateScalar *snap_scalar;  // [num_states]
+    double *snap_hist;             // [num_states][2][4][hist_cap]
+    PwppPlaneState *snap_plane;    // [num_states]
     uint16_t *codes;             // [total points]
     uint32_t *part_count;        // [frames][2B+2] points per part (K1 / K1' histogram)
     uint32_t *part_off;          // [frames][2B+2] first slot of every part in the sorted_* planes (relative to sbase)

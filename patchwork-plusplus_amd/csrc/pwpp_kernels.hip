@@ -440,6 +440,41 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     // threads just wrote to global memory is a round trip of its own, and a single frame waits for this chain)
     __shared__ unsigned s_pc[PWPP_NUM_PARTS(PWPP_MAX_BINS)], s_po[PWPP_NUM_PARTS(PWPP_MAX_BINS)];
     const int f = blockIdx.x;
+    if (blockIdx.y >= 1) {
+        // One-pass binning of stateful streams (pwpp_dev.h, snap_*): eight more workgroups per frame copy the stream's state as
+        // it is before this call -- what a redo after a segment overflow starts from -- beside the scan, off its chain: one
+        // history each (a single workgroup took 9.5 us for the eight 1000-entry histories, the scan takes 5.8), the first of
+        // them the scalars and the plane members as well.
+        if (!Bt.snap_scalar) return;
+        const int st = Bt.frames[f].state_in;
+        if (st < 0) return;
+        static_assert(sizeof(PwppStateScalar) % 4 == 0 && sizeof(PwppPlaneState) % 4 == 0 &&
+                      offsetof(PwppStateScalar, flat_len) == offsetof(PwppStateScalar, elev_len) + 16, "copied word by word; lengths read as one array");
+        const unsigned *ss = reinterpret_cast<const unsigned *>(Bt.st_scalar + st), *ps = reinterpret_cast<const unsigned *>(Bt.st_plane + st);
+        const int w = (int)blockIdx.y - 1;  // this workgroup's history: elevation of ring 0-3, flatness of ring 0-3
+        if (w == 0) {
+            if (threadIdx.x < sizeof(PwppStateScalar) / 4) reinterpret_cast<unsigned *>(Bt.snap_scalar + st)[threadIdx.x] = ss[threadIdx.x];
+            if (threadIdx.x < sizeof(PwppPlaneState) / 4) reinterpret_cast<unsigned *>(Bt.snap_plane + st)[threadIdx.x] = ps[threadIdx.x];
+        }
+        const int *lens = Bt.st_scalar[st].elev_len;  // elev_len[4], flat_len[4]
+        int len = lens[w];
+        len = len < Bt.P.hist_cap ? len : Bt.P.hist_cap;
+        const size_t row = ((size_t)st * 8 + (size_t)w) * (size_t)Bt.P.hist_cap;
+        for (int i0 = 0; i0 < len; i0 += 4 * kBlock) {  // (four entries per thread in flight)
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * kBlock + (int)threadIdx.x;
+                v[q] = i < len ? Bt.st_hist[row + i] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * kBlock + (int)threadIdx.x;
+                if (i < len) Bt.snap_hist[row + i] = v[q];
+            }
+        }
+        return;
+    }
     const int B = Bt.P.num_bins, NB = B + 2, NP = PWPP_NUM_PARTS(B);
     int probe_i = 16;  // timing probes (debug_flags & 8): slots 16.. of the probe array (tools/k5_chain.py)
     auto probe = [&]() {
@@ -2367,7 +2402,7 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
                 else hipLaunchKernelGGL(k_czm_bin_scatter<1024>, grid, dim3(1024), binning_lds_bytes(B, 2), stream, B, tpf);
             }
             if (ev) (void)hipEventRecord(ev[1], stream);
-            hipLaunchKernelGGL(k_czm_scan, dim3(F), dim3(kBlock), 0, stream, B);
+            hipLaunchKernelGGL(k_czm_scan, dim3(F, B.snap_scalar ? 9 : 1), dim3(kBlock), 0, stream, B);  // (+ eight snapshot workgroups per frame)
             if (ev) (void)hipEventRecord(ev[2], stream);
         } else {
             if (gx > 0) hipLaunchKernelGGL(k_czm_bin, dim3(gx, F), dim3(kBlock), binning_lds_bytes(B, 1), stream, B);
