@@ -376,6 +376,7 @@ void sync_all_streams(pwpp_handle *h) {
 
 // the stream history slabs [stream][2][4][cap] re-laid out for a larger cap (contents kept)
 int grow_stream_histories(pwpp_handle *h, int new_cap) {
+    new_cap = (new_cap + 1) & ~1;  // (even: k_gle_tgr fetches two entries per load)
     const size_t rows = (size_t)h->num_streams * 8;
     DevBuf<double> bigger;
     int rc = bigger.ensure(rows * (size_t)new_cap);
@@ -956,9 +957,9 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
                      h->fit_plan.c_str(), (int)h->fit_concurrent, (int)h->no_one_pass, h->one_pass_min_frames, h->one_pass_scale,
                      std::getenv("PWPP_OVERLAP") ? std::atoi(std::getenv("PWPP_OVERLAP")) : 1, (double)h->dp.hi_split, h->dp.split_end);
     const int storage = p->max_elevation_storage > p->max_flatness_storage ? p->max_elevation_storage : p->max_flatness_storage;
-    h->stream_hist_cap = storage + max_near_sectors + 1024;
+    h->stream_hist_cap = (storage + max_near_sectors + 1024 + 1) & ~1;  // (even: k_gle_tgr fetches the histories two entries at a time)
     h->max_pushes_per_frame = max_near_sectors;
-    h->fresh_hist_cap = max_near_sectors + 2;
+    h->fresh_hist_cap = (max_near_sectors + 2 + 1) & ~1;
     if (const char *e = std::getenv("PWPP_OVERLAP")) h->overlap = std::atoi(e) != 0;  // (pwpp_set_overlap; PWPP_OVERLAP=0 runs existing programs on one stream)
     hipError_t se = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);

@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     // for the threshold statistics at the end of the kernel, the loads fly while TGR and the list
     // offsets are worked out.
     constexpr int kHistTile = LAT ? 1056 : 496, kHistStride = kHistTile + 2;  // 8 rows, 16-byte aligned, on distinct LDS banks
-    constexpr int kHistPer = (kHistTile + kBlock - 1) / kBlock;
+    static_assert(kHistTile % 2 == 0 && kHistStride % 2 == 0, "pairs of entries");
     static_assert(LAT || sizeof(s_e) >= sizeof(double) * 8 * kHistStride, "history tile must fit into the retired s_e");
     __shared__ __attribute__((aligned(16))) double s_tile_lat[LAT ? 8 * kHistStride : 2];
     int len_w[8], maxlen = 0;
@@ -1401,15 +1401,19 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     bool fresh_hist = LAT && s_dropped == 0;
 #pragma unroll
     for (int k = 0; k < PWPP_MAX_ROI; ++k) fresh_hist = fresh_hist && s_len0[0][k] == 0 && s_len0[1][k] == 0;
-    double v[8][kHistPer];
+    // (two entries per thread and load: a 256-thread workgroup issuing forty 8-byte loads per thread took 3.2 us to ISSUE them;
+    // the slabs' rows start 16-byte aligned -- hist_cap is even -- and a pair that straddles the end of a history reads one
+    // entry of slack, never beyond the row)
+    constexpr int kHistPer2 = (kHistTile + 2 * kBlock - 1) / (2 * kBlock);
+    double2 v[8][kHistPer2];
     auto fetch = [&](int base) {  // unconditional loads (clamped), all in flight together
 #pragma unroll
         for (int w = 0; w < 8; ++w)
 #pragma unroll
-            for (int q = 0; q < kHistPer; ++q) {
-                if (base + q * kBlock >= maxlen) continue;  // (uniform) nothing that far in any history
-                const int i = base + q * kBlock + (int)threadIdx.x;
-                v[w][q] = hist_out[(size_t)w * P.hist_cap + (i < len_w[w] ? i : 0)];
+            for (int q = 0; q < kHistPer2; ++q) {
+                if (base + q * 2 * kBlock >= maxlen) continue;  // (uniform) nothing that far in any history
+                const int i = base + 2 * (q * kBlock + (int)threadIdx.x);
+                v[w][q] = *reinterpret_cast<const double2 *>(hist_out + (size_t)w * P.hist_cap + (i < len_w[w] && i + 1 < P.hist_cap ? i : 0));
             }
     };
     if (ntiles > 0 && !fresh_hist) fetch(0);
@@ -1549,10 +1553,12 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
             for (int w = 0; w < 8; ++w) {
                 const double m = s_mean[w];
 #pragma unroll
-                for (int q = 0; q < kHistPer; ++q) {
-                    if (base + q * kBlock >= maxlen) continue;
-                    const int i = q * kBlock + (int)threadIdx.x;
-                    if (i < kHistTile) tile[w * kHistStride + i] = pass ? (v[w][q] - m) * (v[w][q] - m) : v[w][q];  // ref :564
+                for (int q = 0; q < kHistPer2; ++q) {
+                    if (base + q * 2 * kBlock >= maxlen) continue;
+                    const int i = 2 * (q * kBlock + (int)threadIdx.x);
+                    if (i + 1 < kHistTile)  // (kHistTile is even)
+                        *reinterpret_cast<double2 *>(tile + w * kHistStride + i) =
+                            pass ? make_double2((v[w][q].x - m) * (v[w][q].x - m), (v[w][q].y - m) * (v[w][q].y - m)) : v[w][q];  // ref :564
                 }
             }
             __syncthreads();
