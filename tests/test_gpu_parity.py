@@ -829,6 +829,32 @@ def test_history_statistics_shortcut_only_where_it_is_exact(kitti):
     assert seen[0] == seen[1]
 
 
+def test_history_statistics_of_a_big_stream_batch_equal_the_single_stream_kernel(kitti):
+    """k_gle_tgr has two variants: up to 64 frames a workgroup stages a whole 1000-entry history in one LDS tile (the variant the
+    long-sequence tests hold against the oracle), larger batches walk it in tiles of 496 entries, fetched two entries per load
+    while the tile before is summed.  Here stream 0 of a 70-stream batch and a single stream start from the same restored
+    histories (900-1030 float-valued entries: two to three tiles, trimming included) and see the same two frames: thresholds,
+    sensor height, histories and ground sets must be identical."""
+    rng = np.random.default_rng(77)
+    hist = [[(rng.normal(-1.73, 0.05, 900 + 37 * r + 11 * w)).astype(np.float32).astype(np.float64) if w == 0 else
+             np.abs(rng.normal(2e-3, 1e-3, 905 + 29 * r)).astype(np.float32).astype(np.float64) for r in range(4)] for w in range(2)]
+    got = []
+    for S in (70, 1):
+        h = pwpp_hip.Handle()
+        h.set_num_streams(S)
+        h.estimate_ground_batch([kitti[(s + 3) % 6] for s in range(S)], mode=pwpp_hip.MODE_STREAMS)  # (the streams exist now)
+        for w in range(2):
+            for r in range(4):
+                h.set_history(0, w, r, hist[w][r])
+        for t in (1, 2):
+            h.estimate_ground_batch([kitti[t]] + [kitti[(s + t) % 6] for s in range(1, S)], mode=pwpp_hip.MODE_STREAMS)
+        st = h.state(0)
+        got.append((st.sensor_height, list(st.elevation_thr), list(st.flatness_thr),
+                    [h.history(0, w, r).tobytes() for w in range(2) for r in range(4)], np.sort(h.ground_indices(0)).tobytes()))
+    assert got[0] == got[1]
+    assert max(len(x) for x in got[0][3]) // 8 == 1000  # (the longest histories were trimmed to max_*_storage on the way)
+
+
 def test_handle_reuse_across_modes_and_sizes(kitti, oracle):
     """One handle, interleaved: lock-step streams, a fresh batch (one-pass), a single fresh frame, a
     bigger fresh batch, reference-order mode on and off.  The streams' adaptive state lives in its own
