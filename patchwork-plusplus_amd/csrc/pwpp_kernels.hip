@@ -1570,6 +1570,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
             // reference's sequential sum never rounds and equals the sum taken in any other order: two histories per wave,
             // seventeen adds per lane and a butterfly.  (A history restored from a checkpoint with arbitrary doubles, a
             // flatness of 1e-9 beside 1e-2: the lane keeps its sequential loop.)  Only where one tile holds the history (LAT).
+            static_assert(kHistTile <= 2048, "the exactness argument below counts on at most 2^11 entries per history tile");
             bool fast0 = false;
             if (LAT && ntiles == 1 && pass == 0 && !(Bt.debug & 128)) {  // (debug flag 128: always the sequential sum, for the tests)
                 const int wv = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63;
