@@ -301,9 +301,14 @@ PWPP_API int pwpp_set_output_order(pwpp_handle *h, int order);
  * schedule.  pwpp_set_overlap(h, 0) / PWPP_OVERLAP=0 select that schedule for everything. */
 PWPP_API int pwpp_set_overlap(pwpp_handle *h, int on);
 /* one-pass binning (fixed bin segments; DESIGN.md 3, K1'): batches launched that way and how many of
- * them had to be redone on the exact two-pass path because a bin outgrew its segment.  Finishes the
- * batch in flight first.  No reference counterpart. */
+ * them had at least one frame redone on the exact two-pass path because a bin outgrew its segment.  Finishes the
+ * batch in flight first.  No reference counterpart (its bins are unbounded vectors, patchworkpp.cpp:578-622). */
 PWPP_API int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone);
+/* ... and the same per FRAME: frames that went through one-pass binning, and how many of them were redone.  An
+ * overflow costs the frames it happened in, not their batch (round 5): such a frame is binned again, exactly and
+ * in place, while the other frames' results stand; only a frame too large for its own slots of the one-pass layout
+ * (or the option "redo_whole_batch") sends the whole batch through the two-pass path, and then every frame counts. */
+PWPP_API int pwpp_get_redo_stats(pwpp_handle *h, int64_t *frames_one_pass, int64_t *frames_redone);
 
 
 /* Tuning and test switches (no reference counterpart).  The environment variables PWPP_DEBUG_FLAGS,
@@ -314,6 +319,8 @@ PWPP_API int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *
  *   "fit_plan"            which fit kernel handles which patch sizes, e.g. "W16:1023,W64.2:65535"; "" = automatic
  *   "fit_concurrent"      "1": the classes of a plan side by side on two streams
  *   "one_pass"            "0": always the two-pass binning
+ *   "redo_whole_batch"    "1": a segment overflow of the one-pass binning redoes every frame of the batch (rounds 1-4) instead of
+ *                         the frames that overflowed
  *   "one_pass_min_frames" smallest batch that takes the one-pass binning (default 1; rounds 1-3: 5 for stream batches, whose state
  *                         must be copied aside for a redo -- the binning pipeline now copies it itself, off the chain)
  *   "one_pass_scale"      segment size of a bin in multiples of its even share of a frame (default 4)

@@ -149,7 +149,10 @@ struct pwpp_handle {
     int max_n = 0;
     int64_t total_points = 0;
     int cols = 4, layout = 0;
-    long long one_pass_batches = 0, one_pass_redone = 0;
+    long long one_pass_batches = 0, one_pass_redone = 0;  // batches on the one-pass path; of those, batches with at least one frame redone
+    long long one_pass_frames = 0, one_pass_redone_frames = 0;  // the same per frame (pwpp_get_redo_stats)
+    std::vector<uint8_t> frame_two_pass;  // frames of the last one-pass batch that were redone in place (compact layout at their own first slot)
+    bool redo_whole_batch = false;        // option "redo_whole_batch": an overflow redoes every frame of the batch (rounds 1-4; tests, A/B)
     long long fixed_up_frames = 0;   // frames finished by k_fit_fixup (a patch needed the plane fitted before it)
     long long clamped_frames = 0;    // frames with a patch whose final ground set spanned more than z0 +- ZR (PwppFrameResult.overflow bit 2)
 
@@ -436,10 +439,12 @@ int read_observed(pwpp_handle *h) {
     return PWPP_OK;
 }
 
-// Histogram of up to 16 frames spread over the batch described by h->descs (inputs already on their way to the device):
+// Histogram of up to 256 frames spread over the batch described by h->descs (inputs already on their way to the device):
 // K0 + K1 + K2 on a private descriptor array, which leaves the bins' largest counts in d_bin_max.
 int probe_histogram(pwpp_handle *h) {
-    const int S = h->frames < 32 ? h->frames : 32;
+    // (round 5: up to 256 sample frames -- with 32, 353 of the first 512 frames of a varied drive outgrew some segment (bench.py,
+    // `distinct` leg); the probe is a histogram pass, ~1 us per frame)
+    const int S = h->frames < 256 ? h->frames : 256;
     std::vector<PwppFrameDesc> sample((size_t)S);
     int max_n = 0;
     for (int i = 0; i < S; ++i) {
@@ -756,25 +761,78 @@ int finish_pending(pwpp_handle *h) {
         h->profile_pending = false;
     }
     const bool was_one_pass = h->one_pass;
-    if (h->one_pass) {  // did every bin fit its segment?  if not, redo the batch on the exact two-pass path
-        bool over = false;
-        for (int f = 0; f < h->frames; ++f) over = over || (h->h_results.p[f].overflow & 1) != 0;
+    bool redone_in_place = false;
+    if (h->one_pass) {  // did every bin of every frame fit its segment?  the frames that did not are redone on the exact two-pass path
+        std::vector<int> redo;
+        for (int f = 0; f < h->frames; ++f)
+            if (h->h_results.p[f].overflow & 1) redo.push_back(f);
         h->one_pass = false;
-        if (over) {
+        h->frame_two_pass.assign((size_t)h->frames, 0);
+        if (!redo.empty()) {
             ++h->one_pass_redone;
             h->one_pass_holdoff = 0;  // (the redo's exact counts enter d_bin_max and the table is rebuilt: no need to stay away)
             h->table_stale = true;
-            if (h->mode == PWPP_MODE_STREAMS) {  // back to the streams' state before the first attempt
-                const size_t slab = (size_t)8 * (size_t)h->stream_hist_cap;
-                HIPCHK(hipMemcpyAsync(h->d_st_stream.p, h->d_st_snap.p, (size_t)h->frames * sizeof(PwppStateScalar), hipMemcpyDeviceToDevice, h->stream));
-                HIPCHK(hipMemcpyAsync(h->d_pl_stream.p, h->d_pl_snap.p, (size_t)h->frames * sizeof(PwppPlaneState), hipMemcpyDeviceToDevice, h->stream));
-                HIPCHK(hipMemcpyAsync(h->d_hist_stream.p, h->d_hist_snap.p, (size_t)h->frames * slab * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            // A frame is redone IN PLACE: its compact two-pass layout (points + the parts' alignment pads) starts at the frame's own
+            // first slot of the one-pass layout, whose segments are ~2.7 slots per point -- the other frames of the batch are not
+            // touched (frames are independent: fresh state, or one stream each).  Only a frame that would not fit its own
+            // slots (a table built from much smaller frames) sends the whole batch through the compact layout.
+            const int NP = PWPP_NUM_PARTS(h->dp.num_bins);
+            bool in_place = !h->redo_whole_batch;
+            for (int f : redo) {
+                const int64_t need = (int64_t)h->descs[(size_t)f].n + (int64_t)(PWPP_SLOT_ALIGN - 1) * NP + PWPP_SLOT_ALIGN;
+                if (need > h->slots_per_frame) in_place = false;
             }
-            int rc = launch_prepared(h, false);
-            if (rc) return rc;
-            h->pending = true;
-            if ((rc = finish_pending(h))) return rc;
-            return read_observed(h);  // the exact counts of the redo size the next table
+            if (h->mode == PWPP_MODE_STREAMS) {  // back to the state before the first attempt -- of the streams that are redone
+                const size_t slab = (size_t)8 * (size_t)h->stream_hist_cap;
+                if (!in_place) {
+                    HIPCHK(hipMemcpyAsync(h->d_st_stream.p, h->d_st_snap.p, (size_t)h->frames * sizeof(PwppStateScalar), hipMemcpyDeviceToDevice, h->stream));
+                    HIPCHK(hipMemcpyAsync(h->d_pl_stream.p, h->d_pl_snap.p, (size_t)h->frames * sizeof(PwppPlaneState), hipMemcpyDeviceToDevice, h->stream));
+                    HIPCHK(hipMemcpyAsync(h->d_hist_stream.p, h->d_hist_snap.p, (size_t)h->frames * slab * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                } else {
+                    for (int f : redo) {
+                        HIPCHK(hipMemcpyAsync(h->d_st_stream.p + f, h->d_st_snap.p + f, sizeof(PwppStateScalar), hipMemcpyDeviceToDevice, h->stream));
+                        HIPCHK(hipMemcpyAsync(h->d_pl_stream.p + f, h->d_pl_snap.p + f, sizeof(PwppPlaneState), hipMemcpyDeviceToDevice, h->stream));
+                        HIPCHK(hipMemcpyAsync(h->d_hist_stream.p + (size_t)f * slab, h->d_hist_snap.p + (size_t)f * slab, slab * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                    }
+                }
+            }
+            if (!in_place) {
+                h->one_pass_redone_frames += h->frames;
+                int rc = launch_prepared(h, false);
+                if (rc) return rc;
+                h->pending = true;
+                if ((rc = finish_pending(h))) return rc;
+                return read_observed(h);  // the exact counts of the redo size the next table
+            }
+            h->one_pass_redone_frames += (long long)redo.size();
+            PwppBatch bt;
+            fill_batch(h, bt);
+            bt.cap_off = nullptr;  // compact layout, exact two-pass binning (K1, K2, K3)
+            bt.next_slabs = 1;     // (the other copy of the counters was zeroed for a one-pass call by the first attempt's K5 already)
+            const bool ordered = h->output_order == PWPP_ORDER_REFERENCE;
+            for (size_t i = 0; i < redo.size();) {  // runs of neighbouring frames go through the pipeline together
+                size_t j = i + 1;
+                while (j < redo.size() && redo[j] == redo[j - 1] + 1) ++j;
+                const int f0 = redo[i], nf = (int)(j - i);
+                PwppBatch v = frame_range(h, bt, f0, nf);  // (no_clear set: the three counter slabs of a frame RANGE are not adjacent)
+                int vmax = 0;
+                for (int f = f0; f < f0 + nf; ++f) {
+                    h->frame_two_pass[(size_t)f] = 1;
+                    vmax = h->descs[(size_t)f].n > vmax ? h->descs[(size_t)f].n : vmax;
+                }
+                v.max_n = vmax;
+                const size_t words = (size_t)nf * (size_t)NP * sizeof(uint32_t);
+                HIPCHK(hipMemsetAsync(v.part_count, 0, words, h->stream));
+                HIPCHK(hipMemsetAsync(v.part_off, 0, words, h->stream));
+                HIPCHK(hipMemsetAsync(v.part_cursor, 0, words, h->stream));
+                HIPCHK(hipMemsetAsync(v.results, 0, (size_t)nf * sizeof(PwppFrameResult), h->stream));
+                const int lrc = pwpp_launch_pipeline(&v, h->stream, nullptr, nullptr, nullptr, nullptr, ordered ? h->d_ord_a.p : nullptr,
+                                                     ordered ? h->d_ord_b.p : nullptr, 7);
+                if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+                i = j;
+            }
+            HIPCHK(hipStreamSynchronize(h->stream));
+            redone_in_place = true;
         }
     }
     // Frames with a patch whose first fit set was empty (pwpp_fit.hip: needs_previous_plane -- a lowest height of -inf or
@@ -786,12 +844,12 @@ int finish_pending(pwpp_handle *h) {
         if (any) {
             PwppBatch bt;
             fill_batch(h, bt);
-            bt.cap_off = was_one_pass ? h->d_cap_off.p : nullptr;
             bt.fixup_run = 1;
             const bool ordered = h->output_order == PWPP_ORDER_REFERENCE;
             for (int f = 0; f < h->frames; ++f) {
                 if (!(h->h_results.p[f].overflow & 2)) continue;
-                const PwppBatch v = frame_range(h, bt, f, 1);
+                PwppBatch v = frame_range(h, bt, f, 1);
+                v.cap_off = was_one_pass && !h->frame_two_pass[(size_t)f] ? h->d_cap_off.p : nullptr;  // (a frame redone in place is in the compact layout)
                 const int lrc = pwpp_launch_pipeline(&v, h->stream, nullptr, nullptr, nullptr, nullptr, ordered ? h->d_ord_a.p : nullptr,
                                                      ordered ? h->d_ord_b.p : nullptr, 2 | 4 | 8);
                 if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
@@ -803,7 +861,10 @@ int finish_pending(pwpp_handle *h) {
     for (int f = 0; f < h->frames; ++f)
         if (h->h_results.p[f].overflow & 4) ++h->clamped_frames;
     h->have_results = true;
-    if (was_one_pass) {
+    if (redone_in_place) {  // the exact counts of the redone frames are in d_bin_max now: they size the next table
+        const int rc = read_observed(h);
+        if (rc) return rc;
+    } else if (was_one_pass) {
         // a bin that came within 10 % of its segment's capacity: grow the table before the next batch
         h->observed.assign(h->h_bin_max.p, h->h_bin_max.p + h->cap_table.size());
         for (size_t b = 0; b < h->cap_table.size() && !h->table_stale; ++b)
@@ -1241,7 +1302,9 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     }
 
     // ---- 4. the bin-ordered buffers (slack: the fit kernels fetch whole chunks, up to 512 points beyond a patch's end)
-    if (one_pass && (h->d_sorted_z.ensure(bin_slots + 1024) || h->d_sorted_xy.ensure(bin_slots + 1024) || h->d_sorted_idx.ensure(bin_slots))) {
+    const size_t member_pads = (size_t)frames * (size_t)NP * PWPP_MEMBER_PAD + 4096;
+    if (one_pass && (h->d_sorted_z.ensure(bin_slots + 1024) || h->d_sorted_xy.ensure(bin_slots + 1024) || h->d_sorted_idx.ensure(bin_slots) ||
+                     h->d_member.ensure(bin_slots / 8 + member_pads))) {  // (the membership plane is part of the trial, not a hard error after it)
         one_pass = false;  // the big allocation failed after all (fragmentation): compact layout, two-pass binning
         bin_slots = compact_slots;
         (void)hipGetLastError();
@@ -1249,7 +1312,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     if ((rc = h->d_sorted_z.ensure(bin_slots + 1024))) return rc;
     if ((rc = h->d_sorted_xy.ensure(bin_slots + 1024))) return rc;
     if ((rc = h->d_sorted_idx.ensure(bin_slots))) return rc;
-    if ((rc = h->d_member.ensure(bin_slots / 8 + (size_t)frames * (size_t)NP * PWPP_MEMBER_PAD + 4096))) return rc;
+    if ((rc = h->d_member.ensure(bin_slots / 8 + member_pads))) return rc;
 
     h->frames = frames;
     h->mode = mode;
@@ -1257,7 +1320,11 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     h->total_points = total;
     h->cols = cols;
     h->layout = layout;
-    if (one_pass) ++h->one_pass_batches;
+    if (one_pass) {
+        ++h->one_pass_batches;
+        h->one_pass_frames += frames;
+    }
+    h->frame_two_pass.clear();
     if (one_pass && mode == PWPP_MODE_STREAMS) {  // stream i = frame i: keep what a redo must start from
         const size_t slab = (size_t)8 * (size_t)h->stream_hist_cap;
         if ((rc = h->d_st_snap.ensure((size_t)frames))) return rc;
@@ -1641,6 +1708,8 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
         h->fit_concurrent = std::atoi(value) != 0;
     } else if (k == "one_pass") {
         h->no_one_pass = std::atoi(value) == 0;
+    } else if (k == "redo_whole_batch") {
+        h->redo_whole_batch = std::atoi(value) != 0;
     } else if (k == "one_pass_min_frames") {
         const int v = std::atoi(value);
         if (v < 1) return fail(PWPP_E_ARG, "one_pass_min_frames=%s: >= 1 expected", value);
@@ -1771,6 +1840,16 @@ int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone) {
     if ((rc = finish_pending(h))) return rc;
     if (batches) *batches = h->one_pass_batches;
     if (redone) *redone = h->one_pass_redone;
+    return PWPP_OK;
+}
+
+int pwpp_get_redo_stats(pwpp_handle *h, int64_t *frames_one_pass, int64_t *frames_redone) {
+    if (!h) return fail(PWPP_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    if (frames_one_pass) *frames_one_pass = h->one_pass_frames;
+    if (frames_redone) *frames_redone = h->one_pass_redone_frames;
     return PWPP_OK;
 }
 

@@ -506,6 +506,9 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
                 if (p >= NP) continue;
                 const unsigned cap = nxt[q] - seg[q];
                 poff[p] = seg[q];
+                // what the host sizes the segments of the NEXT batches from: the part's TRUE count (the binning kernel counts every
+                // point it meets, stored or not), so the table is right after ONE overflow, redo or not
+                if (c[q] > mx[q]) atomicMax(&Bt.bin_max[p], c[q]);
                 if (c[q] > cap) {
                     c[q] = cap;
                     pcnt[p] = cap;
@@ -513,9 +516,6 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
                 }
                 s_pc[p] = c[q];
                 s_po[p] = seg[q];
-                // what the host sizes the segments of the NEXT batches from (an overflowed part reports its clamped count
-                // here; the exact redo that follows reports the true one)
-                if (c[q] > mx[q]) atomicMax(&Bt.bin_max[p], c[q]);
             }
         }
     } else {

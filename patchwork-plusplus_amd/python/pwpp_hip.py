@@ -114,6 +114,7 @@ def load():
         L.pwpp_get_workspace_bytes.argtypes = [vp]
         L.pwpp_get_workspace_bytes.restype = ctypes.c_int64
         L.pwpp_get_one_pass_stats.argtypes = [vp, vp, vp]
+        L.pwpp_get_redo_stats.argtypes = [vp, vp, vp]
         L.pwpp_set_output_order.argtypes = [vp, ci]
         L.pwpp_set_overlap.argtypes = [vp, ci]
         L.pwpp_kernel_name.argtypes = [ci]
@@ -414,6 +415,12 @@ class Handle:
     def set_overlap(self, on):
         """True: batches of 128+ frames run as two frame ranges on the handle's two streams (same results)."""
         self._check(self._L.pwpp_set_overlap(self._h, 1 if on else 0))
+
+    def redo_stats(self):
+        """(frames that went through one-pass binning, frames redone on the two-pass path after a segment overflow)"""
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._L.pwpp_get_redo_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
 
     def one_pass_stats(self):
         """(batches launched with one-pass binning, batches redone on the two-pass path after an overflow)"""

@@ -247,3 +247,23 @@ def jacobi(cov):
     sv = np.zeros(3, np.float32)
     restatement().lib.pwo_ext_jacobi(_vp(cov), _vp(u), _vp(sv))
     return u.reshape(3, 3), sv
+
+
+if __name__ == "__main__":
+    # Worker of bench.py's cpu_baseline: one single-threaded process of the frame-parallel CPU harness.
+    #   oracle_lib.py --bench-worker FRAMES.npz COUNT T_GO KIND ARITH
+    # loads the library and the frames, waits for the wall-clock mark T_GO, runs COUNT frames (fresh object each) on ONE thread
+    # and prints "t_begin t_end frames".
+    import sys
+    import time
+    if len(sys.argv) >= 7 and sys.argv[1] == "--bench-worker":
+        _z = np.load(sys.argv[2])
+        _frames = [_z[k] for k in _z.files]
+        _count, _t_go, _kind, _arith = int(sys.argv[3]), float(sys.argv[4]), sys.argv[5], int(sys.argv[6])
+        _lib = reference(_arith) if _kind == "reference" else restatement()
+        cpu_bench(_lib, _frames, len(_frames), 1, arith=_arith)  # (pages, caches)
+        while time.time() < _t_go:
+            time.sleep(0.002)
+        _b = time.time()
+        cpu_bench(_lib, _frames, _count, 1, arith=_arith)
+        print(_b, time.time(), _count)

@@ -155,6 +155,7 @@ def test_multi_stream_one_pass_with_state_restore(kitti, oracle):
         redone.append(h.one_pass_stats())
     # (the redo's exact counts size the segments of the following batches: one-pass again, and nothing more is redone)
     assert redone[0] == (1, 0) and redone[1] == (2, 1) and redone[2] == (3, 1) and redone[11] == (12, 1)
+    assert h.redo_stats() == (12 * S, 1)  # only stream 3 went back to its state before step 1 and was redone
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
@@ -622,6 +623,73 @@ def test_one_pass_binning_and_its_overflow_fallback(kitti, oracle):
     assert h2.one_pass_stats() == (1, 1)
 
 
+def test_an_overflow_costs_its_frame_not_the_batch(kitti, oracle):
+    """the reference's bins are unbounded vectors (patchworkpp.cpp:578-622), the one-pass binning gives
+    every bin a fixed segment.  One frame of 256 overflows its segments: exactly that frame is binned again (exact
+    two-pass path, in place), every one of the 256 frames is the oracle's bit for bit, fresh frames and reference-ordered
+    lists alike; with the option "redo_whole_batch" (rounds 1-4) every frame counts as redone and the results are the same.
+    Then three outliers, two of them neighbours (one run through the pipeline), and one at each end of the batch."""
+    rng = np.random.default_rng(5)
+
+    def wedge_of(src, lo):
+        w = src.copy()
+        sel = rng.random(w.shape[0]) < 0.7
+        r = np.hypot(w[sel, 0], w[sel, 1])
+        a = rng.uniform(lo, lo + 0.17, sel.sum())
+        w[sel, 0] = (r * np.cos(a)).astype(np.float32)
+        w[sel, 1] = (r * np.sin(a)).astype(np.float32)
+        return w
+
+    est = lambda p: ol.Estimator(oracle, arith=ol.ARITH_FXP).run(p)
+    refs = [est(k) for k in kitti]
+    F = 256
+    base = [kitti[i % 6] for i in range(F)]
+    h = pwpp_hip.Handle()
+    h.estimate_ground_batch(base, mode=pwpp_hip.MODE_FRESH)
+    assert h.one_pass_stats() == (1, 0) and h.redo_stats() == (F, 0)
+    w0 = wedge_of(kitti[0], 0.1)
+    odd = list(base)
+    odd[77] = w0
+    h.estimate_ground_batch(odd, mode=pwpp_hip.MODE_FRESH)
+    assert h.one_pass_stats() == (2, 1) and h.redo_stats() == (2 * F, 1)
+    rw0 = est(w0)
+    for i in range(F):
+        assert_frame_equal(h, i, rw0 if i == 77 else refs[i % 6], odd[i].shape[0], check_state=(i % 32 == 13))
+    # the redone frame's exact counts sized the table: the same batch fits now
+    h.estimate_ground_batch(odd, mode=pwpp_hip.MODE_FRESH)
+    assert h.redo_stats() == (3 * F, 1)
+    assert_frame_equal(h, 77, rw0, w0.shape[0])
+    # three outliers in other sectors: first frame, two neighbours, last frame
+    w1, w2, w3 = wedge_of(kitti[1], 1.3), wedge_of(kitti[2], 2.6), wedge_of(kitti[3], -2.0)
+    odd2 = list(base)
+    odd2[0], odd2[100], odd2[101], odd2[F - 1] = w1, w2, w3, w1
+    h.estimate_ground_batch(odd2, mode=pwpp_hip.MODE_FRESH)
+    assert h.redo_stats() == (4 * F, 5)
+    special = {0: est(w1), 100: est(w2), 101: est(w3), F - 1: est(w1)}
+    for i in list(special) + [1, 99, 102, 128, F - 2]:
+        assert_frame_equal(h, i, special.get(i, refs[i % 6]), odd2[i].shape[0])
+    # rounds 1-4's behaviour behind an option: same results, every frame redone
+    h2 = pwpp_hip.Handle()
+    h2.set_option("redo_whole_batch", 1)
+    h2.estimate_ground_batch(base, mode=pwpp_hip.MODE_FRESH)
+    h2.estimate_ground_batch(odd, mode=pwpp_hip.MODE_FRESH)
+    assert h2.one_pass_stats() == (2, 1) and h2.redo_stats() == (2 * F, F)
+    for i in (0, 76, 77, 78, F - 1):
+        assert_frame_equal(h2, i, rw0 if i == 77 else refs[i % 6], odd[i].shape[0])
+    # reference-ordered lists (single-stream schedule + the sort kernels) through the same in-place redo
+    h3 = pwpp_hip.Handle()
+    h3.set_output_order(True)
+    small = [kitti[i % 6] for i in range(12)]
+    h3.estimate_ground_batch(small, mode=pwpp_hip.MODE_FRESH)
+    small[5] = w0
+    h3.estimate_ground_batch(small, mode=pwpp_hip.MODE_FRESH)
+    assert h3.redo_stats() == (24, 1)
+    for i in (4, 5, 6):
+        r = rw0 if i == 5 else refs[i % 6]
+        assert_frame_equal(h3, i, r, small[i].shape[0])
+        assert np.array_equal(small[i][h3.ground_indices(i), 2], small[i][r.ground_idx, 2])  # same heights position by position (ties in cloud order)
+
+
 def test_point_order_invariance_and_determinism(kitti):
     """Size-independent properties of the arithmetic contract: the plane-fit sums
     are exact integers, so (1) shuffling the rows of a cloud gives the same ground SET (indices mapped
@@ -961,6 +1029,7 @@ def test_overlap_mode_two_frame_ranges_on_two_streams(kitti, oracle):
     odd = frames[:200] + [wedge] + frames[:39]
     h.estimate_ground_batch(odd, mode=pwpp_hip.MODE_FRESH)
     assert h.one_pass_stats() == (2, 1)
+    assert h.redo_stats() == (F + 240, 1)  # (round 5: the wedge alone is redone, in place)
     assert_frame_equal(h, 200, ol.Estimator(oracle, arith=ol.ARITH_FXP).run(wedge), wedge.shape[0], check_state=False)
     for i in (0, 119, 120, 199, 201, 239):
         assert_frame_equal(h, i, refs[(i if i < 200 else i - 201) % 6], odd[i].shape[0], check_state=False)

@@ -33,11 +33,7 @@ FLAVOURS = (("eigen_f32", ol.ARITH_EIGEN_F32), ("f32_packet4", ol.ARITH_F32_PACK
 
 def consensus_frame(i):
     """Frame i of the set: deterministic, realistic, varied."""
-    rng = np.random.default_rng(40_000 + i)
-    return pwpp_synth.make_cloud(
-        7_000 + i, beams=64, azimuth_steps=int(rng.integers(1700, 2100)), sensor_height=float(rng.uniform(1.55, 1.90)),
-        n_boxes=int(rng.integers(10, 70)), undulation=float(rng.uniform(0.0, 0.35)), reflect_frac=float(rng.uniform(0.0, 0.03)),
-        range_noise=float(rng.uniform(0.005, 0.03)))
+    return pwpp_synth.varied_frame(i)
 
 
 def reference_sets(pts):
