@@ -178,6 +178,9 @@ struct pwpp_handle {
     DevBuf<uint32_t> d_cls_start;  // frames * 8
     DevBuf<uint32_t> d_cap_off;    // 2B + 3 segment starts of the one-pass path (one segment per part)
     DevBuf<uint32_t> d_bin_max;    // 2B + 2: largest count of every part so far (k_czm_scan)
+    DevBuf<uint8_t> d_emit_long;   // k_emit's table of long bins: B + 2 flags, then (4-byte aligned) the list of those bins as uint16
+    std::vector<uint8_t> emit_long_flags;
+    int emit_long_n = 0, emit_long_parts = 1;
     std::vector<uint32_t> observed, cap_table;  // host copies: d_bin_max as last read; capacities of the table on the device
     bool have_observation = false, table_stale = true;
     DevBuf<PwppFrameDesc> d_frames_probe;
@@ -473,6 +476,37 @@ int probe_histogram(pwpp_handle *h) {
     return read_observed(h);
 }
 
+// k_emit's table of "long" bins (pwpp_dev.h: emit_long) from the parts' largest counts so far; uploaded when it changes.
+// Called with no launch in flight (estimate_batch, after finish_pending).
+int refresh_emit_long(pwpp_handle *h) {
+    const int B = h->dp.num_bins, NB = B + 2;
+    std::vector<uint8_t> flag((size_t)NB, 0);
+    std::vector<uint16_t> list;
+    uint32_t biggest = 0;
+    for (int b = 0; b < NB && h->observed.size() == (size_t)PWPP_NUM_PARTS(B); ++b) {
+        const uint32_t c = b < B ? h->observed[2 * (size_t)b] + h->observed[2 * (size_t)b + 1] : h->observed[(size_t)B + b];  // (pseudo-bin s = part B + s)
+        if (c > PWPP_EMIT_LONG_MIN) {
+            flag[(size_t)b] = 1;
+            list.push_back((uint16_t)b);
+            biggest = c > biggest ? c : biggest;
+        }
+    }
+    int parts = (int)((biggest > 512u * PWPP_EMIT_LONG_BLOCKS ? biggest - 512u * PWPP_EMIT_LONG_BLOCKS : 0u) / 4096u) + 1;
+    parts = parts > 32 ? 32 : parts;
+    if (flag == h->emit_long_flags && parts == h->emit_long_parts) return PWPP_OK;
+    const size_t list_at = (size_t)((NB + 3) & ~3);
+    std::vector<uint8_t> blob(list_at + 2 * (size_t)NB, 0);
+    std::memcpy(blob.data(), flag.data(), flag.size());
+    if (!list.empty()) std::memcpy(blob.data() + list_at, list.data(), list.size() * sizeof(uint16_t));
+    int rc = h->d_emit_long.ensure(blob.size());
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(h->d_emit_long.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    h->emit_long_flags = flag;
+    h->emit_long_n = (int)list.size();
+    h->emit_long_parts = parts;
+    return PWPP_OK;
+}
+
 // everything a launch needs except the frame range, the capacity table and the events
 void fill_batch(pwpp_handle *h, PwppBatch &bt) {
     const int B = h->dp.num_bins, NB = B + 2;
@@ -543,6 +577,18 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
         if (h->frames <= 8) parts = 8;
         else if (h->frames <= 64 && parts < 4) parts = 4;
         bt.emit_parts = parts > 8 ? 8 : parts;
+        if (h->frames > 64) {
+            // Big batches (round 5): ONE wave per bin, and extra waves only for the bins that have held more than PWPP_EMIT_LONG_MIN
+            // entries in some frame of this handle (refresh_emit_long: a table on the device, rebuilt when the maxima change).
+            // A long list in a bin that is not in the table yet is copied whole by its one wave: slower, never wrong.
+            bt.emit_parts = 1;
+            if (h->emit_long_n > 0) {
+                bt.emit_long = h->d_emit_long.p;
+                bt.emit_long_list = reinterpret_cast<const uint16_t *>(h->d_emit_long.p + (size_t)((B + 2 + 3) & ~3));
+                bt.emit_long_n = h->emit_long_n;
+                bt.emit_long_parts = h->emit_long_parts;
+            }
+        }
     }
 }
 
@@ -1080,6 +1126,7 @@ int pwpp_destroy(pwpp_handle *h) {
     h->d_recs.release();
     h->d_cls_start.release();
     h->d_cap_off.release();
+    h->d_emit_long.release();
     h->d_cls_list.release();
     h->d_centers.release();
     h->d_normals.release();
@@ -1332,6 +1379,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
         if ((rc = h->d_pl_snap.ensure((size_t)frames))) return rc;
         // (the copies themselves are made by the binning kernel: PwppBatch.snap_*, set in launch_prepared)
     }
+    if (frames > 64 && (rc = refresh_emit_long(h))) return rc;
     if ((rc = launch_prepared(h, one_pass))) return rc;
     h->pending = true;
     h->have_results = false;
@@ -1766,7 +1814,7 @@ int64_t pwpp_get_workspace_bytes(pwpp_handle *h) {
     return b(h->d_frames.cap, sizeof(PwppFrameDesc)) + b(h->d_frames_probe.cap, sizeof(PwppFrameDesc)) + b(h->d_in.cap, 4) + b(h->d_codes.cap, 2) +
            b(h->d_sorted_z.cap, 4) + b(h->d_sorted_xy.cap, 8) + b(h->d_sorted_idx.cap, 4) + b(h->d_bin_origin.cap, 8) + b(h->d_bin_bbox.cap, 16) +
            b(h->d_member.cap, 1) + b(h->d_out.cap, 4) + b(h->d_ord_a.cap, 8) + b(h->d_ord_b.cap, 8) + b(h->d_ord_work.cap, 4) + b(h->d_bins.cap, 4) + b(h->d_parts.cap, 4) +
-           b(h->d_cls_start.cap, 4) + b(h->d_cap_off.cap, 4) + b(h->d_bin_max.cap, 4) + b(h->d_cls_list.cap, 2) +
+           b(h->d_cls_start.cap, 4) + b(h->d_cap_off.cap, 4) + b(h->d_emit_long.cap, 1) + b(h->d_bin_max.cap, 4) + b(h->d_cls_list.cap, 2) +
            b(h->d_recs.cap, sizeof(PwppPatchRec)) + b(h->d_centers.cap, 4) + b(h->d_normals.cap, 4) + b(h->d_results.cap, sizeof(PwppFrameResult)) +
            b(h->d_xyz.cap, 4) + b(h->d_dbg.cap, 8) + b(h->d_st_stream.cap, sizeof(PwppStateScalar)) + b(h->d_st_fresh.cap, sizeof(PwppStateScalar)) +
            b(h->d_st_snap.cap, sizeof(PwppStateScalar)) + b(h->d_hist_stream.cap, 8) + b(h->d_hist_fresh.cap, 8) + b(h->d_hist_snap.cap, 8) +

@@ -34,6 +34,8 @@
 #define PWPP_PART_LO(bin) (2 * (bin))
 #define PWPP_PART_HI(bin) (2 * (bin) + 1)
 #define PWPP_NUM_PARTS(B) (2 * (B) + 2)
+#define PWPP_EMIT_LONG_BLOCKS 8   // blocks of 512 list entries the main wave of a "long" bin copies in k_emit; the rest goes to the extra waves
+#define PWPP_EMIT_LONG_MIN 8192   // a bin whose count has exceeded this in some frame of the handle is "long"
 
 struct PwppDevParams {
     int32_t enable_RNR, enable_RVPF, enable_TGR;
@@ -179,6 +181,14 @@ struct PwppBatch {
     int32_t plan_frames;         // frames the automatic fit plan is chosen for: the WHOLE call's when this batch is one of its frame ranges (0: num_frames)
     int32_t fit_concurrent;      // option "fit_concurrent": the classes of a plan side by side on two streams
     int32_t emit_parts;          // waves per bin in k_emit (1..8, from the largest bin seen so far)
+    // Big batches (round 5): one wave per bin, and the FEW bins that have held long lists so far (pseudo-bins of a sensor that sees
+    // beyond max_range or its own vehicle, the near bins of a dense cloud) get extra waves from a second, small launch -- not every
+    // bin of every frame (a 55 k-point pseudo-bin used to put seven waves on each of 500 k bins: k_emit 0.29 -> 0.92 ms).
+    const uint8_t *emit_long;        // [B+2] 1 = the bin is in emit_long_list: its main wave stops after PWPP_EMIT_LONG_BLOCKS blocks; null = none
+    const uint16_t *emit_long_list;  // [emit_long_n] those bins
+    int32_t emit_long_n;
+    int32_t emit_long_parts;     // waves per listed bin of the second launch
+    int32_t emit_long_pass;      // set in the copy of the batch the second launch gets
     int32_t bin_block;           // option "bin_block": threads per workgroup of k_czm_bin_scatter (256, 512, 1024; four points each)
     // The counters a call starts from (part_count [+ part_off, part_cursor], results) exist TWICE; a call works on one copy
     // and its K5 zeroes the frame's share of the OTHER copy, so that the next call of the same shape needs no clearing

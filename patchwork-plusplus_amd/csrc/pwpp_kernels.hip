@@ -1763,15 +1763,26 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, unsigned l
     __shared__ int s_stage[512];  // (membership-plane path: the two lists of a block of 512 points, compacted before they are written)
     __shared__ unsigned s_zk[KEYS ? 512 : 1];  // reference-order mode: the height keys of the staged entries
     constexpr bool keep_cat = KEYS;  // (an instantiation of its own: the default path keeps its registers)
-    const int f = blockIdx.y, seg = blockIdx.x;
+    const int f = blockIdx.y;
+    // Which blocks of 512 entries of the bin's lists this wave copies: [first_block + part, end_block) in steps of `parts`.  Big
+    // batches run one wave per bin; the bins the host has seen long lists in (Bt.emit_long) stop after PWPP_EMIT_LONG_BLOCKS blocks
+    // and a second launch over those bins alone (emit_long_pass) deals out the rest.
+    int seg = blockIdx.x;
+    unsigned first_block = 0u, end_block = 0xffffffu;
+    if (Bt.emit_long_pass) {
+        seg = Bt.emit_long_list[blockIdx.x];
+        first_block = PWPP_EMIT_LONG_BLOCKS;
+    } else if (Bt.emit_long && Bt.emit_long[seg]) {
+        end_block = PWPP_EMIT_LONG_BLOCKS;
+    }
     // the frame's counters are final since K5: hand them to the host through its pinned mirror (eight posted
     // PCIe writes) instead of a copy command behind the pipeline (a dispatch of its own, ~9 us of a single frame)
-    if (seg == 0 && blockIdx.z == 0 && threadIdx.x == 0) Bt.results_host[f] = Bt.results[f];
+    if (!Bt.emit_long_pass && seg == 0 && blockIdx.z == 0 && threadIdx.x == 0) Bt.results_host[f] = Bt.results[f];
     const PwppDevParams &P = Bt.P;
     const int B = P.num_bins, NB = B + 2;
     // A pseudo-bin is one part -- its own count / offset stand in -- and has no patch record: that of bin 0 is read and ignored.
     const unsigned n = Bt.bin_count[(size_t)f * NB + seg];
-    if (!EAGER && n == 0) return;
+    if (!EAGER && n <= first_block * 512u) return;  // (empty bin; or an extra wave of a list the main wave copies whole)
     const PwppFrameDesc fd = Bt.frames[f];
     const unsigned off = Bt.bin_off[(size_t)f * NB + seg];
     const unsigned da = Bt.dst_a[(size_t)f * NB + seg];
@@ -1795,7 +1806,9 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, unsigned l
     const unsigned part = blockIdx.z, parts = gridDim.z;
     constexpr int kU = 8;
     if (whole) {  // (the out-of-range pseudo-bin of a sensor that sees beyond max_range holds 10^5 points)
-        for (unsigned i0 = part * (kU * kEmitBlock) + threadIdx.x; i0 < n; i0 += parts * (kU * kEmitBlock)) {
+        static_assert(kU * kEmitBlock == 512, "first_block / end_block count blocks of 512 entries");
+        const unsigned n_end = (uint64_t)end_block * 512u < n ? end_block * 512u : n;
+        for (unsigned i0 = (first_block + part) * (kU * kEmitBlock) + threadIdx.x; i0 < n_end; i0 += parts * (kU * kEmitBlock)) {
             int v[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
@@ -1840,7 +1853,8 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, unsigned l
             return (unsigned)__builtin_amdgcn_readfirstlane((int)wave_sum_u32(c));
         };
         unsigned g_before = 0, next_b = 0;  // ground points in the blocks [0, next_b)
-        for (unsigned b = part; b < nb; b += parts) {
+        const unsigned nb_end = nb < end_block ? nb : end_block;
+        for (unsigned b = first_block + part; b < nb_end; b += parts) {
             const bool hi = b >= nb_lo;
             const unsigned bb = hi ? b - nb_lo : b;
             if (b != next_b) {  // (several waves per bin: count what the other waves' blocks hold)
@@ -2440,6 +2454,13 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
         else if (F <= 64) hipLaunchKernelGGL((k_emit<true, false>), egrid, dim3(kEmitBlock), 0, stream, B, order_a);
         else if (order_a) hipLaunchKernelGGL((k_emit<false, true>), egrid, dim3(kEmitBlock), 0, stream, B, order_a);
         else hipLaunchKernelGGL((k_emit<false, false>), egrid, dim3(kEmitBlock), 0, stream, B, order_a);
+        if (B.emit_long && B.emit_long_n > 0) {  // the rest of the long lists: extra waves for the listed bins only
+            PwppBatch L = B;
+            L.emit_long_pass = 1;
+            const dim3 lgrid(B.emit_long_n, F, B.emit_long_parts > 1 ? B.emit_long_parts : 1);
+            if (order_a) hipLaunchKernelGGL((k_emit<false, true>), lgrid, dim3(kEmitBlock), 0, stream, L, order_a);
+            else hipLaunchKernelGGL((k_emit<false, false>), lgrid, dim3(kEmitBlock), 0, stream, L, order_a);
+        }
         if (ev) (void)hipEventRecord(ev[11], stream);
         if (order_a) {
             hipLaunchKernelGGL((k_order_sublists<64, 256, 0>), dim3(NB, F), dim3(64), 0, stream, B, order_a, order_b);

@@ -690,6 +690,52 @@ def test_an_overflow_costs_its_frame_not_the_batch(kitti, oracle):
         assert np.array_equal(small[i][h3.ground_indices(i), 2], small[i][r.ground_idx, 2])  # same heights position by position (ties in cloud order)
 
 
+def test_long_lists_in_a_big_batch(kitti, oracle):
+    """k_emit in big batches (round 5): one wave per bin, and a second launch with extra waves for the bins the handle has seen more
+    than 8192 entries in.  A frame with 60 % of its points closer than min_range (a pseudo-bin of ~75 k entries: bench.py's `distinct`
+    leg has such frames -- a box over the sensor), one with 40 % beyond max_range, a wedge whose bins hold tens of thousands of points
+    (lists compacted from the membership plane).  First batch: the bins are not in the table yet, their one wave copies everything;
+    second and third batch: the table knows them.  Reference-ordered lists take the same second launch."""
+    rng = np.random.default_rng(21)
+
+    def scaled(src, frac, lo, hi):
+        w = src.copy()
+        sel = rng.random(w.shape[0]) < frac
+        r = np.hypot(w[sel, 0], w[sel, 1])
+        s = rng.uniform(lo, hi, sel.sum()) / np.maximum(r, 1e-3)
+        w[sel, 0] = (w[sel, 0] * s).astype(np.float32)
+        w[sel, 1] = (w[sel, 1] * s).astype(np.float32)
+        return w
+
+    near, far = scaled(kitti[1], 0.6, 0.3, 2.5), scaled(kitti[2], 0.4, 85.0, 110.0)
+    wedge = kitti[0].copy()
+    sel = rng.random(wedge.shape[0]) < 0.7
+    r = np.hypot(wedge[sel, 0], wedge[sel, 1])
+    a = rng.uniform(0.1, 0.27, sel.sum())
+    wedge[sel, 0] = (r * np.cos(a)).astype(np.float32)
+    wedge[sel, 1] = (r * np.sin(a)).astype(np.float32)
+    est = lambda p: ol.Estimator(oracle, arith=ol.ARITH_FXP).run(p)
+    refs = [est(k) for k in kitti]
+    F = 72
+    frames = [kitti[i % 6] for i in range(F)]
+    special = {3: near, 40: far, 41: wedge, F - 1: near}
+    want = {i: est(p) for i, p in special.items()}
+    for i, p in special.items():
+        frames[i] = p
+    assert max(len(r.nonground_idx) for r in want.values()) > 60000
+    h = pwpp_hip.Handle()
+    for rep in range(3):
+        h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+        for i in list(special) + [0, 2, 4, 39, 42, F - 2]:
+            assert_frame_equal(h, i, want.get(i, refs[i % 6]), frames[i].shape[0], check_state=(rep == 0))
+    h.set_output_order(True)
+    h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+    for i in (3, 41, 42):
+        r = want.get(i, refs[i % 6])
+        assert np.array_equal(frames[i][h.ground_indices(i), 2], frames[i][np.asarray(r.ground_idx), 2])
+        assert np.array_equal(np.sort(h.nonground_indices(i)), np.sort(r.nonground_idx))
+
+
 def test_point_order_invariance_and_determinism(kitti):
     """Size-independent properties of the arithmetic contract: the plane-fit sums
     are exact integers, so (1) shuffling the rows of a cloud gives the same ground SET (indices mapped
