@@ -328,6 +328,9 @@ PWPP_API int pwpp_get_redo_stats(pwpp_handle *h, int64_t *frames_one_pass, int64
  *   "overlap_mode"        "1" (default): binning and lists on the main stream, the ranges' fits on "fit_streams" more;
  *                         "0": every range as a whole pipeline, alternating between two streams
  *   "fit_streams"         streams the ranges' fit stages are dealt to (1..8, default 2)
+ *   "cu_split"            "N" or "N:mode" (experiment, default "0" = off): the overlap schedule's memory stream on N of the 256 CUs
+ *                         and its fit streams on the others (hipExtStreamCreateWithCUMask).  Slower in every configuration
+ *                         measured (profiles/r05_cu_mask_sweep.txt)
  *   "bin_block"           threads per workgroup of the one-pass binning kernel (128 / 256 / 512 / 1024, default 256)
  *   "hi_split"            metres above the ground level (-sensor_height) where the "high" part of a bin begins
  *                         (default 0.6; 1e30 = no high parts): the fit passes skip a high part whenever they can

@@ -116,6 +116,11 @@ struct pwpp_handle {
     int bin_block = 256;                // option "bin_block": threads per workgroup of the one-pass binning kernel
     int num_fit_streams = 2;            // option "fit_streams": streams the ranges' fit stages are dealt to (aux_stream + extra_streams)
     std::vector<hipStream_t> extra_streams;
+    // option "cu_split" (round 5 experiment): the overlap schedule's memory stream and fit streams on disjoint
+    // sets of CUs (hipExtStreamCreateWithCUMask).  cu_split_mem = CUs of the memory stream (0 = off), cu_split_mode: which bits.
+    int cu_split_mem = 0, cu_split_mode = 0;
+    hipStream_t masked_mem = nullptr;
+    std::vector<hipStream_t> masked_fit;
     // tuning / test options (pwpp_set_option; the PWPP_* environment variables are read ONCE, in pwpp_create)
     int debug_flags = 0;
     std::string fit_plan;
@@ -378,6 +383,8 @@ void sync_all_streams(pwpp_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     for (hipStream_t st : h->extra_streams) (void)hipStreamSynchronize(st);
+    if (h->masked_mem) (void)hipStreamSynchronize(h->masked_mem);
+    for (hipStream_t st : h->masked_fit) (void)hipStreamSynchronize(st);
 }
 
 // the stream history slabs [stream][2][4][cap] re-laid out for a larger cap (contents kept)
@@ -729,6 +736,12 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
                 h->extra_streams.push_back(st);
             }
             hipStream_t mem = h->stream;
+            const bool masked = h->masked_mem != nullptr && (int)h->masked_fit.size() >= h->num_fit_streams;
+            if (masked) {  // the CU-partitioned streams: fork from the main stream (descriptor copy, k_clear), join at the end
+                mem = h->masked_mem;
+                HIPCHK(hipEventRecord(h->aux_fork, h->stream));
+                HIPCHK(hipStreamWaitEvent(mem, h->aux_fork, 0));
+            }
             // (every record / wait is checked: a failed one would leave the fit streams unordered against binning and
             // k_emit, and the batch would "succeed" with racy results -- ADVICE r02)
             auto ordered_ok = [&](hipError_t e) {
@@ -736,7 +749,7 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
             };
             auto bin = [&](int r) {
                 const int k = r % h->num_fit_streams;
-                hipStream_t fit = k == 0 ? h->aux_stream : h->extra_streams[(size_t)k - 1];
+                hipStream_t fit = masked ? h->masked_fit[(size_t)k] : (k == 0 ? h->aux_stream : h->extra_streams[(size_t)k - 1]);
                 stage(r, 1, mem);
                 if (lrc == 0) ordered_ok(hipEventRecord(h->ev_ranges[2 * (size_t)r], mem));
                 if (lrc == 0) ordered_ok(hipStreamWaitEvent(fit, h->ev_ranges[2 * (size_t)r], 0));
@@ -754,6 +767,10 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
                 if (r + 2 < R) bin(r + 2);
             }
             // (the memory stream ends with the lists of the last range, which wait for its fits: h->stream is the join)
+            if (masked && lrc == 0) {
+                ordered_ok(hipEventRecord(h->aux_join, mem));
+                ordered_ok(hipStreamWaitEvent(h->stream, h->aux_join, 0));
+            }
         } else {
             // whole ranges alternating between the two streams
             HIPCHK(hipEventRecord(h->aux_fork, h->stream));
@@ -1149,6 +1166,8 @@ int pwpp_destroy(pwpp_handle *h) {
         if (h->ev_k[k]) (void)hipEventDestroy(h->ev_k[k]);
     for (hipEvent_t e : h->ev_ranges) (void)hipEventDestroy(e);
     for (hipStream_t st : h->extra_streams) (void)hipStreamDestroy(st);
+    for (hipStream_t st : h->masked_fit) (void)hipStreamDestroy(st);
+    if (h->masked_mem) (void)hipStreamDestroy(h->masked_mem);
     if (h->aux_fork) (void)hipEventDestroy(h->aux_fork);
     if (h->aux_join) (void)hipEventDestroy(h->aux_join);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
@@ -1756,6 +1775,33 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
         h->fit_concurrent = std::atoi(value) != 0;
     } else if (k == "one_pass") {
         h->no_one_pass = std::atoi(value) == 0;
+    } else if (k == "cu_split") {
+        // "N" or "N:mode": the overlap schedule's memory stream (binning, index lists) on N of the 256 CUs, the fit streams on the
+        // others.  mode 0: the N lowest bits of the mask; mode 1: the bits i with (i mod 8) < N / 32 (whichever of the two is "whole
+        // XCDs" depends on how the driver numbers the CUs of the eight XCDs in a queue's mask).  "0": off.
+        int n = 0, mode = 0;
+        if (std::sscanf(value, "%d:%d", &n, &mode) < 1 || n < 0 || n >= 256 || (mode != 0 && mode != 1))
+            return fail(PWPP_E_ARG, "cu_split=%s: N or N:mode with 0 <= N < 256, mode 0 or 1 expected", value);
+        sync_all_streams(h);
+        for (hipStream_t st : h->masked_fit) (void)hipStreamDestroy(st);
+        h->masked_fit.clear();
+        if (h->masked_mem) (void)hipStreamDestroy(h->masked_mem);
+        h->masked_mem = nullptr;
+        h->cu_split_mem = n;
+        h->cu_split_mode = mode;
+        if (n > 0) {
+            uint32_t mm[8] = {}, mf[8] = {};
+            for (int i = 0; i < 256; ++i) {
+                const bool to_mem = mode == 0 ? i < n : (i % 8) < n / 32;
+                (to_mem ? mm : mf)[i / 32] |= 1u << (i % 32);
+            }
+            HIPCHK(hipExtStreamCreateWithCUMask(&h->masked_mem, 8, mm));
+            for (int k2 = 0; k2 < 8; ++k2) {
+                hipStream_t st = nullptr;
+                HIPCHK(hipExtStreamCreateWithCUMask(&st, 8, mf));
+                h->masked_fit.push_back(st);
+            }
+        }
     } else if (k == "redo_whole_batch") {
         h->redo_whole_batch = std::atoi(value) != 0;
     } else if (k == "one_pass_min_frames") {
