@@ -8,7 +8,10 @@ rank 0.  For N > 1 it is launched under ``torch.distributed.run`` with one rank 
   GLE/TGR -> index lists) over one batch of ``--frames`` (default 1024) frames that are already
   resident in HBM as 1024 distinct device buffers (2 GB, far beyond the 256 MiB Infinity
   Cache): BASELINE.json configs[2], "Batch of 1024 replayed KITTI frames on 1 MI355X".  Every
-  frame is processed with fresh state (= a fresh reference object per frame).
+  frame is processed with fresh state (= a fresh reference object per frame).  The timed region
+  keeps ``--in-flight`` (default 2) batches enqueued, one library handle each -- the way a caller
+  with a stream of batches drives the C-ABI (double buffering); ``synchronous`` in the line is the
+  one-batch-at-a-time step rounds 1-4 timed.
 * Frames: the six KITTI sample frames of the reference (tests/golden/kitti_*.bin.xz,
   byte-identical to /root/reference/data/*.bin) replayed round-robin; synthetic 64-beam
   frames (pwpp_synth.make_cloud) if the fixtures are missing.
@@ -80,6 +83,16 @@ def cpu_limits():
     return out
 
 
+def quota_cores():
+    """CPUs' worth of time the cgroup grants this container (cpu.max = quota period), or None: the GPU boxes of this pool show 256
+    hardware threads and grant 16 -- which is where the frame-parallel baseline stops scaling."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        return None
+
+
 def cpu_baseline(src, budget_s=4.0):
     """Reference CPU path on the host cores, bounded sample (rank 0, N=1 only).
 
@@ -137,6 +150,7 @@ def cpu_baseline(src, budget_s=4.0):
         "host_threads": cores, "cpu_limits": cpu_limits(), "single_thread_fps": fps1,
         "scaling": best["scaling"],  # value / single-thread rate / workers: 1.0 = linear
         "by_workers": table, "threads_in_one_process": threads_row,
+        "cpu_quota_cores": quota_cores(),
         "sample": "%d frames (%d distinct source frames replayed, fresh reference object per frame) in %.1f s wall on %d single-threaded "
                   "worker processes -- the best of the worker counts in `by_workers`; g++ -O3 build of the reference's own patchworkpp.cpp "
                   "+ Eigen stand-in (oracle/_ref); the reference has no OpenMP in this path, frame-parallelism across processes is the harness's"
@@ -370,6 +384,7 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of the separate single-stream pass that measures per-kernel times")
     ap.add_argument("--dense-frames", type=int, default=256, help="frames of the configs[4] leg (outside the timed region, N = 1 only)")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches kept enqueued in the timed region, one handle each (1 = synchronous steps on one handle)")
     ap.add_argument("--distinct-frames", type=int, default=1024, help="frames of the non-replayed leg (outside the timed region, N = 1 only; 0 = skip)")
     ap.add_argument("--skip-latency", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="no parity_check / reference_order / ingest legs (all of them run outside the timed region)")
@@ -435,6 +450,23 @@ def main():
         h.launch_device_batch(batch, cols=4, mode=pwpp_hip.MODE_FRESH)
         h.synchronize()
 
+    def run_steps(n):
+        """n steps with up to D batches in flight; returns with every batch landed."""
+        if D == 1:
+            for _ in range(n):
+                step()
+            return
+        for hh in H:
+            hh.set_overlap(False)
+        for k in range(n):
+            d = k % D
+            if k >= D:
+                H[d].synchronize()
+            H[d].launch_device_batch(batches[d], cols=4, mode=pwpp_hip.MODE_FRESH)
+        for hh in H:
+            hh.synchronize()
+        h.set_overlap(not args.no_overlap)
+
     step()  # (one step for the checks below; the W warm-up steps run right in front of the timed region, after the host-side checks)
     # self-check: replays of the same source frame must produce identical counts, and
     # ground + non-ground must partition the frame (no reference data needed on the GPU box)
@@ -446,6 +478,31 @@ def main():
     for i in range(F):
         by_src.setdefault(which[i], set()).add(tuple(int(v) for v in counts[i, :3]))
     assert os.environ.get("PWPP_BENCH_NO_SELFCHECK") or all(len(v) == 1 for v in by_src.values()), "replayed frames disagree: %r" % by_src
+
+    # Batches IN FLIGHT (round 5): the timed region keeps D = --in-flight batches enqueued -- D handles, each with its own input
+    # buffers, workspace and stream, every one a full batch of F frames; step k goes to handle k mod D, which first waits for the
+    # batch it launched D steps earlier (its results are complete and readable until then).  The ramp-up of one batch (binning,
+    # nothing to overlap with) then runs under the ramp-down of the one before (last fits, index lists): 2.46 against 2.63 ms per
+    # batch for the synchronous step with the in-handle overlap schedule (profiles/r05_pipelined_batches.txt).  Each handle runs
+    # the plain single-stream schedule (the in-handle overlap schedule on top is slower: 2.83 ms).  D = 1: rounds 1-4's step.
+    D = max(1, args.in_flight) if F >= 128 and not args.no_overlap else 1
+    H, batches, inputs = [h], [batch], [big]
+    for d in range(1, D):
+        which_d = pwpp_dist.shard_sources(len(src), F, rank + d)  # (the same frames in another rotation: other buffers, other addresses)
+        ns_d = [src[j].shape[0] for j in which_d]
+        offs_d = np.concatenate([[0], np.cumsum(ns_d)]).astype(np.int64)
+        big_d = torch.empty((int(offs_d[-1]), 4), dtype=torch.float32, device=dev)
+        for i in range(F):
+            big_d[offs_d[i]:offs_d[i + 1]].copy_(src_dev[which_d[i]])
+        hd = pwpp_hip.Handle(params, device=gpu_index)
+        H.append(hd)
+        inputs.append(big_d)
+        batches.append(hd.make_device_batch([big_d.data_ptr() + int(offs_d[i]) * 16 for i in range(F)], ns_d))
+    torch.cuda.synchronize()
+    # (The other handles are created only now, AFTER the first handle's first step: its overlap schedule has created its third
+    # stream by then.  The HIP runtime multiplexes streams onto four hardware queues in creation order; with the second handle's two
+    # streams created first, the first handle's fit stream shared a hardware queue with its own memory stream and the synchronous
+    # step read 3.18 instead of 2.6 ms -- tools/sync_after_pipelined.py.)
 
     selfcheck = not os.environ.get("PWPP_BENCH_NO_SELFCHECK")
     # oracle anchor (outside the timed region): the ground masks and plane normals of batch frames 0-5 and
@@ -475,18 +532,38 @@ def main():
     # The timed region runs the library's default schedule (overlap mode for batches of 128+ frames) with no
     # profiling events in it; the per-kernel times and the roofline line come from a SEPARATE single-stream pass
     # after the timed region (HIP events around every launch would serialise the two frame ranges).
-    for _ in range(max(args.warmup, 1)):  # W untimed warm-up steps (the checks above leave the GPU idle for a while: warm up AFTER them)
-        step()
+    run_steps(max(args.warmup, 1))  # W untimed warm-up steps (the checks above leave the GPU idle for a while: warm up AFTER them)
     pwpp_dist.barrier(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     pwpp_dist.barrier(dev)
     elapsed = time.perf_counter() - t0
     my_elapsed = elapsed
     elapsed, total_frames = pwpp_dist.aggregate(elapsed, F * args.steps, dev if backend == "nccl" else None)  # MAX time, SUM frames over ranks
+    if D > 1:  # every handle's last batch is complete and equal to the first handle's first one, frame for frame of the same source
+        for d in range(1, D):
+            cd, wd = H[d].all_counts(), pwpp_dist.shard_sources(len(src), F, rank + d)
+            first_of = {}
+            for i in range(F):
+                first_of.setdefault(which[i], i)
+            for i in range(0, F, 37):
+                assert not selfcheck or tuple(cd[i, :3]) == tuple(counts[first_of[wd[i]], :3]), "handle %d frame %d differs from handle 0" % (d, i)
+    # the synchronous step of rounds 1-4 (launch, wait; the library's in-handle overlap schedule), for comparison across rounds
+    sync_leg = None
+    if D > 1:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t1) / 10
+        sync_leg = {"ms_per_step": 1000.0 * dts, "frames_per_s": F / dts, "steps": 10,
+                    "what": "ONE batch at a time on one handle (launch, wait), library default schedule (two frame ranges over three streams): "
+                            "the step rounds 1-4 reported as `value`; also the latency of one 1024-frame batch"}
     if not args.no_profile_events:  # kernel times of the single-stream schedule, outside the timed region
         h.set_profiling(True)
         h.reset_kernel_profile()
@@ -521,7 +598,7 @@ def main():
     dist_info = pwpp_dist.describe(backend, dev)  # backend, world size, RCCL version, every rank's GPU (all-gather)
     dist_info["launcher"] = "bench.py spawned its own ranks (torch.distributed.run)" if os.environ.get("PWPP_BENCH_SELF_SPAWNED") else \
         ("torch.distributed.run" if world > 1 else "single process")
-    dist_info["workspace_gb_per_rank"] = [v / 1e9 for v in pwpp_dist.gather_values(float(h.workspace_bytes()), dev if backend == "nccl" else None)]
+    dist_info["workspace_gb_per_rank"] = [v / 1e9 for v in pwpp_dist.gather_values(float(sum(hh.workspace_bytes() for hh in H)), dev if backend == "nccl" else None)]
 
     # reference-order output mode: the same batch with every sub-list in the reference's z-sorted order
     ref_order = None
@@ -583,12 +660,16 @@ def main():
                                    % (F, F, offs[-1] * 16 / 1e9) if args.workload == "kitti" else
                                    "configs[4]: %d dense synthetic 128-beam ~500k-pt frames per GPU, 36-sector CZM" % F,
                        "frames_per_gpu": F, "points_per_frame": int(np.mean(ns)), "parallelism": "frames sharded, dp%d" % world,
+                       "batches_in_flight": D,
                        "schedule": ("one stream" if args.no_overlap or F < 128 else
-                                    "library default: two frame ranges, binning and lists on the main stream, each range's plane fits on its own")
+                                    ("%d batches in flight (one handle, workspace and stream each; every step = one whole batch of %d frames; a handle's results stay "
+                                     "readable until its next launch); each handle: one stream" % (D, F) if D > 1 else
+                                     "library default: two frame ranges, binning and lists on the main stream, each range's plane fits on its own"))
                                    + "; kernel_ms / roofline.kernel_ms: separate single-stream pass of %d steps outside the timed region" % args.profile_steps},
             "binning": {"one_pass_batches": h.one_pass_stats()[0], "redone_two_pass": h.one_pass_stats()[1],
                         "one_pass_frames": h.redo_stats()[0], "redone_frames": h.redo_stats()[1],
-                        "workspace_gb": h.workspace_bytes() / 1e9, "input_gb": float(offs[-1]) * 16 / 1e9},
+                        "workspace_gb": h.workspace_bytes() / 1e9, "input_gb": float(offs[-1]) * 16 / 1e9,
+                        "workspace_gb_all_handles": sum(hh.workspace_bytes() for hh in H) / 1e9},
         }
         if lat_rows:
             g = sorted(r["gpu_us"] for r in lat_rows)
@@ -597,6 +678,8 @@ def main():
                               "gpu_us": g[len(g) // 2], "gpu_us_min": g[0], "gpu_us_median": g[len(g) // 2], "gpu_us_max": g[-1],
                               "ms_per_frame_wall": wl[len(wl) // 2], "ms_per_frame_wall_max": wl[-1], "by_source": lat_rows,
                               "what": "median of 30 calls per source frame; gpu_us = between HIP events on the library's stream, first kernel to last"}
+        if sync_leg is not None:
+            out["synchronous"] = sync_leg
         out["per_gpu"] = [{"rank": r, "frames_per_s": v} for r, v in enumerate(per_gpu)]
         out["dist"] = dist_info
         out["selfcheck"] = bool(selfcheck)
