@@ -369,13 +369,82 @@ def streams_leg(pwpp_hip, torch, dev, gpu_index, src_dev, ns_src, counts=(1, 64,
     return out
 
 
+def streams_workload(args, pwpp_hip, pwpp_dist, torch, dev, gpu_index, backend, world, rank):
+    """`--workload streams` (SURVEY 8f-f1 at N >= 1): S = --frames long-lived stateful streams PER GPU, stepped in
+    lock-step -- a step is one frame for each of the rank's streams (PWPP_MODE_STREAMS: adaptive thresholds, histories and sensor
+    height carried from frame to frame per stream, as one PatchWorkpp object per sensor does).  Global stream g = rank + world * s
+    lives on rank g mod world and sees the six source frames in the order g, g + 1, ...; its frames sit in buffers of their own
+    (6 S distinct buffers per rank).  No data-path collective; the ranks agree on the slowest rank's time as in the headline."""
+    src, data_name = load_source_frames("kitti")
+    K, S = len(src), args.frames
+    src_dev = [torch.from_numpy(a).to(dev) for a in src]
+    ns_t, ptr_t, keep = [], [], []
+    for t in range(K):
+        pick = [((rank + world * s) + t) % K for s in range(S)]
+        ns = [src[j].shape[0] for j in pick]
+        offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+        big = torch.empty((int(offs[-1]), 4), dtype=torch.float32, device=dev)
+        for s in range(S):
+            big[offs[s]:offs[s + 1]].copy_(src_dev[pick[s]])
+        keep.append(big)
+        ns_t.append(ns)
+        ptr_t.append([big.data_ptr() + int(offs[s]) * 16 for s in range(S)])
+    torch.cuda.synchronize()
+    h = pwpp_hip.Handle(device=gpu_index)
+    h.set_num_streams(S)
+    batches = [h.make_device_batch(ptr_t[t], ns_t[t]) for t in range(K)]
+    clock = [0]
+
+    def step():
+        t = clock[0] % K
+        h.launch_device_batch(batches[t], cols=4, mode=pwpp_hip.MODE_STREAMS)
+        h.synchronize()
+        clock[0] += 1
+        return t
+
+    t = step()
+    counts = h.all_counts()
+    for s in range(S):
+        assert counts[s, 0] + counts[s, 1] + counts[s, 5] == ns_t[t][s], "partition property violated in stream %d" % s
+    for _ in range(max(args.warmup, 1)):
+        step()
+    pwpp_dist.barrier(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    pwpp_dist.barrier(dev)
+    my_elapsed = time.perf_counter() - t0
+    elapsed, total = pwpp_dist.aggregate(my_elapsed, S * args.steps, dev if backend == "nccl" else None)
+    per_gpu = pwpp_dist.gather_values(S * args.steps / my_elapsed, dev if backend == "nccl" else None)
+    heights = pwpp_dist.gather_values(h.state(0).sensor_height, dev if backend == "nccl" else None)
+    dist_info = pwpp_dist.describe(backend, dev)
+    dist_info["launcher"] = "bench.py spawned its own ranks (torch.distributed.run)" if os.environ.get("PWPP_BENCH_SELF_SPAWNED") else \
+        ("torch.distributed.run" if world > 1 else "single process")
+    dist_info["workspace_gb_per_rank"] = [v / 1e9 for v in pwpp_dist.gather_values(float(h.workspace_bytes()), dev if backend == "nccl" else None)]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frames/sec, 64-beam ~120k-pt cloud, estimateGround() hot path, STATEFUL streams (SURVEY 8f-f1)",
+            "value": total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 points; f64 binning/thresholds; int64/int128 fixed-point plane-fit sums", "data": data_name,
+            "config": {"workload": "f1: %d stateful streams per GPU in lock-step (one frame per stream and step), stream g on rank g mod %d, "
+                                   "device-resident frames in %d distinct buffers per rank" % (S, world, K * S),
+                       "streams_per_gpu": S, "parallelism": "streams sharded, dp%d" % world},
+            "per_gpu": [{"rank": r, "frames_per_s": v} for r, v in enumerate(per_gpu)],
+            "sensor_height_of_each_ranks_first_stream": heights, "dist": dist_info}))
+    h.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1024, help="frames per batch per GPU")
-    ap.add_argument("--workload", default="kitti", choices=["kitti", "dense"])
+    ap.add_argument("--workload", default="kitti", choices=["kitti", "dense", "streams"],
+                    help="kitti: configs[2] (the headline); dense: configs[4]; streams: SURVEY 8f-f1 -- --frames stateful streams per GPU in lock-step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-events", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
@@ -424,6 +493,11 @@ def main():
                          % (args.gpus, world, args.gpus))
 
     import pwpp_hip
+
+    if args.workload == "streams":
+        streams_workload(args, pwpp_hip, pwpp_dist, torch, dev, gpu_index, backend, world, rank)
+        pwpp_dist.finalize()
+        return
 
     src, data_name = load_source_frames(args.workload)
     F = args.frames

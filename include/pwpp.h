@@ -180,16 +180,21 @@ PWPP_API int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32
  *   - for 4 points and more: in exact arithmetic (integer moments on a 2^-21 m grid around per-bin / per-patch origins,
  *     z clamped to z0 +- 2^(26-s) m = 32 m with the default CZM -- see pwpp_get_fxp_geometry), because Eigen's float
  *     summation order there depends on the vector width it was built for.  Bit-identical to the CPU restatement of the
- *     contract (oracle/); identical to the "exact-f64" build of the reference on every scan of the test suite.  A float
+ *     contract (oracle/); identical to the "exact-f64" build of the reference on every scan of the GPU test suite (rates off it: below).  A float
  *     build of the reference adds those sums up in float; its own rounding then moves a point that lies within ~1e-4 m
  *     of a threshold now and then (measured: 0-2 of 480 000 indices on dense synthetic clouds, none on the KITTI
  *     samples; plane normals agree to 1e-4 except for ill-conditioned patches, where a float build departs from exact
  *     arithmetic by more than this library does).
- *     Measured on 208 synthetic 64-beam frames against all three builds of the reference (float sums in two orders, exact
- *     sums; tests/test_ref_consensus.py, profiles/r04_ref_consensus.json): the builds are unanimous on 204 frames; this
- *     library returns exactly their ground set on 203 of them and differs by ONE index (of 128 075) on one -- the 2^-21 m grid
- *     of the z sums moved a plane normal by a few float ulps and a point 1e-7 m from th_dist with it; on the 4 frames where
- *     the float builds differ from the exact build (by 1, 1, 8, 129 indices) it equals the exact build.
+ *     Measured on 4 200 frames against all three builds of the reference (float sums in two orders, exact sums; tools/parity_statistics.py,
+ *     profiles/r05_parity_statistics.json -- CPU restatement of the contract, which the HIP path equals bit for bit): 2 000 varied 64-beam
+ *     frames with fresh state, 10 stateful sequences of 200 frames, 200 dense 128-beam frames with the 36-sector CZM.  The builds are
+ *     unanimous on 1 942 / 1 945 / 169 of them; this library returns exactly their ground set on 1 937 (99.74 %, 95 % interval
+ *     99.40-99.89), 1 943 (99.90 %, 99.63-99.97) and 169 (100 %, >= 97.8); the seven misses are 1, 1, 1, 3, 4, 18 and 28 indices of
+ *     ~120 000 -- the 2^-21 m grid of the sums moves a plane by a few float ulps, and a point 1e-7 m from th_dist (or one small patch
+ *     at the edge of a GLE decision) changes sides.  Where the builds differ among themselves (2.9 % / 2.8 % / 15.5 % of the frames)
+ *     there is no single reference result; the library equals the exact build on 45 of 58, 43 of 55 and 28 of 31 of those and is
+ *     never further from it than the float builds are.  Adaptive sensor height over the 200-frame sequences: within 3.3e-7 m of
+ *     the exact build (the float build: 8.5e-7 m).  On the reference's own KITTI samples: identical index sets, every build.
  * (NaN heights are undefined in the reference itself: it sorts bins with `a.z < b.z`.)
  * The order inside a list is not the reference's unless pwpp_set_output_order asks for it. */
 PWPP_API int pwpp_get_ground_indices(pwpp_handle *h, int frame, int32_t *out);

@@ -1058,6 +1058,7 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
     h->device = device;
     // The tuning / test switches: read once, here (not in the launch path), and said out loud.
     if (const char *e = std::getenv("PWPP_DEBUG_FLAGS")) h->debug_flags = std::atoi(e);
+    if ((h->debug_flags & 4) && (h->debug_flags & 8)) h->debug_flags &= ~8;  // (the two sets of timing probes share one array: the fit chain's win)
     if (const char *e = std::getenv("PWPP_FIT_PLAN")) h->fit_plan = e;
     h->fit_concurrent = std::getenv("PWPP_FIT_CONCURRENT") != nullptr;
     h->no_one_pass = std::getenv("PWPP_NO_ONE_PASS") != nullptr;
@@ -1845,7 +1846,10 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
         h->have_observation = false;
         h->table_stale = true;
     } else if (k == "debug_flags") {
-        h->debug_flags = std::atoi(value);
+        const int v = std::atoi(value);
+        //  the fit-chain probes (4) and the binning / scan / GLE probes (8) write the same 64-entry array
+        if ((v & 4) && (v & 8)) return fail(PWPP_E_ARG, "debug_flags=%s: the timing probes 4 and 8 share one probe array; set one of them", value);
+        h->debug_flags = v;
     } else {
         return fail(PWPP_E_ARG, "unknown option '%s'", name);
     }

@@ -54,24 +54,38 @@ int main(int argc, char **argv) {
         const std::vector<patchworkpp_ros::Field> fields = {{"intensity", 0, patchworkpp_ros::kFloat32, 1}, {"x", 4, patchworkpp_ros::kFloat32, 1},
                                                             {"ring", 8, 4 /* UINT16 */, 1},              {"y", 12, patchworkpp_ros::kFloat32, 1},
                                                             {"z", 20, patchworkpp_ros::kFloat32, 1},     {"time", 24, 8 /* FLOAT64 */, 1}};
-        for (int a = 1; a < argc; ++a) {
+        // --layout=odd: a message whose step and offsets are NOT multiples of four (the core repacks it); --layout=bad: a field that
+        // reaches beyond point_step (the core must refuse it before anything reads past a point)
+        std::vector<patchworkpp_ros::Field> alt = fields;
+        uint32_t step = 32;
+        int first = 1;
+        if (argc > 1 && std::string(argv[1]) == "--layout=odd") {
+            alt = {{"x", 1, patchworkpp_ros::kFloat32, 1}, {"y", 9, patchworkpp_ros::kFloat32, 1}, {"z", 17, patchworkpp_ros::kFloat32, 1}};
+            step = 29;
+            first = 2;
+        } else if (argc > 1 && std::string(argv[1]) == "--layout=bad") {
+            alt = {{"x", 4, patchworkpp_ros::kFloat32, 1}, {"y", 12, patchworkpp_ros::kFloat32, 1}, {"z", 30, patchworkpp_ros::kFloat32, 1}};
+            first = 2;
+        }
+        for (int a = first; a < argc; ++a) {
             const std::vector<float> pts = read_bin(argv[a]);
             const size_t n = pts.size() / 4;
-            std::vector<uint8_t> blob(n * 32, 0xA5);  // (whatever lies between the fields must not matter)
+            std::vector<uint8_t> blob(n * step + 8, 0xA5);  // (whatever lies between the fields must not matter)
             for (size_t i = 0; i < n; ++i) {
-                std::memcpy(&blob[i * 32 + 0], &pts[i * 4 + 3], 4);
-                std::memcpy(&blob[i * 32 + 4], &pts[i * 4 + 0], 4);
-                std::memcpy(&blob[i * 32 + 12], &pts[i * 4 + 1], 4);
-                std::memcpy(&blob[i * 32 + 20], &pts[i * 4 + 2], 4);
+                if (alt.size() == fields.size()) std::memcpy(&blob[i * step + 0], &pts[i * 4 + 3], 4);
+                for (const auto &f : alt) {
+                    const int c = f.name == "x" ? 0 : (f.name == "y" ? 1 : (f.name == "z" ? 2 : -1));
+                    if (c >= 0 && f.offset + 4 <= step) std::memcpy(&blob[i * step + f.offset], &pts[i * 4 + c], 4);
+                }
             }
             patchworkpp_ros::CloudView msg;
             msg.height = 1;
             msg.width = (uint32_t)n;
-            msg.point_step = 32;
-            msg.fields = fields.data();
-            msg.num_fields = fields.size();
+            msg.point_step = step;
+            msg.fields = alt.data();
+            msg.num_fields = alt.size();
             msg.data = blob.data();
-            msg.data_size = blob.size();
+            msg.data_size = n * step;
             const patchworkpp_ros::SegmentationCore::Output out = core.estimate(msg);
             std::printf("{\"file\": \"%s\", \"points\": %zu, \"cloud\": [%u, %u, \"%016llx\"], \"ground\": [%u, %u, \"%016llx\"], "
                         "\"nonground\": [%u, %u, \"%016llx\"], \"time_us\": %.1f}\n",

@@ -95,7 +95,27 @@ public:
         const size_t n = (size_t)msg.height * msg.width;
         if (msg.point_step < 12 || n * msg.point_step > msg.data_size) throw std::runtime_error("PointCloud2: data shorter than height * width * point_step");
         if (n > (size_t)(1 << 22)) throw std::runtime_error("PointCloud2: more than 4194304 points");
-        const int rc = pwpp_estimate_ground_fields(pw_->handle(), msg.data, (int)n, (int)msg.point_step, ox, oy, oz, -1);
+        //  every field must lie INSIDE a point: a crafted offset would let the copy below and the device read run past
+        // the end of the data
+        for (const int o : {ox, oy, oz})
+            if (o < 0 || (size_t)o + 4 > (size_t)msg.point_step) throw std::runtime_error("PointCloud2: a field offset lies outside point_step");
+        // The library reads the blob in place and wants 4-byte aligned floats (PWPP_E_ARG otherwise).  A message whose step or
+        // offsets are not multiples of four -- legal in PointCloud2, unusual for a LiDAR driver -- is repacked to x, y, z first.
+        const uint8_t *blob = msg.data;
+        int step = (int)msg.point_step, bx = ox, by = oy, bz = oz;
+        std::vector<float> repacked;
+        if (msg.point_step % 4 != 0 || ox % 4 != 0 || oy % 4 != 0 || oz % 4 != 0 || (reinterpret_cast<uintptr_t>(msg.data) & 3u)) {
+            repacked.resize(3 * n);
+            for (size_t i = 0; i < n; ++i) {
+                const uint8_t *src = msg.data + i * msg.point_step;
+                std::memcpy(&repacked[3 * i], src + ox, 4);
+                std::memcpy(&repacked[3 * i + 1], src + oy, 4);
+                std::memcpy(&repacked[3 * i + 2], src + oz, 4);
+            }
+            blob = reinterpret_cast<const uint8_t *>(repacked.data());
+            step = 12, bx = 0, by = 4, bz = 8;
+        }
+        const int rc = pwpp_estimate_ground_fields(pw_->handle(), blob, (int)n, step, bx, by, bz, -1);
         if (rc < 0) throw std::runtime_error(std::string("patchworkpp (HIP): ") + pwpp_last_error());
         Output out;
         out.cloud = XyzCloud::with_points(n);  // the reference republishes the cloud as x, y, z (EigenMatToPointCloud2, :80)

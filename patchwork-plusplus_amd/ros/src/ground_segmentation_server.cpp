@@ -53,7 +53,13 @@ private:
         view.num_fields = fields.size();
         view.data = msg->data.data();
         view.data_size = msg->data.size();
-        SegmentationCore::Output out = core_->estimate(view);
+        SegmentationCore::Output out;
+        try {  //  one malformed message must not take the node down: log it, drop it
+            out = core_->estimate(view);
+        } catch (const std::exception &e) {
+            RCLCPP_ERROR(get_logger(), "message dropped: %s", e.what());
+            return;
+        }
         cloud_pub_->publish(to_msg(std::move(out.cloud), msg->header));
         std_msgs::msg::Header header = msg->header;
         header.frame_id = base_frame_;

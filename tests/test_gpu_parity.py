@@ -1337,6 +1337,13 @@ def test_ros_node_core(kitti, oracle, tmp_path):
         g, ng = h.ground(0), h.nonground(0)
         assert line["ground"][:2] == [len(ref.ground_idx), 16] and line["nonground"][:2] == [len(ref.nonground_idx), 16]
         assert line["ground"][2] == point_sum(payload(g)) and line["nonground"][2] == point_sum(payload(ng))
+    #  a message whose step / offsets are not multiples of four is repacked, same payloads; a field that reaches
+    # beyond point_step is refused (the node logs and drops such a message)
+    odd = subprocess.run([exe, "--layout=odd"] + paths, capture_output=True, text=True, check=True).stdout
+    odd_lines = [json.loads(l) for l in odd.splitlines() if l.startswith("{")]
+    assert [(l["cloud"], l["ground"], l["nonground"]) for l in odd_lines] == [(l["cloud"], l["ground"], l["nonground"]) for l in lines]
+    bad = subprocess.run([exe, "--layout=bad"] + paths[:1], capture_output=True, text=True)
+    assert bad.returncode == 1 and "outside point_step" in bad.stdout
 
 
 def test_plane_members_carry_over_between_frames(kitti, oracle):
@@ -1501,6 +1508,37 @@ def test_bench_two_ranks_on_one_gpu():
     d = run(64, ["--skip-extras"], bare=True)
     assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 64 and len(d["per_gpu"]) == 2
     assert d["dist"]["world_size"] == 2 and d["dist"]["launcher"].startswith("bench.py spawned")
+
+
+def test_bench_eight_ranks_on_one_gpu():
+    """the driver's first `bench.py --gpus 8` cannot be rehearsed on eight GPUs here -- so it is rehearsed as EIGHT
+    ranks on the one GPU (gloo, every rank on device 0), started bare the way the driver starts it: one JSON line, eight per-GPU
+    rates, eight workspaces, world size 8; the headline workload and the stateful-streams workload (stream g on rank g mod 8).
+    RCCL over xGMI stays unmeasured on hardware."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PWPP_BENCH_SHARE_DEVICE="1", PWPP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for workload, frames in (("kitti", 32), ("streams", 4)):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--frames", str(frames),
+                              "--workload", workload, "--no-cpu-baseline", "--skip-latency", "--skip-extras"], env=env, cwd=root,
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 8 and d["dist"]["world_size"] == 8 and d["dist"]["backend"] == "gloo"
+        assert [g["rank"] for g in d["per_gpu"]] == list(range(8)) and all(g["frames_per_s"] > 0 for g in d["per_gpu"])
+        assert len(d["dist"]["workspace_gb_per_rank"]) == 8 and len(d["dist"]["devices"]) == 8
+        assert d["dist"]["launcher"].startswith("bench.py spawned")
+        assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 8 * frames) < 1e-6 * 8 * frames
+        if workload == "streams":
+            # ranks 0 and 6 hold streams that start on the same source frame (g mod 6): the same adaptive state after the same frames
+            hts = d["sensor_height_of_each_ranks_first_stream"]
+            assert len(hts) == 8 and hts[0] == hts[6] and hts[1] == hts[7] and hts[0] != hts[1]
     # the dense workload (configs[4]) through the same N > 1 path: 2 x 16 frames of ~486 k points, 36-sector CZM
     d = run(16, ["--workload", "dense", "--skip-extras"])
     assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 16 and d["config"]["points_per_frame"] > 400000
