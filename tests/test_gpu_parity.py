@@ -1508,6 +1508,10 @@ def test_bench_two_ranks_on_one_gpu():
     d = run(64, ["--skip-extras"], bare=True)
     assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 64 and len(d["per_gpu"]) == 2
     assert d["dist"]["world_size"] == 2 and d["dist"]["launcher"].startswith("bench.py spawned")
+    # the dense workload (configs[4]) through the same N > 1 path: 2 x 16 frames of ~486 k points, 36-sector CZM
+    d = run(16, ["--workload", "dense", "--skip-extras"])
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 16 and d["config"]["points_per_frame"] > 400000
+    assert len(d["per_gpu"]) == 2 and "parity_check" not in d
 
 
 def test_bench_eight_ranks_on_one_gpu():
@@ -1539,10 +1543,6 @@ def test_bench_eight_ranks_on_one_gpu():
             # ranks 0 and 6 hold streams that start on the same source frame (g mod 6): the same adaptive state after the same frames
             hts = d["sensor_height_of_each_ranks_first_stream"]
             assert len(hts) == 8 and hts[0] == hts[6] and hts[1] == hts[7] and hts[0] != hts[1]
-    # the dense workload (configs[4]) through the same N > 1 path: 2 x 16 frames of ~486 k points, 36-sector CZM
-    d = run(16, ["--workload", "dense", "--skip-extras"])
-    assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 16 and d["config"]["points_per_frame"] > 400000
-    assert len(d["per_gpu"]) == 2 and "parity_check" not in d
 
 
 def test_precleared_counters_under_changing_call_shapes(kitti, oracle):
