@@ -18,11 +18,14 @@ def make_input():
     for i in range(F):
         big[offs[i]:offs[i + 1]].copy_(sd[i % 6])
     return big
+ORDERED = len(sys.argv) > 1 and sys.argv[1] == "--reference-order"   # PWPP_ORDER_REFERENCE: every sub-list in the reference's z-sorted order
 for depth in (1, 2, 3):
-    for overlap in (True, False):
+    for overlap in ((False,) if ORDERED else (True, False)):
         ins = [make_input() for _ in range(depth)]
         hs = [pwpp_hip.Handle() for _ in range(depth)]
-        for h in hs: h.set_overlap(overlap)
+        for h in hs:
+            h.set_overlap(overlap)
+            h.set_output_order(ORDERED)
         bs = [hs[d].make_device_batch([ins[d].data_ptr() + int(offs[i]) * 16 for i in range(F)], ns) for d in range(depth)]
         torch.cuda.synchronize()
         def run(steps):
