@@ -208,6 +208,34 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def two_in_flight(pwpp_hip, torch, h0, batch0, make_second, frames, n, gpu_index, params=None):
+    """frames/s of the headline's schedule on (h0, batch0): a second handle joins (make_second(handle) -> its batch), two batches in
+    flight, every handle on one stream.  Returns (frames/s, frames the second -- cold -- handle had to redo)."""
+    h1 = pwpp_hip.Handle(params, device=gpu_index) if params is not None else pwpp_hip.Handle(device=gpu_index)
+    hs, bs = [h0, h1], [batch0, make_second(h1)]
+    for hh in hs:
+        hh.set_overlap(False)
+
+    def run(m):
+        for k in range(m):
+            if k >= 2:
+                hs[k % 2].synchronize()
+            hs[k % 2].launch_device_batch(bs[k % 2], cols=4, mode=pwpp_hip.MODE_FRESH)
+        for hh in hs:
+            hh.synchronize()
+
+    run(6)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(n)
+    torch.cuda.synchronize()
+    rate = frames * n / (time.perf_counter() - t0)
+    redone = h1.redo_stats()[1]
+    h1.close()
+    h0.set_overlap(True)
+    return rate, redone
+
+
 def dense_leg(pwpp_hip, torch, dev, gpu_index, frames=256, steps=5):
     """BASELINE.json configs[4] on this GPU, outside the timed region: dense synthetic 128-beam ~480k-point frames, 36-sector CZM."""
     import pwpp_synth
@@ -241,8 +269,12 @@ def dense_leg(pwpp_hip, torch, dev, gpu_index, frames=256, steps=5):
     dt = (time.perf_counter() - t0) / steps
     b_alg = float(sum(20 * ns[i] + 24 * int(counts[i, 2]) for i in range(frames)))
     ws = h.workspace_bytes() / 1e9
+    dptrs = [big.data_ptr() + int(offs[i]) * 16 for i in range(frames)]
+    fps2, _ = two_in_flight(pwpp_hip, torch, h, batch, lambda hh: hh.make_device_batch(dptrs, ns), frames, 2 * steps, gpu_index, params)
     h.close()
-    return {"workload": "configs[4] on one GPU: %d dense synthetic 128-beam frames (~%d points each), 36-sector CZM, device-resident, fresh state"
+    dt_sync, dt = dt, frames / fps2
+    return {"schedule": "as the headline: two batches in flight, one handle each", "synchronous": {"frames_per_s": frames / dt_sync, "ms_per_step": 1000.0 * dt_sync},
+            "workload": "configs[4] on one GPU: %d dense synthetic 128-beam frames (~%d points each), 36-sector CZM, device-resident, fresh state"
                         % (frames, int(np.mean(ns))),
             "frames": frames, "steps": steps, "frames_per_s": frames / dt, "ms_per_step": 1000.0 * dt,
             "algorithmic_bytes_per_step": b_alg, "pipeline_achieved_GBps": b_alg / dt / 1e9, "pipeline_frac": b_alg / dt / 1e9 / HBM_PEAK_GBS,
@@ -293,31 +325,7 @@ def distinct_leg(pwpp_hip, torch, dev, gpu_index, frames=1024, steps=10):
     dt = (time.perf_counter() - t1) / steps
     b_alg = float(sum(20 * ns[i] + 24 * int(counts[i, 2]) for i in range(frames)))
 
-    def in_flight_rate(h0, batch0, make_batch, n=2 * steps):
-        """the headline's schedule: two handles, two batches in flight, each handle single-stream"""
-        h1 = pwpp_hip.Handle(device=gpu_index)
-        hs, bs = [h0, h1], [batch0, make_batch(h1)]
-        for hh in hs:
-            hh.set_overlap(False)
-        def run(m):
-            for k in range(m):
-                if k >= 2:
-                    hs[k % 2].synchronize()
-                hs[k % 2].launch_device_batch(bs[k % 2], cols=4, mode=pwpp_hip.MODE_FRESH)
-            for hh in hs:
-                hh.synchronize()
-        run(6)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        run(n)
-        torch.cuda.synchronize()
-        rate = frames * n / (time.perf_counter() - t2)
-        redone = h1.redo_stats()[1]
-        h1.close()
-        h0.set_overlap(True)
-        return rate, redone
-
-    fps_in_flight, redone_second = in_flight_rate(h, whole, lambda hh: hh.make_device_batch(ptrs, ns))
+    fps_in_flight, redone_second = two_in_flight(pwpp_hip, torch, h, whole, lambda hh: hh.make_device_batch(ptrs, ns), frames, 2 * steps, gpu_index)
     h.set_profiling(True)   # per-kernel times of the single-stream schedule on these frames
     h.reset_kernel_profile()
     for _ in range(3):
@@ -344,7 +352,7 @@ def distinct_leg(pwpp_hip, torch, dev, gpu_index, frames=1024, steps=10):
         hc.synchronize()
     dtc = (time.perf_counter() - t1) / steps
     rep_ptrs = [rep.data_ptr() + int(rep_offs[i]) * 16 for i in range(frames)]
-    control_in_flight, _ = in_flight_rate(hc, cb, lambda hh: hh.make_device_batch(rep_ptrs, rep_ns))
+    control_in_flight, _ = two_in_flight(pwpp_hip, torch, hc, cb, lambda hh: hh.make_device_batch(rep_ptrs, rep_ns), frames, 2 * steps, gpu_index)
     control = {"frames_per_s": control_in_flight, "frames_per_s_synchronous": frames / dtc, "ms_per_step": 1000.0 * dtc, "workspace_gb": hc.workspace_bytes() / 1e9, "points_per_frame": int(np.mean(rep_ns)),
                "what": "six of the same synthetic frames replayed over %d distinct buffers (how the headline treats the six KITTI frames)" % frames}
     hc.close()
