@@ -375,7 +375,7 @@ def distinct_leg(pwpp_hip, torch, dev, gpu_index, frames=1024, steps=10):
     return out
 
 
-def streams_leg(pwpp_hip, torch, dev, gpu_index, src_dev, ns_src, counts=(1, 64, 256), steps=30):
+def streams_leg(pwpp_hip, torch, dev, gpu_index, src_dev, ns_src, counts=(1, 64, 256, 1024), steps=30):
     """SURVEY 8f-f1 in the driver's line: S long-lived stateful streams stepped in lock-step -- the reference's
     real use (one PatchWorkpp object per sensor, demo_sequential.cpp:54-67), device-resident frames; stream s sees the source frames
     in the order s, s+1, ...  The single stream is also reported by its GPU time per frame in steady state (A-GLE histories full)."""
@@ -403,6 +403,35 @@ def streams_leg(pwpp_hip, torch, dev, gpu_index, src_dev, ns_src, counts=(1, 64,
             row["history_entries"] = [int(len(h.history(0, 0, r))) for r in range(4)]
             row["gpu_us_min_max"] = [min(gpu), max(gpu)]
         out["by_streams"].append(row)
+        h.close()
+    # 1024 streams as TWO groups of 512, one handle each, a lock-step of each group in flight (a stream's frames stay in order: its
+    # group's handle finishes frame t before it launches frame t + 1; the two groups are different sensors)
+    S = 512
+    hs = [pwpp_hip.Handle(device=gpu_index) for _ in range(2)]
+    bs = []
+    for g, h in enumerate(hs):
+        h.set_num_streams(S)
+        bs.append([h.make_device_batch([src_dev[(g * S + s + t) % K].data_ptr() for s in range(S)], [ns_src[(g * S + s + t) % K] for s in range(S)]) for t in range(K)])
+
+    def run(n):
+        for k in range(n):
+            g = k % 2
+            if k >= 2:
+                hs[g].synchronize()
+            hs[g].launch_device_batch(bs[g][(k // 2) % K], cols=4, mode=pwpp_hip.MODE_STREAMS)
+        for h in hs:
+            h.synchronize()
+
+    run(24)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 2 * steps
+    run(n)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["two_groups_in_flight"] = {"streams": 2 * S, "groups": 2, "frames_per_s": S * n / dt, "ms_per_lockstep_of_a_group": 1000.0 * dt / n,
+                                   "what": "two handles of 512 streams each, alternating: the lock-step of one group under the other's"}
+    for h in hs:
         h.close()
     return out
 

@@ -168,7 +168,7 @@ PWPP_API int pwpp_set_num_streams(pwpp_handle *h, int streams); /* (re)creates `
 PWPP_API int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32_t *n_nonground, int32_t *n_patches);
 /* getGroundIndices()/getNongroundIndices(), reference patchworkpp.h:159-160, patchworkpp.cpp:18-26.
  * The index SETS are those of the reference's control flow with the plane-fit sums of patchworkpp.cpp:56-60
- * evaluated (DESIGN.md 4, contract v3)
+ * evaluated (DESIGN.md 3.4, contract v3)
  *   - for a fit set of 1, 2 or 3 points: in the reference's own float arithmetic, which is determinate there (Eigen
  *     reduces fewer elements than one SIMD packet sequentially; two terms commute) -- points in the order of the
  *     reference's z-sorted bin, equal heights in cloud order (the reference's std::sort is stable only for bins of up
@@ -196,7 +196,7 @@ PWPP_API int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32
  *     never further from it than the float builds are.  Adaptive sensor height over the 200-frame sequences: within 3.3e-7 m of
  *     the exact build (the float build: 8.5e-7 m).  On the reference's own KITTI samples: identical index sets, every build.
  * (NaN heights are undefined in the reference itself: it sorts bins with `a.z < b.z`.)
- * The order inside a list is not the reference's unless pwpp_set_output_order asks for it (DESIGN.md 6). */
+ * The order inside a list is not the reference's unless pwpp_set_output_order asks for it (DESIGN.md 3, K7; INTEGRATION.md 5). */
 PWPP_API int pwpp_get_ground_indices(pwpp_handle *h, int frame, int32_t *out);
 PWPP_API int pwpp_get_nonground_indices(pwpp_handle *h, int frame, int32_t *out);
 /* getGround()/getNonground(), reference patchworkpp.h:157-158: row-major (count,3) float32,
@@ -247,7 +247,7 @@ PWPP_API int64_t pwpp_get_clamped_frames(pwpp_handle *h);
 PWPP_API int pwpp_get_fxp_geometry(const pwpp_params *p, int *shift, float *out_xy, int capacity_bins);
 /* Host only (no device needed): the axis-aligned box {xmin, xmax, ymin, ymax} the library assumes around every CZM bin of
  * a parameter set, bins in traversal order (zone, ring, sector).  The fit kernels prove with it that no point of a bin's
- * high part can lie below a plane (DESIGN.md 3, K4), so every point the reference bins into b must lie inside box b:
+ * high part can lie below a plane (DESIGN.md 3.2), so every point the reference bins into b must lie inside box b:
  * tests/test_capi_cpu.py checks exactly that.  Returns the number of bins (with out_boxes == NULL: just that). */
 PWPP_API int pwpp_get_bin_boxes(const pwpp_params *p, float *out_boxes, int capacity_bins);
 PWPP_API int pwpp_set_plane_state(pwpp_handle *h, int stream, const float in[10]);
@@ -281,7 +281,7 @@ PWPP_API int pwpp_set_profiling(pwpp_handle *h, int enable);
 PWPP_API int pwpp_get_kernel_profile(pwpp_handle *h, double *sum_ms /*[PWPP_NUM_KERNELS]*/, int64_t *launches /*[PWPP_NUM_KERNELS]*/);
 PWPP_API int pwpp_reset_kernel_profile(pwpp_handle *h);
 PWPP_API const char *pwpp_kernel_name(int k);
-/* the fixed-point contract of the plane-fit sums for this handle (DESIGN.md 4): the shift s (grid 2^-s m) ... */
+/* the fixed-point contract of the plane-fit sums for this handle (DESIGN.md 3.4): the shift s (grid 2^-s m) ... */
 PWPP_API int pwpp_get_fxp_shift(pwpp_handle *h);
 /* ... and every bin's origin (its polar centre rounded to 1/8 m): out_xy = B x {x, y}; returns B (out_xy = NULL: only B).
  * The z coordinates of a fit of 4+ points are clamped to z0 +- 2^(26-s) m (32 m with the default CZM; z0 = the patch's first
@@ -305,7 +305,7 @@ PWPP_API int pwpp_set_output_order(pwpp_handle *h, int order);
  * by memory, the plane fits by their dependent chains).  Same results; per-kernel profiling (pwpp_set_profiling) and PWPP_ORDER_REFERENCE use the single-stream
  * schedule.  pwpp_set_overlap(h, 0) / PWPP_OVERLAP=0 select that schedule for everything. */
 PWPP_API int pwpp_set_overlap(pwpp_handle *h, int on);
-/* one-pass binning (fixed bin segments; DESIGN.md 3, K1'): batches launched that way and how many of
+/* one-pass binning (fixed bin segments): batches launched that way and how many of
  * them had at least one frame redone on the exact two-pass path because a bin outgrew its segment.  Finishes the
  * batch in flight first.  No reference counterpart (its bins are unbounded vectors, patchworkpp.cpp:578-622). */
 PWPP_API int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone);
@@ -339,7 +339,7 @@ PWPP_API int pwpp_get_redo_stats(pwpp_handle *h, int64_t *frames_one_pass, int64
  *   "bin_block"           threads per workgroup of the one-pass binning kernel (128 / 256 / 512 / 1024, default 256)
  *   "hi_split"            metres above the ground level (-sensor_height) where the "high" part of a bin begins
  *                         (default 0.6; 1e30 = no high parts): the fit passes skip a high part whenever they can
- *                         prove that none of its points can enter the pass (DESIGN.md 3, K4)
+ *                         prove that none of its points can enter the pass (DESIGN.md 3.2)
  *   "hi_split_zones"      how many zones' bins are stored in two parts (0..4, default 1: the near zone)
  *   "debug_flags"         4: timing probes of the fit chain; 8: timing probes of the binning, scan and GLE kernels;
  *                         16: exact binning arithmetic only;

@@ -36,7 +36,7 @@ typedef struct pwo_params {
 /* Arithmetic of the plane fit's sums (reference patchworkpp.cpp:56-60), the one place the
  * reference defers to Eigen:
  *   EIGEN_F32    float accumulators, rows in storage order (plainest reading of Eigen)
- *   FXP          the product's order-independent fixed-point contract (DESIGN.md section 4);
+ *   FXP          the product's order-independent fixed-point contract (DESIGN.md section 3.4);
  *                the restatement only (it needs the bin and its first LPR, which the shim cannot see)
  *   EXACT_F64    reference-neutral arbiter: double accumulation of the unquantised floats,
  *                one rounding to float per output

@@ -35,7 +35,7 @@ int pwo_ext_num_records(void *h);
 void pwo_ext_get_records(void *h, pwo_patch_record *out);
 void pwo_ext_set_state(void *h, double sensor_height, const double *elevation_thr4, const double *flatness_thr4);
 void pwo_ext_jacobi(const float *cov9_rowmajor, float *u9_rowmajor, float *sv3);
-/* the fixed-point contract (DESIGN.md section 4): shift, z half-range, per-bin origins (ox/oy may be NULL) */
+/* the fixed-point contract (DESIGN.md section 3.4): shift, z half-range, per-bin origins (ox/oy may be NULL) */
 void pwo_ext_fxp_geometry(void *h, int *shift, double *zr, float *ox, float *oy);
 long long pwo_ext_quantise(float v, double origin, int shift);
 long long pwo_ext_quantise_z(float v, double z0, int shift);

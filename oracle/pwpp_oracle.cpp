@@ -19,7 +19,7 @@
 // Arithmetic flavours for the plane fit (the only place where the reference defers to
 // Eigen); everything else follows the reference's own float/double expressions:
 //   PWO_ARITH_EIGEN_F32  float accumulators in storage order (plain reading of Eigen)
-//   PWO_ARITH_FXP        the product's contract v3 (DESIGN.md section 4): fit sets of 1-3 points in the
+//   PWO_ARITH_FXP        the product's contract v3 (DESIGN.md section 3.4): fit sets of 1-3 points in the
 //                        reference's own float arithmetic (determinate there), larger ones in
 //                        order-independent fixed point; this is the flavour the HIP kernels
 //                        must match bit for bit.
@@ -74,7 +74,7 @@ float f_abs(float v) { return v < 0.0f ? -v : v; }
 float f_max(float a, float b) { return a < b ? b : a; }
 
 // ---------------------------------------------------------------------------------
-// The fixed-point contract of the plane-fit sums (DESIGN.md section 4), version 2.
+// The fixed-point contract of the plane-fit sums (DESIGN.md section 3.4), version 2.
 //   * every CZM bin has an ORIGIN (ox, oy): its polar centre rounded to 1/8 m; R = the largest
 //     distance of any bin corner from its origin;
 //   * s = the largest shift <= 21 with (R + 0.01) * 2^s <= 2^26; ZR = 2^(26 - s) metres;

@@ -110,7 +110,7 @@ struct pwpp_handle {
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     bool overlap = true;   // pwpp_set_overlap: big batches as a pipeline of frame ranges over the two streams (default on)
     int overlap_ranges = 2;  // (more ranges were slower at every setting tried: each range's fit kernels end with the tail of their
-                             // longest waves -- DESIGN.md section 9)
+                             // longest waves -- docs/history/design_through_round4.md section 9)
     int overlap_mode = 1;  // option "overlap_mode": 1 = memory stream / fit stream pipeline, 0 = whole ranges alternating between the streams
     std::vector<hipEvent_t> ev_ranges;  // two per frame range: binned, fitted
     int bin_block = 256;                // option "bin_block": threads per workgroup of the one-pass binning kernel
@@ -218,7 +218,7 @@ struct pwpp_handle {
 
 namespace {
 
-// The fixed-point contract of the plane-fit sums (DESIGN.md section 4): every bin sums its points around an
+// The fixed-point contract of the plane-fit sums (DESIGN.md section 3.4): every bin sums its points around an
 // ORIGIN, its polar centre rounded to 1/8 m (a sector wider than a quarter turn keeps the sensor), and the
 // shift s is the largest one <= 21 that keeps every point of every bin within 2^26 grid steps of its origin.
 void fxp_geometry(const PwppDevParams &d, std::vector<float2> &origin, int &shift) {

@@ -1,5 +1,5 @@
 // pwpp_common.hpp -- device helpers shared by the gfx950 kernels of this library.
-// The arithmetic helpers implement the contract of DESIGN.md section 4; citations are
+// The arithmetic helpers implement the contract of DESIGN.md section 3.4; citations are
 // /root/reference/cpp/patchworkpp/src/patchworkpp.cpp unless a header is named.
 #ifndef PWPP_COMMON_HPP
 #define PWPP_COMMON_HPP
@@ -220,7 +220,7 @@ __device__ void jacobi_svd3(const float a[9], float u[9], float sv[3]) {
 }
 
 // ------------------------------------------------------------------------------------------
-// The fixed-point contract of the plane-fit sums (DESIGN.md section 4; restated for the checker
+// The fixed-point contract of the plane-fit sums (DESIGN.md section 3.4; restated for the checker
 // in oracle/pwpp_oracle.cpp):
 //   Q_x(v) = rint(double(v) * 2^s - ox * 2^s), Q_y alike        (ox, oy: the bin's origin, multiples of 1/8 m)
 //   Q_z(v) = the same around z0 after clamping v to [z0 - ZR, z0 + ZR] in float
@@ -303,7 +303,7 @@ struct Moments {
 };
 
 // ------------------------------------------------------------------------------------------
-// plane of ref :47-75 from the exact integer moments of a point set (DESIGN.md section 4):
+// plane of ref :47-75 from the exact integer moments of a point set (DESIGN.md section 3.4):
 //   mean_a = float( (S1_a * (1/n)) * 2^-s + origin_a )
 //   cov_ab = float( ((n*S2_ab - S1_a*S1_b) * (1/(n*(n-1)))) * 2^-2s )     numerator exact in 128 bits; both reciprocals in double
 // then Eigen's JacobiSVD on the float covariance, normal = U.col(2) flipped to z >= 0 (:66-68),

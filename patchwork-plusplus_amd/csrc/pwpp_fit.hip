@@ -30,7 +30,7 @@
 // DESIGN.md section 3 has the measurements that led here (and the variants that were dropped: points
 // parked in LDS, the chain cut into phase kernels).
 //
-// All reductions are integer (DESIGN.md section 4), so every variant produces bit-identical
+// All reductions are integer (DESIGN.md section 3.4), so every variant produces bit-identical
 // planes and the same index sets whatever the lane count.
 #include <stdio.h>
 #include <stdlib.h>
@@ -887,7 +887,7 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
             if (need_lpr) {
                 lpr = l;
                 lpr_valid = true;
-                if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative (DESIGN.md section 4)
+                if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative (DESIGN.md section 3.4)
                     z0 = fxp_z_origin(l);
                     z0_set = true;
                     org = fxp_org(pc.ox, pc.oy, z0, scale, P.fxp_zr);
@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : PWPP_W16_OCC) void k_f
                 const double l = sh.p[ln].u.lpr;
                 O(lpr) = l;
                 O(lpr_valid) = 1;
-                if (!O(z0_set)) {  // the z origin of this patch's sums: its first lowest-point representative (DESIGN.md section 4)
+                if (!O(z0_set)) {  // the z origin of this patch's sums: its first lowest-point representative (DESIGN.md section 3.4)
                     O(z0) = fxp_z_origin(l);
                     O(z0_set) = 1;
                 }
@@ -1892,7 +1892,7 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
                 if (eligible >= P.num_lpr || pc.n_hi == 0u) break;
             }
             lpr_valid = true;
-            if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative (DESIGN.md section 4)
+            if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative (DESIGN.md section 3.4)
                 z0 = fxp_z_origin(lpr);
                 z0_set = true;
                 org = fxp_org(pc.ox, pc.oy, z0, scale, P.fxp_zr);
@@ -2102,7 +2102,7 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
     auto new_lpr = [&]() {
         lpr = block_lpr(sh, pts, use_cutoff, cutoff, P.num_lpr);
         lpr_valid = true;
-        if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative (DESIGN.md section 4)
+        if (!z0_set) {  // the z origin of this patch's sums: its first lowest-point representative (DESIGN.md section 3.4)
             z0 = fxp_z_origin(lpr);
             z0_set = true;
             org = fxp_org(pc.ox, pc.oy, z0, scale, P.fxp_zr);

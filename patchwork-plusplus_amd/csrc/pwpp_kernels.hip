@@ -22,7 +22,7 @@
 // VALU issue (plane fits): no MFMA anywhere (3x3 covariances); the levers are coalesced 16 B/lane
 // traffic, LDS-staged atomics, XCD-aware grids and as few passes over a patch as the chain allows.
 //
-// ARITHMETIC CONTRACT (DESIGN.md section 4).  Everything the reference evaluates in its own
+// ARITHMETIC CONTRACT (DESIGN.md section 3.4).  Everything the reference evaluates in its own
 // float/double expressions is evaluated here with the same operations in the same order
 // (this file is compiled with -ffp-contract=off; f32 / and sqrt are correctly rounded under
 // hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt; f64 always).  The one place the

@@ -13,7 +13,7 @@
 //  * without it (or with PWPP_NO_EIGEN) the getters return the small row-major containers below and
 //    estimateGround takes a raw pointer.
 //
-// Differences a caller can observe, all documented in DESIGN.md section 6:
+// Differences a caller can observe, all documented in DESIGN.md section 7 and INTEGRATION.md section 5:
 //  * index and point lists hold the same SETS as the reference, ordered by the device
 //    pipeline, not by the reference's bin traversal / z order;
 //  * getTimeTaken() is GPU time in microseconds (the reference reports CPU clock ticks = us);

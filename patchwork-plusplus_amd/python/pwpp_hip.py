@@ -387,7 +387,7 @@ class Handle:
         return self._L.pwpp_get_fxp_shift(self._h)
 
     def fxp_origins(self):
-        """(B, 2) float32: the origin of every bin's fixed-point plane-fit sums (DESIGN.md section 4)."""
+        """(B, 2) float32: the origin of every bin's fixed-point plane-fit sums (DESIGN.md section 3.4)."""
         nb = self._L.pwpp_get_fxp_origins(self._h, None, 0)  # size query
         self._check(nb)
         out = np.zeros((nb, 2), np.float32)

@@ -27,7 +27,7 @@ def compare(ground_a, recs_a, ground_b, recs_b, min_points=0, min_ground=0):
     """a against b (b = the arbiter: its singular values define the conditioning).  recs_*: structured arrays
     with mean / normal / sv per processed patch, same patches in the same order.
     Returns dict(symdiff, iou, dc, dn, dn_well, cond_of_worst, excess) where excess = max over the patches of
-    dn / (3e-5 + 4e-10 * cond): <= 1 means every patch is within the bound of DESIGN.md section 4.
+    dn / (3e-5 + 4e-10 * cond): <= 1 means every patch is within the bound of DESIGN.md section 3.4.
     min_points: patches with fewer points are left out of the plane statistics (two or three points do not
     define a plane: their normal is whatever the last bit of the covariance says, in every arithmetic).
     min_ground: patches whose FINAL fit set (a's ground points) is smaller are left out of the plane statistics -- the

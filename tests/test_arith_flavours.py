@@ -1,4 +1,4 @@
-"""The arithmetic contract of the plane-fit sums, measured (DESIGN.md section 4, VERDICT r01 item 1).
+"""The arithmetic contract of the plane-fit sums, measured (DESIGN.md section 3.4, VERDICT r01 item 1).
 
 The reference adds up the sums of estimate_plane (patchworkpp.cpp:56-60) in float, in whatever order Eigen
 picks; the product adds them up exactly, in fixed point.  Neither can be the yardstick for the other, so both
@@ -160,7 +160,7 @@ def test_contract_is_no_further_from_exact_arithmetic_than_float_sums_on_adversa
     """CPU only (tools/fuzz_arbiter.py, 24 seeds = 48 frames of its adversarial clouds): walls, ramps, heavy undulation and
     reflected noise produce degenerate INTERMEDIATE fits -- a handful of collinear seeds whose plane is vertical with
     n_z = +-1e-6 -- and the reference orients a normal by the sign of n_z (patchworkpp.cpp:68), so the next one-sided round
-    takes one side of the plane or the other: every arithmetic parts ways with every other there (DESIGN.md section 4).
+    takes one side of the plane or the other: every arithmetic parts ways with every other there (DESIGN.md section 3.4).
     What must hold: the fixed-point contract differs from the exact arbiter in no more frames than the reference's float
     sums do (give or take the small-sample noise), and on most frames none of the three differs at all."""
     import importlib.util

@@ -219,7 +219,7 @@ def test_bin_boxes_contain_every_point_the_reference_bins_there(lib):
 
 
 def test_fixed_point_geometry_matches_the_restatement(lib, oracle_built):
-    """Shift and per-bin origins of the plane-fit sums (DESIGN.md section 4) are computed on the host in pwpp_create and,
+    """Shift and per-bin origins of the plane-fit sums (DESIGN.md section 3.4) are computed on the host in pwpp_create and,
     independently, by the CPU restatement: they must agree for every CZM shape and range -- host logic, no GPU."""
     import numpy as np
     lib.pwpp_get_fxp_geometry.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]

@@ -737,7 +737,7 @@ def test_long_lists_in_a_big_batch(kitti, oracle):
 
 
 def test_point_order_invariance_and_determinism(kitti):
-    """Size-independent properties of the arithmetic contract (DESIGN.md section 4): the plane-fit sums
+    """Size-independent properties of the arithmetic contract (DESIGN.md section 3.4): the plane-fit sums
     are exact integers, so (1) shuffling the rows of a cloud gives the same ground SET (indices mapped
     back), bit-identical patch planes and the same adaptive state; (2) two runs of the same batch give
     identical outputs although the scatter order inside a bin depends on atomics."""

@@ -163,7 +163,7 @@ def test_jacobi_is_an_eigen_decomposition(oracle_built):
 
 
 def test_fxp_contract_primitives(oracle_built):
-    """Shift, origins and quantisers of the fixed-point contract (DESIGN.md section 4)."""
+    """Shift, origins and quantisers of the fixed-point contract (DESIGN.md section 3.4)."""
     lib = oracle_built.restatement()
     L = lib.lib
     sh, zr, ox, oy = ol.Estimator(lib, arith=ol.ARITH_FXP).fxp_geometry()

@@ -6,13 +6,13 @@ sums in a 4-lane order, double sums rounded once).
 Where the three builds of the reference agree on a frame's ground set -- i.e. where the reference's result does not hang on the
 summation order Eigen happens to be compiled with -- the product is held against that set; where they disagree among themselves
 there is no single "reference result", those frames are counted and the product is held against the exact-arithmetic build (the
-arbiter of DESIGN.md section 4).  MEASURED (round 4, all 208 frames on the CPU with the restatement of the contract, which the HIP
+arbiter of DESIGN.md section 3.4).  MEASURED (round 4, all 208 frames on the CPU with the restatement of the contract, which the HIP
 path equals bit for bit -- asserted below): the three builds are unanimous on 204 frames; on 203 of them the contract gives exactly
 their set, on ONE (frame 6) it differs by one index of 128 075 -- the 2^-21 m grid of the z sums moves cov_xz by a few float ulps,
 the normal by as many, and a point 1e-7 m from th_dist changes sides; on the 4 frames where the float builds part from exact
 arithmetic (by 1, 1, 8 and 129 indices) the contract sides with exact arithmetic.  A grid four or eight times finer for z
 (tried in the restatement) trades frame 6 for another knife edge (frame 137): no arithmetic that is not Eigen's own order can be
-unanimous-exact on every frame, and Eigen's order is not knowable here (DESIGN.md section 5).  So the assertions are: the HIP path
+unanimous-exact on every frame, and Eigen's order is not knowable here (DESIGN.md section 3.4).  So the assertions are: the HIP path
 equals the contract on every frame; it equals a unanimous reference on at least 99 % of the unanimous frames and never differs
 from it by more than 64 indices (round 5, 4 200 frames on the CPU -- tools/parity_statistics.py, profiles/r05_parity_statistics.json:
 99.74 % of 1 942 fresh and 99.90 % of 1 945 stateful unanimous frames exact, the seven misses 1-28 indices; dense 36-sector frames

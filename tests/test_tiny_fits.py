@@ -1,4 +1,4 @@
-"""Contract v3 (DESIGN.md section 4, VERDICT r02 item 1): a fit set of ONE, TWO or THREE points follows the reference's own
+"""Contract v3 (DESIGN.md section 3.4, VERDICT r02 item 1): a fit set of ONE, TWO or THREE points follows the reference's own
 float arithmetic (patchworkpp.cpp:56-60) -- there Eigen's sums are determinate (fewer elements than a SIMD packet are
 reduced sequentially in storage order, two terms commute), so nothing about those planes is "degenerate": all three
 builds of the reference agree on them, and the product must agree with them.

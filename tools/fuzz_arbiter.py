@@ -2,7 +2,7 @@
 """CPU only: the arithmetic contract of the product (restatement, fixed-point flavour -- what the HIP path reproduces bit
 for bit) against the exact-f64 arbiter (the same control flow with the sums of patchworkpp.cpp:56-60 in exact arithmetic)
 on the randomised inputs of tools/fuzz_parity.py, and the float flavour of the reference measured the same way.
-Heights further than 32 m from a patch's lowest points are left out (the contract clamps them, DESIGN.md section 4), and so
+Heights further than 32 m from a patch's lowest points are left out (the contract clamps them, DESIGN.md section 3.4), and so
 are parameter sets whose fits have one or two points (no arithmetic defines those planes).
 
 usage: python tools/fuzz_arbiter.py [cases] [first_seed]
