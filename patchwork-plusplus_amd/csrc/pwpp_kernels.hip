@@ -291,156 +291,18 @@ __global__ __launch_bounds__(kBlock) void k_czm_bin(PwppBatch Bt) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K1'  one-pass binning (k_czm_bin_scatter): code AND scatter in the same kernel.
-// The two-pass path streams the cloud twice (K1: 18 B/pt, K3: 34 B/pt) only because a point's
-// slot needs the frame's complete histogram.  With 288 GB of HBM the bins can have FIXED segments
-// instead: bin b of every frame owns cap_off[b+1] - cap_off[b] slots (a multiple of its expected
-// share of the largest frame, sized on the host), so the slot is  segment start + the range this
-// workgroup reserves with one global atomic per bin + the rank inside the workgroup  -- no scan
-// in between, 16 bytes read and 16 written per point.  A bin that outgrows its segment raises the
-// frame's overflow flag (points beyond the segment are not written); the host then redoes the
-// batch on the exact two-pass path, so the result never depends on the capacities.
-// ------------------------------------------------------------------------------------------
-// BLOCK threads, four points each.  The per-workgroup set-up (zeroing the counters, fetching the segment table, the
-// reservation atomics) does not depend on the tile size, so a larger workgroup halves it per point.
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 8) void k_czm_bin_scatter(PwppBatch Bt, int tiles_per_frame) {
-    constexpr int kBlock = BLOCK;
-    constexpr int kOnePassPts = 4 * BLOCK;  // points per workgroup
-    extern __shared__ unsigned s_dyn[];  // sized at launch (binning_lds_bytes): 8 KB for the default model
-    const int NB = PWPP_NUM_PARTS(Bt.P.num_bins);
-    unsigned *s_cnt = s_dyn;             // [parts] points of this workgroup per part, then its first slot in the part
-    unsigned *s_seg = s_dyn + NB;        // [parts + 1] segment starts
-    __shared__ float4 s_zt[8];
-    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and the
-    // scattered 12-byte / 4-byte records of a bin merge into full lines only if the workgroups that write
-    // that bin share an L2.  So XCD k takes the frames k, k + 8, ..., all tiles of a frame in a row.
-    // Fewer than 8 frames (tiles_per_frame < 0): latency, not write merging, is what counts, and a frame confined to one
-    // XCD would have 32 of the 256 CUs -- its tiles are dealt over all XCDs instead.
-    const bool spread = tiles_per_frame < 0;
-    if (spread) tiles_per_frame = -tiles_per_frame;
-    const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
-    const int f = spread ? lin / tiles_per_frame : xcd + 8 * (slot / tiles_per_frame);
-    if (f >= Bt.num_frames) return;
-    const PwppFrameDesc fd = Bt.frames[f];
-    const int first = ((spread ? lin : slot) % tiles_per_frame) * kOnePassPts;
-    if (first >= fd.n) return;
-    const PwppDevParams &P = Bt.P;
-    constexpr int kPer = kOnePassPts / kBlock;
-    unsigned pc[kPer];  // code | rank inside the workgroup << 16
-    float px[kPer], py[kPer], pz[kPer], pw[kPer];
-    int probe_i = 0;  // timing probes (debug_flags & 8): slots 0.. of the probe array, workgroup 0; slot 8 = the latest end of any workgroup
-    auto probe = [&]() {
-        if ((Bt.debug & 8) && blockIdx.x == 0 && threadIdx.x == 0 && probe_i < 8) Bt.dbg[probe_i++] = wall_clock64();
-    };
-    probe();
-    // the points first: their loads are under way while the tables are set up (the kernel is a latency chain per
-    // workgroup -- at half its occupancy it takes 1.4 x as long -- and the barrier below would otherwise stand
-    // between the table loads and these)
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const int i = first + j * kBlock + threadIdx.x;
-        px[j] = py[j] = pz[j] = pw[j] = 0.0f;
-        if (i < fd.n) load_point(fd, i, px[j], py[j], pz[j], pw[j]);
-    }
-    for (int b = threadIdx.x; b < NB; b += kBlock) s_cnt[b] = 0;
-    for (int b0 = 0; b0 <= NB; b0 += 4 * kBlock) {  // (four table entries per thread in flight: not one L2 round trip per iteration)
-        unsigned sv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int b = b0 + q * kBlock + (int)threadIdx.x;
-            sv[q] = b <= NB ? Bt.cap_off[b] : 0u;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int b = b0 + q * kBlock + (int)threadIdx.x;
-            if (b <= NB) s_seg[b] = sv[q];
-        }
-    }
-    fill_zone_table(P, s_zt);
-    __syncthreads();
-    probe();  // 1: tables in LDS
-    const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
-    const float rnr_z_guard = (float)(-sensor_height - 0.8) + 1e-3f;
-    const float zs = hi_split_z(P, sensor_height);
-    unsigned dropped = 0;
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const int i = first + j * kBlock + threadIdx.x;
-        unsigned code = PWPP_CODE_DROP;
-        if (i < fd.n) {
-            const float x = px[j], y = py[j], z = pz[j], w = pw[j];
-            code = part_of(P, czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0), z, zs);
-            if (code == PWPP_CODE_DROP) ++dropped;
-            pz[j] = binned_z(z);
-        }
-        unsigned pos;
-        const unsigned old = wave_run_add(s_cnt, code, code != PWPP_CODE_DROP, pos);
-        pc[j] = code | ((old + pos) << 16);
-    }
-    __syncthreads();
-    probe();  // 2: points in, codes and ranks
-    unsigned *gcount = Bt.part_count + (size_t)f * NB;
-    // histogram and range reservation in one: a global atomic per non-empty part.  Four parts per thread at a time, all
-    // four atomics in flight before the first result is needed (as a plain loop every atomic waited for the one before)
-    for (int b0 = 0; b0 < NB; b0 += 4 * kBlock) {
-        unsigned c[4], base[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int b = b0 + q * kBlock + (int)threadIdx.x;
-            c[q] = b < NB ? s_cnt[b] : 0u;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int b = b0 + q * kBlock + (int)threadIdx.x;
-            base[q] = c[q] ? atomicAdd(&gcount[b], c[q]) : 0u;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int b = b0 + q * kBlock + (int)threadIdx.x;
-            if (b < NB) s_cnt[b] = base[q];
-        }
-    }
-    dropped = wave_sum_u32(dropped);
-    if (lane_id() == 0 && dropped) atomicAdd((unsigned *)&Bt.results[f].n_dropped, dropped);
-    __syncthreads();
-    probe();  // 3: ranges reserved
-    float *sorted_z = Bt.sorted_z + fd.sbase;
-    float2 *sorted_xy = Bt.sorted_xy + fd.sbase;
-    int *sorted_idx = Bt.sorted_idx + fd.sbase;
-    bool over = false;
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const unsigned code = pc[j] & 0xffffu;
-        if (code != PWPP_CODE_DROP) {
-            const unsigned seg = s_seg[code], cap = s_seg[code + 1] - seg;
-            const unsigned r = s_cnt[code] + (pc[j] >> 16);
-            if (r < cap) {
-                if (code < (unsigned)NB - 2u) {  // (a pseudo-bin -- RNR hit, out of range -- is never fitted: only its cloud indices are read again)
-                    sorted_z[seg + r] = pz[j];
-                    sorted_xy[seg + r] = make_float2(px[j], py[j]);
-                }
-                sorted_idx[seg + r] = first + j * kBlock + (int)threadIdx.x;
-            } else {
-                over = true;
-            }
-        }
-    }
-    if (__any(over) && lane_id() == 0) Bt.results[f].overflow = 1;
-    probe();  // 4: stores issued
-    if ((Bt.debug & 8) && threadIdx.x == 0) atomicMax(&Bt.dbg[8], wall_clock64());
-}
-
-// ------------------------------------------------------------------------------------------
 // K2  exclusive scan of the per-frame histogram
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
+// The body of K2 for frame f (yblock 0: the scan; 1..8: the snapshot workgroups of a stream frame).  A kernel of its own
+// (k_czm_scan, below K1') for batches; for fewer than eight frames the LAST workgroup of K1' to finish a frame runs it in place
+// (FUSED: no kernel boundary between binning and scan, 2.5-3 us of a single frame's chain).
+template <bool FUSED>
+__device__ __forceinline__ void czm_scan_frame(const PwppBatch &Bt, const int f, const int yblock) {
     __shared__ unsigned s_part[kBlock];
     // the frame's part counts and offsets stay in LDS for the second half of the kernel (reading back what other
     // threads just wrote to global memory is a round trip of its own, and a single frame waits for this chain)
     __shared__ unsigned s_pc[PWPP_NUM_PARTS(PWPP_MAX_BINS)], s_po[PWPP_NUM_PARTS(PWPP_MAX_BINS)];
-    const int f = blockIdx.x;
-    if (blockIdx.y >= 1) {
+    if (yblock >= 1) {
         // One-pass binning of stateful streams (pwpp_dev.h, snap_*): eight more workgroups per frame copy the stream's state as
         // it is before this call -- what a redo after a segment overflow starts from -- beside the scan, off its chain: one
         // history each (a single workgroup took 9.5 us for the eight 1000-entry histories, the scan takes 5.8), the first of
@@ -451,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
         static_assert(sizeof(PwppStateScalar) % 4 == 0 && sizeof(PwppPlaneState) % 4 == 0 &&
                       offsetof(PwppStateScalar, flat_len) == offsetof(PwppStateScalar, elev_len) + 16, "copied word by word; lengths read as one array");
         const unsigned *ss = reinterpret_cast<const unsigned *>(Bt.st_scalar + st), *ps = reinterpret_cast<const unsigned *>(Bt.st_plane + st);
-        const int w = (int)blockIdx.y - 1;  // this workgroup's history: elevation of ring 0-3, flatness of ring 0-3
+        const int w = yblock - 1;  // this workgroup's history: elevation of ring 0-3, flatness of ring 0-3
         if (w == 0) {
             if (threadIdx.x < sizeof(PwppStateScalar) / 4) reinterpret_cast<unsigned *>(Bt.snap_scalar + st)[threadIdx.x] = ss[threadIdx.x];
             if (threadIdx.x < sizeof(PwppPlaneState) / 4) reinterpret_cast<unsigned *>(Bt.snap_plane + st)[threadIdx.x] = ps[threadIdx.x];
@@ -478,7 +340,7 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     const int B = Bt.P.num_bins, NB = B + 2, NP = PWPP_NUM_PARTS(B);
     int probe_i = 16;  // timing probes (debug_flags & 8): slots 16.. of the probe array (tools/k5_chain.py)
     auto probe = [&]() {
-        if ((Bt.debug & 8) && blockIdx.x == 0 && threadIdx.x == 0 && probe_i < 32) Bt.dbg[probe_i++] = wall_clock64();
+        if ((Bt.debug & 8) && f == 0 && threadIdx.x == 0 && probe_i < 32) Bt.dbg[probe_i++] = wall_clock64();
     };
     probe();
     unsigned *pcnt = Bt.part_count + (size_t)f * NP;
@@ -496,7 +358,8 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
                 if (p < NP) {
                     seg[q] = Bt.cap_off[p];
                     nxt[q] = Bt.cap_off[p + 1];
-                    c[q] = pcnt[p];
+                    // (FUSED: the counts are other workgroups' device-scope atomics of THIS kernel -- read them where those were performed)
+                    c[q] = FUSED ? __hip_atomic_load(&pcnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pcnt[p];
                     mx[q] = Bt.bin_max[p];
                 }
             }
@@ -640,6 +503,179 @@ __global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) {
     }
     probe();  // 4: end
 }
+
+// ------------------------------------------------------------------------------------------
+// K1'  one-pass binning (k_czm_bin_scatter): code AND scatter in the same kernel.
+// The two-pass path streams the cloud twice (K1: 18 B/pt, K3: 34 B/pt) only because a point's
+// slot needs the frame's complete histogram.  With 288 GB of HBM the bins can have FIXED segments
+// instead: bin b of every frame owns cap_off[b+1] - cap_off[b] slots (a multiple of its expected
+// share of the largest frame, sized on the host), so the slot is  segment start + the range this
+// workgroup reserves with one global atomic per bin + the rank inside the workgroup  -- no scan
+// in between, 16 bytes read and 16 written per point.  A bin that outgrows its segment raises the
+// frame's overflow flag (points beyond the segment are not written); the host then redoes the
+// batch on the exact two-pass path, so the result never depends on the capacities.
+// ------------------------------------------------------------------------------------------
+// BLOCK threads, four points each.  The per-workgroup set-up (zeroing the counters, fetching the segment table, the
+// reservation atomics) does not depend on the tile size, so a larger workgroup halves it per point.
+template <int BLOCK, bool FUSE = false>
+__global__ __launch_bounds__(BLOCK, FUSE ? 2 : 8) void k_czm_bin_scatter(PwppBatch Bt, int tiles_per_frame) {
+    constexpr int kBlock = BLOCK;
+    constexpr int kOnePassPts = 4 * BLOCK;  // points per workgroup
+    extern __shared__ unsigned s_dyn[];  // sized at launch (binning_lds_bytes): 8 KB for the default model
+    const int NB = PWPP_NUM_PARTS(Bt.P.num_bins);
+    unsigned *s_cnt = s_dyn;             // [parts] points of this workgroup per part, then its first slot in the part
+    unsigned *s_seg = s_dyn + NB;        // [parts + 1] segment starts
+    __shared__ float4 s_zt[8];
+    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and the
+    // scattered 12-byte / 4-byte records of a bin merge into full lines only if the workgroups that write
+    // that bin share an L2.  So XCD k takes the frames k, k + 8, ..., all tiles of a frame in a row.
+    // Fewer than 8 frames (tiles_per_frame < 0): latency, not write merging, is what counts, and a frame confined to one
+    // XCD would have 32 of the 256 CUs -- its tiles are dealt over all XCDs instead.
+    const bool spread = tiles_per_frame < 0;
+    if (spread) tiles_per_frame = -tiles_per_frame;
+    const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+    if constexpr (FUSE) {  // (few frames only: spread) the workgroups behind the tiles copy the streams' state (K2's snapshot workgroups)
+        static_assert(BLOCK == kBlock, "czm_scan_frame is written for kBlock threads");
+        const int tiles = tiles_per_frame * Bt.num_frames;
+        if (lin >= tiles) {
+            czm_scan_frame<true>(Bt, (lin - tiles) / 8, 1 + (lin - tiles) % 8);
+            return;
+        }
+    }
+    const int f = spread ? lin / tiles_per_frame : xcd + 8 * (slot / tiles_per_frame);
+    if (f >= Bt.num_frames) return;
+    const PwppFrameDesc fd = Bt.frames[f];
+    const int first = ((spread ? lin : slot) % tiles_per_frame) * kOnePassPts;
+    if (first >= fd.n) {
+        if (FUSE && fd.n == 0 && first == 0) czm_scan_frame<true>(Bt, f, 0);  // an empty frame: nobody takes a ticket
+        return;
+    }
+    const PwppDevParams &P = Bt.P;
+    constexpr int kPer = kOnePassPts / kBlock;
+    unsigned pc[kPer];  // code | rank inside the workgroup << 16
+    float px[kPer], py[kPer], pz[kPer], pw[kPer];
+    int probe_i = 0;  // timing probes (debug_flags & 8): slots 0.. of the probe array, workgroup 0; slot 8 = the latest end of any workgroup
+    auto probe = [&]() {
+        if ((Bt.debug & 8) && blockIdx.x == 0 && threadIdx.x == 0 && probe_i < 8) Bt.dbg[probe_i++] = wall_clock64();
+    };
+    probe();
+    // the points first: their loads are under way while the tables are set up (the kernel is a latency chain per
+    // workgroup -- at half its occupancy it takes 1.4 x as long -- and the barrier below would otherwise stand
+    // between the table loads and these)
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = first + j * kBlock + threadIdx.x;
+        px[j] = py[j] = pz[j] = pw[j] = 0.0f;
+        if (i < fd.n) load_point(fd, i, px[j], py[j], pz[j], pw[j]);
+    }
+    for (int b = threadIdx.x; b < NB; b += kBlock) s_cnt[b] = 0;
+    for (int b0 = 0; b0 <= NB; b0 += 4 * kBlock) {  // (four table entries per thread in flight: not one L2 round trip per iteration)
+        unsigned sv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + q * kBlock + (int)threadIdx.x;
+            sv[q] = b <= NB ? Bt.cap_off[b] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + q * kBlock + (int)threadIdx.x;
+            if (b <= NB) s_seg[b] = sv[q];
+        }
+    }
+    fill_zone_table(P, s_zt);
+    __syncthreads();
+    probe();  // 1: tables in LDS
+    const double sensor_height = fd.state_in >= 0 ? Bt.st_scalar[fd.state_in].sensor_height : P.sensor_height;
+    const float rnr_z_guard = (float)(-sensor_height - 0.8) + 1e-3f;
+    const float zs = hi_split_z(P, sensor_height);
+    unsigned dropped = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = first + j * kBlock + threadIdx.x;
+        unsigned code = PWPP_CODE_DROP;
+        if (i < fd.n) {
+            const float x = px[j], y = py[j], z = pz[j], w = pw[j];
+            code = part_of(P, czm_code(P, s_zt, x, y, z, w, fd.cols >= 4, sensor_height, rnr_z_guard, (Bt.debug & 16) != 0), z, zs);
+            if (code == PWPP_CODE_DROP) ++dropped;
+            pz[j] = binned_z(z);
+        }
+        unsigned pos;
+        const unsigned old = wave_run_add(s_cnt, code, code != PWPP_CODE_DROP, pos);
+        pc[j] = code | ((old + pos) << 16);
+    }
+    __syncthreads();
+    probe();  // 2: points in, codes and ranks
+    unsigned *gcount = Bt.part_count + (size_t)f * NB;
+    // histogram and range reservation in one: a global atomic per non-empty part.  Four parts per thread at a time, all
+    // four atomics in flight before the first result is needed (as a plain loop every atomic waited for the one before)
+    for (int b0 = 0; b0 < NB; b0 += 4 * kBlock) {
+        unsigned c[4], base[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + q * kBlock + (int)threadIdx.x;
+            c[q] = b < NB ? s_cnt[b] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + q * kBlock + (int)threadIdx.x;
+            base[q] = c[q] ? atomicAdd(&gcount[b], c[q]) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + q * kBlock + (int)threadIdx.x;
+            if (b < NB) s_cnt[b] = base[q];
+        }
+    }
+    dropped = wave_sum_u32(dropped);
+    if (lane_id() == 0 && dropped) atomicAdd((unsigned *)&Bt.results[f].n_dropped, dropped);
+    __syncthreads();
+    probe();  // 3: ranges reserved
+    float *sorted_z = Bt.sorted_z + fd.sbase;
+    float2 *sorted_xy = Bt.sorted_xy + fd.sbase;
+    int *sorted_idx = Bt.sorted_idx + fd.sbase;
+    bool over = false;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const unsigned code = pc[j] & 0xffffu;
+        if (code != PWPP_CODE_DROP) {
+            const unsigned seg = s_seg[code], cap = s_seg[code + 1] - seg;
+            const unsigned r = s_cnt[code] + (pc[j] >> 16);
+            if (r < cap) {
+                if (code < (unsigned)NB - 2u) {  // (a pseudo-bin -- RNR hit, out of range -- is never fitted: only its cloud indices are read again)
+                    sorted_z[seg + r] = pz[j];
+                    sorted_xy[seg + r] = make_float2(px[j], py[j]);
+                }
+                sorted_idx[seg + r] = first + j * kBlock + (int)threadIdx.x;
+            } else {
+                over = true;
+            }
+        }
+    }
+    if (__any(over) && lane_id() == 0) atomicOr((unsigned *)&Bt.results[f].overflow, 1u);
+    probe();  // 4: stores issued
+    if ((Bt.debug & 8) && threadIdx.x == 0) atomicMax(&Bt.dbg[8], wall_clock64());
+    if constexpr (FUSE) {
+        // K2 in place: every workgroup takes a ticket (bits 8.. of the frame's overflow word, zero when the kernel starts); the one
+        // that takes the frame's last runs the scan.  Its inputs are the part counts -- device-scope atomics whose results this
+        // workgroup's threads have all waited for (they needed the reserved ranges) before the barrier above, so they were
+        // performed before the ticket is taken; the scan reads them with device-scope loads.  What the scan writes is read by
+        // the NEXT kernel.
+        __shared__ int s_last;
+        if (threadIdx.x == 0) {
+            const unsigned tiles = (unsigned)((fd.n + kOnePassPts - 1) / kOnePassPts);
+            const unsigned old = atomicAdd((unsigned *)&Bt.results[f].overflow, 256u);
+            s_last = (old >> 8) + 1u == tiles;
+            if (s_last) atomicAnd((unsigned *)&Bt.results[f].overflow, 255u);
+        }
+        __syncthreads();
+        if (s_last) czm_scan_frame<true>(Bt, f, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2 as a kernel of its own (batches; the two-pass path)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_czm_scan(PwppBatch Bt) { czm_scan_frame<false>(Bt, blockIdx.x, blockIdx.y); }
 
 // ------------------------------------------------------------------------------------------
 // K3  scatter into bin order
@@ -2416,6 +2452,13 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
             const bool spread = F < 8;  // (see the kernel: a few frames are dealt over all XCDs)
             const dim3 grid(gx1 * (unsigned)(spread ? F : (F + 7) / 8 * 8));
             const int tpf = spread ? -(int)gx1 : (int)gx1;
+            const bool fused = spread && gx1 > 0 && bb == kBlock && !(B.debug & 128);  // K2 inside K1' (debug 128: as two kernels)
+            if (fused) {
+                const dim3 fgrid(gx1 * (unsigned)F + (B.snap_scalar ? 8u * (unsigned)F : 0u));
+                hipLaunchKernelGGL((k_czm_bin_scatter<kBlock, true>), fgrid, dim3(kBlock), binning_lds_bytes(B, 2), stream, B, tpf);
+                if (ev) (void)hipEventRecord(ev[1], stream);
+                if (ev) (void)hipEventRecord(ev[2], stream);
+            } else {
             if (gx1 > 0) {
                 if (bb == 128) hipLaunchKernelGGL(k_czm_bin_scatter<128>, grid, dim3(128), binning_lds_bytes(B, 2), stream, B, tpf);
                 else if (bb == 256) hipLaunchKernelGGL(k_czm_bin_scatter<256>, grid, dim3(256), binning_lds_bytes(B, 2), stream, B, tpf);
@@ -2425,6 +2468,7 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
             if (ev) (void)hipEventRecord(ev[1], stream);
             hipLaunchKernelGGL(k_czm_scan, dim3(F, B.snap_scalar ? 9 : 1), dim3(kBlock), 0, stream, B);  // (+ eight snapshot workgroups per frame)
             if (ev) (void)hipEventRecord(ev[2], stream);
+            }
         } else {
             if (gx > 0) hipLaunchKernelGGL(k_czm_bin, dim3(gx, F), dim3(kBlock), binning_lds_bytes(B, 1), stream, B);
             if (ev) (void)hipEventRecord(ev[1], stream);
