@@ -507,7 +507,7 @@ def streams_workload(args, pwpp_hip, pwpp_dist, torch, dev, gpu_index, backend, 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1024, help="frames per batch per GPU")
     ap.add_argument("--workload", default="kitti", choices=["kitti", "dense", "streams"],
