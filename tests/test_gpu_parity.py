@@ -1114,10 +1114,58 @@ def test_error_reporting_on_the_device(kitti):
             setattr(p, k, v)
         with pytest.raises(pwpp_hip.PwppError):
             pwpp_hip.Handle(p)
+    with pytest.raises(pwpp_hip.PwppError, match="share one probe array"):   # (the two sets of timing probes)
+        h.set_option("debug_flags", 4 | 8)
+    with pytest.raises(pwpp_hip.PwppError, match="cu_split"):
+        h.set_option("cu_split", "300")
     h.estimate_ground(kitti[0])   # still usable
     assert h.counts(0)[0] + h.counts(0)[1] == kitti[0].shape[0]
     with pytest.raises(pwpp_hip.PwppError, match="out of range"):
         h.ground_indices(3)
+
+
+def test_schedules_and_binning_variants_give_one_result(kitti, oracle):
+    """The same 136-frame batch through every schedule the library has -- one stream, the in-handle overlap schedule, that schedule
+    on CU-partitioned streams (option cu_split, round 5's experiment), four frame ranges, the scan as a kernel of its own for a
+    single frame (debug 128; by default K2 runs inside K1' for fewer than eight frames) -- and two handles with a batch each in
+    flight: identical counts everywhere, spot frames identical to the oracle."""
+    refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(k) for k in kitti]
+    F = 136
+    frames = [kitti[i % 6] for i in range(F)]
+    h = pwpp_hip.Handle()
+    h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+    want = h.all_counts().copy()
+    for i in (0, 67, 135):
+        assert_frame_equal(h, i, refs[i % 6], frames[i].shape[0], check_state=False)
+    for setup in (lambda: h.set_overlap(False), lambda: h.set_overlap(True), lambda: h.set_option("cu_split", "96:0"), lambda: h.set_option("cu_split", "64:1"),
+                  lambda: (h.set_option("cu_split", "0"), h.set_option("overlap_ranges", 4))):
+        setup()
+        h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+        assert np.array_equal(h.all_counts(), want)
+        assert_frame_equal(h, 101, refs[101 % 6], frames[101].shape[0], check_state=False)
+    h2 = pwpp_hip.Handle()
+    for hh in (h, h2):
+        hh.set_overlap(False)
+    import torch
+    dev = torch.device("cuda", 0)
+    bufs = [torch.from_numpy(f).to(dev) for f in kitti]
+    ptrs, ns = [bufs[i % 6].data_ptr() for i in range(F)], [kitti[i % 6].shape[0] for i in range(F)]
+    b1, b2 = h.make_device_batch(ptrs, ns), h2.make_device_batch(ptrs, ns)
+    for k in range(6):  # two batches in flight, as bench.py's timed region
+        hh, bb = (h, b1) if k % 2 == 0 else (h2, b2)
+        if k >= 2:
+            hh.synchronize()
+        hh.launch_device_batch(bb, cols=4, mode=pwpp_hip.MODE_FRESH)
+    for hh in (h, h2):
+        hh.synchronize()
+        assert np.array_equal(hh.all_counts(), want)
+        assert_frame_equal(hh, 29, refs[29 % 6], frames[29].shape[0], check_state=False)
+    one = pwpp_hip.Handle()
+    for flags in (0, 128, 0):
+        one.set_option("debug_flags", flags)
+        for k in (2, 5):
+            one.estimate_ground_batch([kitti[k]], mode=pwpp_hip.MODE_FRESH)
+            assert_frame_equal(one, 0, refs[k], kitti[k].shape[0])
 
 
 def test_cpp_class_with_eigen_types(kitti, golden, tmp_path):
