@@ -2452,7 +2452,7 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
             const bool spread = F < 8;  // (see the kernel: a few frames are dealt over all XCDs)
             const dim3 grid(gx1 * (unsigned)(spread ? F : (F + 7) / 8 * 8));
             const int tpf = spread ? -(int)gx1 : (int)gx1;
-            const bool fused = spread && gx1 > 0 && bb == kBlock && !(B.debug & 128);  // K2 inside K1' (debug 128: as two kernels)
+            const bool fused = spread && gx1 > 0 && bb == kBlock && !(B.debug & 256);  // K2 inside K1' (debug 256: as two kernels; 128 is taken by K5's statistics)
             if (fused) {
                 const dim3 fgrid(gx1 * (unsigned)F + (B.snap_scalar ? 8u * (unsigned)F : 0u));
                 hipLaunchKernelGGL((k_czm_bin_scatter<kBlock, true>), fgrid, dim3(kBlock), binning_lds_bytes(B, 2), stream, B, tpf);

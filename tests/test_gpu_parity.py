@@ -1127,7 +1127,7 @@ def test_error_reporting_on_the_device(kitti):
 def test_schedules_and_binning_variants_give_one_result(kitti, oracle):
     """The same 136-frame batch through every schedule the library has -- one stream, the in-handle overlap schedule, that schedule
     on CU-partitioned streams (option cu_split, round 5's experiment), four frame ranges, the scan as a kernel of its own for a
-    single frame (debug 128; by default K2 runs inside K1' for fewer than eight frames) -- and two handles with a batch each in
+    single frame (debug 256; by default K2 runs inside K1' for fewer than eight frames) -- and two handles with a batch each in
     flight: identical counts everywhere, spot frames identical to the oracle."""
     refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(k) for k in kitti]
     F = 136
@@ -1161,7 +1161,7 @@ def test_schedules_and_binning_variants_give_one_result(kitti, oracle):
         assert np.array_equal(hh.all_counts(), want)
         assert_frame_equal(hh, 29, refs[29 % 6], frames[29].shape[0], check_state=False)
     one = pwpp_hip.Handle()
-    for flags in (0, 128, 0):
+    for flags in (0, 256, 0):
         one.set_option("debug_flags", flags)
         for k in (2, 5):
             one.estimate_ground_batch([kitti[k]], mode=pwpp_hip.MODE_FRESH)

@@ -7,7 +7,7 @@ import numpy as np, torch
 torch.cuda.init()
 import conftest, pwpp_hip
 src = [torch.from_numpy(conftest.load_kitti(k)).cuda() for k in range(6)]
-for flags in (0, 128, 0, 128):
+for flags in (0, 256, 0, 256):
     row = []
     for k in range(6):
         h = pwpp_hip.Handle()
