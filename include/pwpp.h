@@ -344,6 +344,8 @@ PWPP_API int pwpp_get_redo_stats(pwpp_handle *h, int64_t *frames_one_pass, int64
  *   "debug_flags"         4: timing probes of the fit chain; 8: timing probes of the binning, scan and GLE kernels;
  *                         16: exact binning arithmetic only;
  *                         128: the first pass of the history statistics always as the reference's sequential sum (no exact shortcut);
+ *                         256: fewer than eight frames: the scan as a kernel of its own (by default the last workgroup of the
+ *                         binning kernel to finish a frame runs it in place);
  *                         64: before a call that skips the clearing kernel (the last call's K5 zeroed this call's counters),
  *                         read the counters back and fail with PWPP_E_STATE unless every word is zero;
  *                         16384 / 32768: force the fall-back paths of the lowest-point selection
