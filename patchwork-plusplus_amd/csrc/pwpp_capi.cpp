@@ -490,7 +490,7 @@ int refresh_emit_long(pwpp_handle *h) {
     std::vector<uint8_t> flag((size_t)NB, 0);
     std::vector<uint16_t> list;
     uint32_t biggest = 0;
-    for (int b = 0; b < NB && h->observed.size() == (size_t)PWPP_NUM_PARTS(B); ++b) {
+    for (int b = 0; b < NB && h->observed.size() == (size_t)PWPP_NUM_PARTS(B) && !(h->debug_flags & 1024); ++b) {  // (debug 1024: no long-list table)
         const uint32_t c = b < B ? h->observed[2 * (size_t)b] + h->observed[2 * (size_t)b + 1] : h->observed[(size_t)B + b];  // (pseudo-bin s = part B + s)
         if (c > PWPP_EMIT_LONG_MIN) {
             flag[(size_t)b] = 1;

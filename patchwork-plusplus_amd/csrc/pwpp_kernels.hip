@@ -1818,7 +1818,10 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, unsigned l
     const int B = P.num_bins, NB = B + 2;
     // A pseudo-bin is one part -- its own count / offset stand in -- and has no patch record: that of bin 0 is read and ignored.
     const unsigned n = Bt.bin_count[(size_t)f * NB + seg];
-    if (!EAGER && n <= first_block * 512u) return;  // (empty bin; or an extra wave of a list the main wave copies whole)
+    // (empty bin; or an extra wave of a list the main wave copies whole.  A bin of two parts is copied in blocks of 512 slots PER PART,
+    // so it can have one block more than n / 512 says -- a 700 + 3300-point bin is nine blocks: the test leaves a block of slack and
+    // the loops below decide exactly.  Found by tools/distinct_parity.py: such bins lost the entries of their last block.)
+    if (!EAGER && (n == 0u || (first_block > 0u && n + 512u <= first_block * 512u))) return;
     const PwppFrameDesc fd = Bt.frames[f];
     const unsigned off = Bt.bin_off[(size_t)f * NB + seg];
     const unsigned da = Bt.dst_a[(size_t)f * NB + seg];
