@@ -141,6 +141,8 @@ def one_case(seed, oracle):
     h.set_output_order(ordered)
     fortran = rng.random() < 0.2   # column-major matrices (Eigen's storage)
     mode = rng.random()
+    if os.environ.get("FUZZ_BIG"):  # only the big-batch mode
+        mode = 0.99
     global LAST
     LAST = "plan '%s' one_pass_min_frames=1: %s ordered %s fortran %s mode %.2f" % (plan, opm, ordered, fortran, mode)
 
@@ -153,6 +155,19 @@ def one_case(seed, oracle):
 
     def lay(c):
         return np.asfortranarray(c) if fortran else c
+    if mode >= 0.94:  # (round 5) a BIG fresh batch: the kernels only batches above 64 / 128 frames run (list kernel with one wave per
+        # bin and its long-list launch, K5's throughput variant, the XCD-dealt binning, the overlap schedule), on a few distinct clouds replayed
+        distinct = [random_cloud(rng, p.sensor_height) for _ in range(int(rng.integers(2, 6)))]
+        if len({f.shape[1] for f in distinct}) > 1:
+            distinct = [np.ascontiguousarray(f[:, :3]) for f in distinct]
+        refs = [ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(f) for f in distinct]
+        nfr = int(rng.choice([65, 72, 100, 129, 136, 160]))
+        pick = [int(rng.integers(0, len(distinct))) for _ in range(nfr)]
+        for rep in range(2):  # (the second call knows the bins with long lists)
+            h.estimate_ground_batch([lay(distinct[k]) for k in pick], mode=pwpp_hip.MODE_FRESH)
+            for i in sorted(set(int(x) for x in rng.integers(0, nfr, 24)) | {0, nfr - 1}):
+                check(i, refs[pick[i]], distinct[pick[i]], check_state=False)
+        return "big batch of %d" % nfr
     if mode < 0.45:  # a fresh batch
         frames = [random_cloud(rng, p.sensor_height) for _ in range(int(rng.integers(1, 7)))]
         if len({f.shape[1] for f in frames}) > 1:
@@ -161,7 +176,7 @@ def one_case(seed, oracle):
         for i, pts in enumerate(frames):
             check(i, ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(pts), pts)
         return "batch of %d" % len(frames)
-    if mode < 0.8:  # one stateful stream, frame after frame
+    if mode < 0.78:  # one stateful stream, frame after frame
         est = ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP)
         n = int(rng.integers(2, 6))
         for _ in range(n):
