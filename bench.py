@@ -591,22 +591,18 @@ def main():
         h.launch_device_batch(batch, cols=4, mode=pwpp_hip.MODE_FRESH)
         h.synchronize()
 
+    held = {}  # which of the D batches each pipe handle processed last
+
     def run_steps(n):
         """n steps with up to D batches in flight; returns with every batch landed."""
         if D == 1:
             for _ in range(n):
                 step()
             return
-        for hh in H:
-            hh.set_overlap(False)
         for k in range(n):
-            d = k % D
-            if k >= D:
-                H[d].synchronize()
-            H[d].launch_device_batch(batches[d], cols=4, mode=pwpp_hip.MODE_FRESH)
-        for hh in H:
-            hh.synchronize()
-        h.set_overlap(not args.no_overlap)
+            holder = pipe.submit_device_batch(batches[k % D], cols=4)  # (waits for the batch this handle launched D submits ago)
+            held[holder._h.value] = k % D
+        pipe.drain()
 
     step()  # (one step for the checks below; the W warm-up steps run right in front of the timed region, after the host-side checks)
     # self-check: replays of the same source frame must produce identical counts, and
@@ -626,8 +622,8 @@ def main():
     # nothing to overlap with) then runs under the ramp-down of the one before (last fits, index lists): 2.46 against 2.63 ms per
     # batch for the synchronous step with the in-handle overlap schedule (profiles/r05_pipelined_batches.txt).  Each handle runs
     # the plain single-stream schedule (the in-handle overlap schedule on top is slower: 2.83 ms).  D = 1: rounds 1-4's step.
-    D = max(1, args.in_flight) if F >= 128 and not args.no_overlap else 1
-    H, batches, inputs = [h], [batch], [big]
+    D = max(1, min(4, args.in_flight)) if F >= 128 and not args.no_overlap else 1
+    batches, inputs = [batch], [big]
     for d in range(1, D):
         which_d = pwpp_dist.shard_sources(len(src), F, rank + d)  # (the same frames in another rotation: other buffers, other addresses)
         ns_d = [src[j].shape[0] for j in which_d]
@@ -635,16 +631,12 @@ def main():
         big_d = torch.empty((int(offs_d[-1]), 4), dtype=torch.float32, device=dev)
         for i in range(F):
             big_d[offs_d[i]:offs_d[i + 1]].copy_(src_dev[which_d[i]])
-        hd = pwpp_hip.Handle(params, device=gpu_index)
-        H.append(hd)
         inputs.append(big_d)
-        batches.append(hd.make_device_batch([big_d.data_ptr() + int(offs_d[i]) * 16 for i in range(F)], ns_d))
+        batches.append(h.make_device_batch([big_d.data_ptr() + int(offs_d[i]) * 16 for i in range(F)], ns_d))
+    # the library's own pipe (pwpp_pipe_*: D handles, single-stream schedule each); H = [the first handle of the legs, the pipe's handles]
+    pipe = pwpp_hip.Pipe(params, device=gpu_index, depth=D) if D > 1 else None
+    H = [h] + ([pipe.handle(i) for i in range(D)] if pipe else [])
     torch.cuda.synchronize()
-    # (The other handles are created only now, AFTER the first handle's first step: its overlap schedule has created its third
-    # stream by then.  The HIP runtime multiplexes streams onto four hardware queues in creation order; with the second handle's two
-    # streams created first, the first handle's fit stream shared a hardware queue with its own memory stream and the synchronous
-    # step read 3.18 instead of 2.6 ms -- tools/sync_after_pipelined.py.)
-
     selfcheck = not os.environ.get("PWPP_BENCH_NO_SELFCHECK")
     # oracle anchor (outside the timed region): the ground masks and plane normals of batch frames 0-5 and
     # of one frame of the second frame range against the committed goldens, which tests/golden/make_golden.py generated
@@ -684,8 +676,10 @@ def main():
     my_elapsed = elapsed
     elapsed, total_frames = pwpp_dist.aggregate(elapsed, F * args.steps, dev if backend == "nccl" else None)  # MAX time, SUM frames over ranks
     if D > 1:  # every handle's last batch is complete and equal to the first handle's first one, frame for frame of the same source
-        for d in range(1, D):
-            cd, wd = H[d].all_counts(), pwpp_dist.shard_sources(len(src), F, rank + d)
+        for d in range(D):
+            if H[1 + d]._h.value not in held:
+                continue
+            cd, wd = H[1 + d].all_counts(), pwpp_dist.shard_sources(len(src), F, rank + held[H[1 + d]._h.value])
             first_of = {}
             for i in range(F):
                 first_of.setdefault(which[i], i)
@@ -803,8 +797,8 @@ def main():
                        "frames_per_gpu": F, "points_per_frame": int(np.mean(ns)), "parallelism": "frames sharded, dp%d" % world,
                        "batches_in_flight": D,
                        "schedule": ("one stream" if args.no_overlap or F < 128 else
-                                    ("%d batches in flight (one handle, workspace and stream each; every step = one whole batch of %d frames; a handle's results stay "
-                                     "readable until its next launch); each handle: one stream" % (D, F) if D > 1 else
+                                    ("%d batches in flight through the library's pipe (pwpp_pipe_*: one handle, workspace and stream per batch in flight; every step = one "
+                                     "whole batch of %d frames; a handle's results stay readable until its next launch); each handle: one stream" % (D, F) if D > 1 else
                                      "library default: two frame ranges, binning and lists on the main stream, each range's plane fits on its own"))
                                    + "; kernel_ms / roofline.kernel_ms: separate single-stream pass of %d steps outside the timed region" % args.profile_steps},
             "binning": {"one_pass_batches": h.one_pass_stats()[0], "redone_two_pass": h.one_pass_stats()[1],

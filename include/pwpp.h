@@ -316,6 +316,26 @@ PWPP_API int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *
 PWPP_API int pwpp_get_redo_stats(pwpp_handle *h, int64_t *frames_one_pass, int64_t *frames_redone);
 
 
+/* ---- batches in flight (no reference counterpart; round 5) --------------------------------------------------------------------
+ * A pipe keeps `depth` batches of independent frames enqueued: it owns `depth` handles (each with its own workspace and HIP streams,
+ * each on the single-stream schedule) and deals the submitted batches to them in turn.  pwpp_pipe_submit waits for the batch the
+ * next handle launched `depth` submits ago (its results are complete then, and are replaced by the new batch), launches the new one
+ * and returns that handle: the caller reads the results through the usual getters after pwpp_synchronize(handle), any time before
+ * the handle comes round again.  The ramp-up of one batch (binning, nothing to overlap with) then runs under the ramp-down of
+ * the one before (last plane fits, index lists): 2.32-2.46 instead of 2.49-2.63 ms per 1024-frame batch with depth 2
+ * (profiles/r05_pipelined_batches.txt; depth 3: +0.5 %).  Fresh state per frame only (PWPP_MODE_FRESH: a stream's frames must
+ * stay in order on ONE handle); `mem` as in pwpp_estimate_ground_batch (PWPP_MEM_DEVICE or PWPP_MEM_HOST_PINNED to stay
+ * asynchronous).  depth 1..4. */
+typedef struct pwpp_pipe pwpp_pipe;
+PWPP_API int pwpp_pipe_create(const pwpp_params *p, int device, int depth, pwpp_pipe **out);
+PWPP_API int pwpp_pipe_submit(pwpp_pipe *pipe, const float *const *points, const int32_t *n, int frames, int cols, int layout, int mem,
+                              pwpp_handle **holder);
+/* waits for every batch in flight */
+PWPP_API int pwpp_pipe_drain(pwpp_pipe *pipe);
+/* the pipe's handles (options, statistics, getters): index 0 .. depth - 1; NULL beyond */
+PWPP_API pwpp_handle *pwpp_pipe_handle(pwpp_pipe *pipe, int index);
+PWPP_API int pwpp_pipe_destroy(pwpp_pipe *pipe);
+
 /* Tuning and test switches (no reference counterpart).  The environment variables PWPP_DEBUG_FLAGS,
  * PWPP_FIT_PLAN, PWPP_FIT_CONCURRENT, PWPP_NO_ONE_PASS, PWPP_ONE_PASS_MIN_FRAMES, PWPP_ONE_PASS_SCALE,
  * PWPP_OVERLAP, PWPP_OVERLAP_MODE, PWPP_OVERLAP_RANGES, PWPP_FIT_STREAMS, PWPP_BIN_BLOCK, PWPP_HI_SPLIT and

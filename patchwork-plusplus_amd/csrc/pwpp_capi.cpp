@@ -14,6 +14,7 @@
 #include <cstring>
 #include <atomic>
 #include <string>
+#include <new>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -1969,6 +1970,67 @@ int pwpp_debug_read(pwpp_handle *h, unsigned long long *out64) {
     if (!h->d_dbg.p) return fail(PWPP_E_STATE, "no probes");
     HIPCHK(hipMemcpy(out64, h->d_dbg.p, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PWPP_OK;
+}
+
+
+/* ---- batches in flight (include/pwpp.h) ---- */
+struct pwpp_pipe {
+    std::vector<pwpp_handle *> handles;
+    unsigned long long submits = 0;
+};
+
+int pwpp_pipe_create(const pwpp_params *p, int device, int depth, pwpp_pipe **out) {
+    if (!p || !out) return fail(PWPP_E_ARG, "null argument");
+    if (depth < 1 || depth > 4) return fail(PWPP_E_ARG, "depth %d: 1..4 expected", depth);
+    pwpp_pipe *pipe = new (std::nothrow) pwpp_pipe;
+    if (!pipe) return fail(PWPP_E_NOMEM, "out of host memory");
+    for (int k = 0; k < depth; ++k) {
+        pwpp_handle *h = nullptr;
+        const int rc = pwpp_create(p, device, &h);
+        if (rc) {
+            (void)pwpp_pipe_destroy(pipe);
+            return rc;
+        }
+        if (depth > 1) h->overlap = false;  // (the in-handle overlap schedule on top of batches in flight is slower: 2.83 against 2.46 ms)
+        pipe->handles.push_back(h);
+    }
+    *out = pipe;
+    return PWPP_OK;
+}
+
+int pwpp_pipe_submit(pwpp_pipe *pipe, const float *const *points, const int32_t *n, int frames, int cols, int layout, int mem, pwpp_handle **holder) {
+    if (!pipe || pipe->handles.empty()) return fail(PWPP_E_ARG, "null pipe");
+    pwpp_handle *h = pipe->handles[(size_t)(pipe->submits % pipe->handles.size())];
+    // (pwpp_estimate_ground_batch first waits for this handle's own batch in flight: the one submitted `depth` submits ago)
+    const int rc = pwpp_estimate_ground_batch(h, points, n, frames, cols, layout, mem, PWPP_MODE_FRESH);
+    if (rc) return rc;
+    ++pipe->submits;
+    if (holder) *holder = h;
+    return PWPP_OK;
+}
+
+int pwpp_pipe_drain(pwpp_pipe *pipe) {
+    if (!pipe) return fail(PWPP_E_ARG, "null pipe");
+    for (pwpp_handle *h : pipe->handles) {
+        const int rc = pwpp_synchronize(h);
+        if (rc) return rc;
+    }
+    return PWPP_OK;
+}
+
+pwpp_handle *pwpp_pipe_handle(pwpp_pipe *pipe, int index) {
+    return pipe && index >= 0 && (size_t)index < pipe->handles.size() ? pipe->handles[(size_t)index] : nullptr;
+}
+
+int pwpp_pipe_destroy(pwpp_pipe *pipe) {
+    if (!pipe) return PWPP_OK;
+    int rc = PWPP_OK;
+    for (pwpp_handle *h : pipe->handles) {
+        const int r = pwpp_destroy(h);
+        rc = rc ? rc : r;
+    }
+    delete pipe;
+    return rc;
 }
 
 }  // extern "C"

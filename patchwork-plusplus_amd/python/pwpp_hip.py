@@ -115,6 +115,12 @@ def load():
         L.pwpp_get_workspace_bytes.restype = ctypes.c_int64
         L.pwpp_get_one_pass_stats.argtypes = [vp, vp, vp]
         L.pwpp_get_redo_stats.argtypes = [vp, vp, vp]
+        L.pwpp_pipe_create.argtypes = [vp, ci, ci, ctypes.POINTER(vp)]
+        L.pwpp_pipe_submit.argtypes = [vp, vp, vp, ci, ci, ci, ci, ctypes.POINTER(vp)]
+        L.pwpp_pipe_drain.argtypes = [vp]
+        L.pwpp_pipe_handle.argtypes = [vp, ci]
+        L.pwpp_pipe_handle.restype = vp
+        L.pwpp_pipe_destroy.argtypes = [vp]
         L.pwpp_set_output_order.argtypes = [vp, ci]
         L.pwpp_set_overlap.argtypes = [vp, ci]
         L.pwpp_kernel_name.argtypes = [ci]
@@ -173,7 +179,8 @@ class Handle:
 
     def close(self):
         if self._h:
-            self._L.pwpp_destroy(self._h)
+            if not getattr(self, "_borrowed", False):  # (a view of a Pipe's handle: the pipe destroys it)
+                self._L.pwpp_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -427,3 +434,61 @@ class Handle:
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)
         self._check(self._L.pwpp_get_one_pass_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
         return int(a.value), int(b.value)
+
+
+class Pipe:
+    """Batches of independent frames in flight (pwpp_pipe_*): `depth` handles, each batch goes to the next one in turn.
+    submit_device_batch returns a Handle VIEW of the handle that holds the batch: synchronize() it, then read the results with
+    the usual getters -- before that handle comes round again, `depth` submits later."""
+
+    def __init__(self, params=None, device=0, depth=2):
+        self._L = load()
+        self.params = params if params is not None else default_params()
+        p = ctypes.c_void_p()
+        self._p = None
+        rc = self._L.pwpp_pipe_create(ctypes.byref(self.params), device, depth, ctypes.byref(p))
+        if rc < 0:
+            raise PwppError("pwpp error %d: %s" % (rc, self._L.pwpp_last_error().decode()))
+        self._p = p
+        self.depth = depth
+        self._views = {}
+
+    def _view(self, raw):
+        key = raw.value if hasattr(raw, "value") else int(raw)
+        if key not in self._views:
+            v = Handle.__new__(Handle)  # a view: the pipe owns the handle
+            v._L, v.params, v._h, v._keep, v._borrowed = self._L, self.params, ctypes.c_void_p(key), None, True
+            self._views[key] = v
+        return self._views[key]
+
+    def handle(self, index):
+        raw = self._L.pwpp_pipe_handle(self._p, index)
+        return self._view(ctypes.c_void_p(raw)) if raw else None
+
+    def submit_device_batch(self, batch, cols=4, layout=LAYOUT_ROW_MAJOR):
+        cp, cn, k = batch
+        holder = ctypes.c_void_p()
+        rc = self._L.pwpp_pipe_submit(self._p, cp, cn, k, cols, layout, MEM_DEVICE, ctypes.byref(holder))
+        if rc < 0:
+            raise PwppError("pwpp error %d: %s" % (rc, self._L.pwpp_last_error().decode()))
+        return self._view(holder)
+
+    def drain(self):
+        rc = self._L.pwpp_pipe_drain(self._p)
+        if rc < 0:
+            raise PwppError("pwpp error %d: %s" % (rc, self._L.pwpp_last_error().decode()))
+
+    def workspace_bytes(self):
+        return sum(self.handle(i).workspace_bytes() for i in range(self.depth))
+
+    def close(self):
+        if self._p is not None:
+            self._L.pwpp_pipe_destroy(self._p)
+            self._p = None
+            self._views = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1160,6 +1160,22 @@ def test_schedules_and_binning_variants_give_one_result(kitti, oracle):
         hh.synchronize()
         assert np.array_equal(hh.all_counts(), want)
         assert_frame_equal(hh, 29, refs[29 % 6], frames[29].shape[0], check_state=False)
+    # ... and the library's own pipe (pwpp_pipe_*): two batches in flight, two different batches alternating; the handle a submit
+    # returns holds that batch's results until it comes round again
+    frames_b = [kitti[(i + 3) % 6] for i in range(F)]
+    bufs_b = [bufs[(i + 3) % 6] for i in range(F)]
+    pipe = pwpp_hip.Pipe(depth=2)
+    ba = pipe.handle(0).make_device_batch(ptrs, ns)
+    bb = pipe.handle(0).make_device_batch([t.data_ptr() for t in bufs_b], [f.shape[0] for f in frames_b])
+    holders = [pipe.submit_device_batch(ba if k % 2 == 0 else bb) for k in range(5)]
+    assert holders[0]._h.value == holders[2]._h.value == holders[4]._h.value != holders[1]._h.value == holders[3]._h.value
+    pipe.drain()
+    assert np.array_equal(holders[4].all_counts(), want)                      # batch a
+    assert_frame_equal(holders[4], 77, refs[77 % 6], frames[77].shape[0], check_state=False)
+    assert_frame_equal(holders[3], 77, refs[(77 + 3) % 6], frames_b[77].shape[0], check_state=False)  # batch b
+    with pytest.raises(pwpp_hip.PwppError, match="depth"):
+        pwpp_hip.Pipe(depth=9)
+    pipe.close()
     one = pwpp_hip.Handle()
     for flags in (0, 256, 0):
         one.set_option("debug_flags", flags)
