@@ -59,7 +59,35 @@ int main(int argc, char **argv) {
     printf("points %d ground %d nonground %d patches %d height %.6f time_us %.1f\n", n, (int)n_ground, (int)n_nonground,
            (int)n_patches, pwpp_get_height(h), pwpp_get_time_us(h));
     free(ground);
-    free(pts);
     pwpp_destroy(h);
+
+    /* Batches in flight (pwpp_pipe_*, no reference counterpart): four batches of three independent frames through a pipe of depth 2.
+     * From pageable host memory a submit returns with the batch done (PWPP_MEM_HOST); device or pinned buffers make it asynchronous
+     * and the two handles overlap.  The handle a submit returns holds that batch until it comes round again. */
+    {
+        pwpp_pipe *pipe = NULL;
+        const float *frames[3];
+        int32_t ns[3];
+        int k, same = 1;
+        frames[0] = frames[1] = frames[2] = pts;
+        ns[0] = ns[1] = ns[2] = n;
+        if (pwpp_pipe_create(&params, 0, 2, &pipe) != PWPP_OK) return fail("pwpp_pipe_create");
+        for (k = 0; k < 4; ++k) {
+            pwpp_handle *holder = NULL;
+            int32_t g = 0, ng = 0, np = 0;
+            int fr;
+            if (pwpp_pipe_submit(pipe, frames, ns, 3, 4, PWPP_LAYOUT_ROW_MAJOR, PWPP_MEM_HOST, &holder) != PWPP_OK) return fail("pwpp_pipe_submit");
+            if (pwpp_synchronize(holder) != PWPP_OK) return fail("pwpp_synchronize");
+            if (holder != pwpp_pipe_handle(pipe, k % 2)) same = 0;
+            for (fr = 0; fr < 3; ++fr) {
+                if (pwpp_get_counts(holder, fr, &g, &ng, &np) != PWPP_OK) return fail("pwpp_get_counts");
+                if (g != n_ground || ng != n_nonground || np != n_patches) same = 0;
+            }
+        }
+        if (pwpp_pipe_drain(pipe) != PWPP_OK) return fail("pwpp_pipe_drain");
+        printf("pipe depth 2: 4 batches of 3 frames, every frame %s the single call\n", same ? "equal to" : "DIFFERENT FROM");
+        pwpp_pipe_destroy(pipe);
+    }
+    free(pts);
     return 0;
 }

@@ -576,6 +576,7 @@ def test_c_abi_demo_program(kitti, golden, tmp_path):
     assert int(m.group(1)) == kitti[0].shape[0]
     assert [int(m.group(2)), int(m.group(3)), int(m.group(4))] == list(golden["f32/seq/0/counts"])
     assert abs(float(m.group(5)) - golden["f32/seq/0/state"][0]) < 1e-4
+    assert "pipe depth 2: 4 batches of 3 frames, every frame equal to the single call" in out  # (pwpp_pipe_* from C)
 
 
 def test_one_pass_binning_and_its_overflow_fallback(kitti, oracle):
