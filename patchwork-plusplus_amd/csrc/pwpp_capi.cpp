@@ -152,6 +152,7 @@ struct pwpp_handle {
     int one_pass_holdoff = 0;        // batches to run on the two-pass path after an overflow
     int64_t slots_per_frame = 0;     // of the current capacity table
     int cap_max_n = -1;              // largest frame the capacity table on the device was built for
+    bool cap_few = false;            // ... and whether it was built with the head-room of calls of a few frames
     int max_n = 0;
     int64_t total_points = 0;
     int cols = 4, layout = 0;
@@ -413,13 +414,18 @@ int grow_stream_histories(pwpp_handle *h, int new_cap) {
 int build_capacity_table(pwpp_handle *h, int max_n) {
     const PwppDevParams &P = h->dp;
     const int NB = PWPP_NUM_PARTS(P.num_bins);  // one segment per part
-    const double scale = 1.5 * h->one_pass_scale / 4.0;
+    // A FEW frames per call (a single sensor's stream, the reference's own use): memory is no concern there (2 048 slots more per part
+    // are 40 MB per frame), but every overflow is a frame binned twice, and a handle that has seen a handful of frames knows little
+    // about its bins -- 2.5 x the head-room (round 5: 43 of 180 frames of six varied streams were redone with the batch table).
+    const bool few = h->frames <= 16 && h->one_pass_scale >= 1.0;
+    h->cap_few = few;
+    const double scale = (few ? 3.75 : 1.5) * h->one_pass_scale / 4.0;
     std::vector<uint32_t> off((size_t)NB + 1);
     h->cap_table.assign((size_t)NB, 0u);
     uint64_t run = 0;
     for (int b = 0; b < NB; ++b) {
         off[(size_t)b] = (uint32_t)run;
-        double cap = scale * (double)h->observed[(size_t)b] + (h->one_pass_scale >= 1.0 ? 256.0 : 16.0);
+        double cap = scale * (double)h->observed[(size_t)b] + (h->one_pass_scale >= 1.0 ? (few ? 2048.0 : 256.0) : 16.0);
         if (cap > (double)max_n + 16.0) cap = (double)max_n + 16.0;
         uint64_t c = ((uint64_t)cap + (PWPP_SLOT_ALIGN - 1)) & ~(uint64_t)(PWPP_SLOT_ALIGN - 1);
         if (b < 2 * P.num_bins && (b & 1) && b / 2 >= P.split_end) c = 0;  // the high part of a bin that is not split: never used
@@ -1364,7 +1370,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
             if ((rc = probe_histogram(h))) return rc;
             h->table_stale = true;
         }
-        if (h->table_stale || max_n > h->cap_max_n || 2 * (int64_t)max_n < h->cap_max_n)
+        if (h->table_stale || max_n > h->cap_max_n || 2 * (int64_t)max_n < h->cap_max_n || h->cap_few != (frames <= 16 && h->one_pass_scale >= 1.0))
             if ((rc = build_capacity_table(h, max_n + max_n / 8))) return rc;
         const size_t want = (size_t)frames * (size_t)h->slots_per_frame;
         size_t free_b = 0, total_b = 0;
