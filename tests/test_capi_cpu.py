@@ -83,6 +83,20 @@ def test_no_cpu_fallback(lib):
         pypatchworkpp.patchworkpp(pypatchworkpp.Parameters())
 
 
+def test_pipe_arguments_without_a_gpu(lib):
+    """pwpp_pipe_* (batches in flight): argument errors come back before anything touches a device; a valid pipe needs a GPU like
+    a handle does -- no CPU fallback behind the pipe either."""
+    with pytest.raises(pwpp_hip.PwppError, match="depth"):
+        pwpp_hip.Pipe(depth=0)
+    with pytest.raises(pwpp_hip.PwppError, match="depth"):
+        pwpp_hip.Pipe(depth=5)
+    assert lib.pwpp_pipe_handle(None, 0) is None and lib.pwpp_pipe_destroy(None) == 0
+    if not _has_gpu():
+        with pytest.raises(pwpp_hip.PwppError) as e:
+            pwpp_hip.Pipe(depth=2)
+        assert "no CPU path" in str(e.value)
+
+
 def test_pybind_module_surface():
     """Same names as the reference module (python/patchworkpp/pybinding.cpp:9-57)."""
     import pypatchworkpp as m
