@@ -36,12 +36,14 @@ typedef struct pwo_params {
 /* Arithmetic of the plane fit's sums (reference patchworkpp.cpp:56-60), the one place the
  * reference defers to Eigen:
  *   EIGEN_F32    float accumulators, rows in storage order (plainest reading of Eigen)
- *   FXP          the product's order-independent fixed-point contract;
- *                the restatement only (it needs the bin and its first LPR, which the shim cannot see)
+ *   FXP          the product's order-independent fixed-point contract: exact integer
+ *                moments on a 2^-30 m grid (contract v4); the restatement only (it needs the bin and its
+ *                first LPR, which the shim cannot see)
  *   EXACT_F64    reference-neutral arbiter: double accumulation of the unquantised floats,
  *                one rounding to float per output
- *   F32_PACKET4  float again, four partial sums (a 4-wide SIMD reduction order) */
-enum { PWO_ARITH_EIGEN_F32 = 0, PWO_ARITH_FXP = 1, PWO_ARITH_EXACT_F64 = 2, PWO_ARITH_F32_PACKET4 = 3 };
+ *   F32_PACKET4  float again, four partial sums (a 4-wide SIMD reduction order)
+ *   FXP21        rounds 3-5's contract v3: FXP on a 2^-21 m grid (restatement only; a witness, not the product) */
+enum { PWO_ARITH_EIGEN_F32 = 0, PWO_ARITH_FXP = 1, PWO_ARITH_EXACT_F64 = 2, PWO_ARITH_F32_PACKET4 = 3, PWO_ARITH_FXP21 = 4 };
 
 void pwo_default_params(pwo_params *p);                 /* patchworkpp.h:79-111 */
 int pwo_arith_supported(int arith);                     /* 1 if this build can do it */

@@ -38,7 +38,7 @@ void pwo_ext_jacobi(const float *cov9_rowmajor, float *u9_rowmajor, float *sv3);
 /* the fixed-point contract: shift, z half-range, per-bin origins (ox/oy may be NULL) */
 void pwo_ext_fxp_geometry(void *h, int *shift, double *zr, float *ox, float *oy);
 long long pwo_ext_quantise(float v, double origin, int shift);
-long long pwo_ext_quantise_z(float v, double z0, int shift);
+long long pwo_ext_quantise_z(float v, double z0, int shift, double zr);
 double pwo_ext_z_origin(double lpr);
 long pwo_ext_max_sweeps(int reset); /* largest Jacobi sweep count of one fit since the last reset (this thread) */
 

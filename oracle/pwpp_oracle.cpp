@@ -19,10 +19,14 @@
 // Arithmetic flavours for the plane fit (the only place where the reference defers to
 // Eigen); everything else follows the reference's own float/double expressions:
 //   PWO_ARITH_EIGEN_F32  float accumulators in storage order (plain reading of Eigen)
-//   PWO_ARITH_FXP        the product's contract v3: fit sets of 1-3 points in the
-//                        reference's own float arithmetic (determinate there), larger ones in
-//                        order-independent fixed point; this is the flavour the HIP kernels
-//                        must match bit for bit.
+//   PWO_ARITH_FXP        the product's contract v4: fit sets of 1-3 points in the
+//                        reference's own float arithmetic (determinate there), larger ones as EXACT integer
+//                        moments on a 2^-30 m grid -- every float of magnitude >= 2^-7 m enters the sums
+//                        unquantised, so the sums are those of exact arithmetic on the reference's own
+//                        floats, whatever the order; this is the flavour the HIP kernels must match bit for bit.
+//   PWO_ARITH_FXP21      contract v3 of rounds 3-5 (the same on a 2^-21 m grid), kept as a witness: the
+//                        grid was coarser than the float ulp of the data, which cost 0.2 % of the frames
+//                        a few indices against the reference (profiles/r05_parity_statistics_10k.json).
 //   PWO_ARITH_EXACT_F64  reference-neutral arbiter: what :56-60 give in (near-)exact
 //                        arithmetic -- double accumulation of the unquantised floats, one
 //                        rounding to float per output.  Neither the product nor the
@@ -74,33 +78,38 @@ float f_abs(float v) { return v < 0.0f ? -v : v; }
 float f_max(float a, float b) { return a < b ? b : a; }
 
 // ---------------------------------------------------------------------------------
-// The fixed-point contract of the plane-fit sums, version 2.
+// The fixed-point contract of the plane-fit sums, version 4 (v3 in brackets).
 //   * every CZM bin has an ORIGIN (ox, oy): its polar centre rounded to 1/8 m; R = the largest
 //     distance of any bin corner from its origin;
-//   * s = the largest shift <= 21 with (R + 0.01) * 2^s <= 2^26; ZR = 2^(26 - s) metres;
+//   * s = the largest shift <= 30 [21] with (R + 0.01) * 2^s <= 2^35 [2^26]; ZR = 2^(35 - s) [2^(26 - s)] metres;
 //   * every visit of a bin (ref :206) has a z origin z0: the first lowest-point representative
 //     the visit computes (ref :103), rounded to 1/8 m (0 if it is not finite, +-4096 at most);
-//   * Q_x(v) = rint(double(v) * 2^s - ox * 2^s), Q_y alike, Q_z(v) the same around z0 after
-//     clamping v to [z0 - ZR, z0 + ZR] in float (fmaxf, then fminf);
+//   * Q_x(v) = the integer nearest to the EXACT value v * 2^s - ox * 2^s (ties to even), Q_y alike, Q_z(v) the
+//     same around z0 after clamping v to [z0 - ZR, z0 + ZR] in float (fmaxf, then fminf);
+//     with s = 30 a float of magnitude >= 2^-7 m is a multiple of 2^-30 m: Q is then exact, not rounded;
 //   * exact integer moments n, S1_a = sum Q_a, S2_ab = sum Q_a Q_b;
 //   * mean_a = float(double(S1_a) * (1 / double(n)) * 2^-s + origin_a);
 //     cov_ab = float(double(n S2_ab - S1_a S1_b) * (1 / (double(n) double(n-1))) * 2^-2s), numerator exact,
 //     the two reciprocals formed once per fit in double (contract v3);
 //   * fit sets of 1-3 points: the reference's own float sums in (z, cloud index) order (estimate_plane below).
 // ---------------------------------------------------------------------------------
-constexpr int kFxpMaxShift = 21;
-constexpr double kFxpQMax = 67108864.0;  // 2^26
+struct FxpGrid {
+    int max_shift;
+    double qmax;
+};
+constexpr FxpGrid kFxpV4 = {30, 34359738368.0};  // 2^-30 m, |Q| <= 2^35
+constexpr FxpGrid kFxpV3 = {21, 67108864.0};     // 2^-21 m, |Q| <= 2^26
 
 struct FxpGeom {
     int shift = 0;
     double scale = 1.0;  // 2^shift
-    double zr = 0.0;     // 2^(26 - shift)
+    double zr = 0.0;     // qmax / 2^shift
     std::vector<float> ox, oy;
 };
 
 // geometry in double, exactly as the reference's constructor computes it (patchworkpp.h:122-134)
 FxpGeom fxp_geometry(const double min_ranges[4], const double ring_sizes[4], const double sector_sizes[4],
-                     const int rings[4], const int sectors[4], double max_range) {
+                     const int rings[4], const int sectors[4], double max_range, const FxpGrid &grid) {
     FxpGeom g;
     double rmax = 0.0;
     for (int z = 0; z < 4; ++z)
@@ -130,11 +139,11 @@ FxpGeom fxp_geometry(const double min_ranges[4], const double ring_sizes[4], con
                 }
                 rmax = std::max(rmax, far);
             }
-    int s = kFxpMaxShift;
-    while (s > 0 && (rmax + 0.01) * (double)(1 << s) > kFxpQMax) --s;
+    int s = grid.max_shift;
+    while (s > 0 && (rmax + 0.01) * (double)(1 << s) > grid.qmax) --s;
     g.shift = s;
     g.scale = (double)(1 << s);
-    g.zr = kFxpQMax / g.scale;
+    g.zr = grid.qmax / g.scale;
     return g;
 }
 
@@ -146,13 +155,30 @@ double fxp_z_origin(double lpr) {
     return t;
 }
 
-int64_t fxp_quantise(float v, double origin, double scale) {  // Q_x, Q_y
-    return (int64_t)std::rint((double)v * scale - origin * scale);
+// Q(v) = round-half-even of the exact value v * 2^shift - origin * 2^shift, in integers (the device forms it with ONE
+// fused multiply-add, a single rounding; two roundings in double could differ on a tie for |v| < 2^-shift).
+// v finite; origin * 2^shift is an integer (origins are multiples of 1/8 m, shift >= 3).
+int64_t fxp_quantise(float v, double origin, int shift) {  // Q_x, Q_y
+    const int64_t O = (int64_t)std::ldexp(origin, shift);
+    int e = 0;
+    const double fr = std::frexp((double)v, &e);        // v = fr * 2^e, 0.5 <= |fr| < 1 (or 0)
+    const int64_t m = (int64_t)std::ldexp(fr, 24);      // 24-bit signed mantissa, exact
+    const int sh = e - 24 + shift;                      // v * 2^shift = m * 2^sh
+    if (m == 0) return -O;
+    if (sh >= 0) return (int64_t)((__int128)m << sh) - O;  // (|v * scale| < 2^63 for every value the clamps let through)
+    const int k = -sh;
+    if (k > 26) return -O;                               // |m * 2^sh| < 1/4: nearest integer of (tiny - O) is -O
+    const __int128 num = (__int128)m - ((__int128)O << k);  // value = num / 2^k
+    const __int128 one = (__int128)1 << k, half = one >> 1;
+    __int128 q = num >> k;                               // floor
+    const __int128 rem = num - (q << k);                 // 0 <= rem < 2^k
+    if (rem > half || (rem == half && (q & 1))) ++q;
+    return (int64_t)q;
 }
-int64_t fxp_quantise_z(float v, double z0, double zr, double scale) {
+int64_t fxp_quantise_z(float v, double z0, double zr, int shift) {
     const float lo = (float)(z0 - zr), hi = (float)(z0 + zr);
     const float c = std::fmin(std::fmax(v, lo), hi);  // NaN -> lo, as v_max_f32 / v_min_f32 do
-    return (int64_t)std::rint((double)c * scale - z0 * scale);
+    return fxp_quantise(c, z0, shift);
 }
 
 // ---------------------------------------------------------------------------------
@@ -290,7 +316,7 @@ public:
         bins.resize((size_t)num_bins);
         std::memset(&plane, 0, sizeof(plane));
         fxp = fxp_geometry(min_ranges, ring_sizes, sector_sizes, prm.num_rings_each_zone, prm.num_sectors_each_zone,
-                           prm.max_range);
+                           prm.max_range, arith == PWO_ARITH_FXP21 ? kFxpV3 : kFxpV4);
     }
 
     pwo_params prm;  // params_ of the reference; sensor_height / thresholds mutate (:347-350,368)
@@ -611,8 +637,8 @@ private:
             __int128 s2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (int i = 0; i < n; ++i) {
                 const Pt &p = g[(size_t)i];
-                const int64_t q[3] = {fxp_quantise(p.x, org[0], fxp.scale), fxp_quantise(p.y, org[1], fxp.scale),
-                                      fxp_quantise_z(p.z, z0, fxp.zr, fxp.scale)};
+                const int64_t q[3] = {fxp_quantise(p.x, org[0], fxp.shift), fxp_quantise(p.y, org[1], fxp.shift),
+                                      fxp_quantise_z(p.z, z0, fxp.zr, fxp.shift)};
                 for (int a = 0; a < 3; ++a) {
                     s1[a] += q[a];
                     for (int b = 0; b < 3; ++b) s2[a * 3 + b] += (__int128)q[a] * (__int128)q[b];
@@ -806,7 +832,7 @@ void pwo_default_params(pwo_params *p) {  // reference patchworkpp.h:79-111
     p->max_elevation_storage = 1000;
 }
 
-int pwo_arith_supported(int arith) { return arith >= PWO_ARITH_EIGEN_F32 && arith <= PWO_ARITH_F32_PACKET4; }
+int pwo_arith_supported(int arith) { return arith >= PWO_ARITH_EIGEN_F32 && arith <= PWO_ARITH_FXP21; }
 
 void *pwo_create(const pwo_params *p, int arith) {
     if (!pwo_arith_supported(arith)) return nullptr;
@@ -885,9 +911,9 @@ long pwo_ext_max_sweeps(int reset) {
     if (reset) g_max_sweeps = 0;
     return v;
 }
-long long pwo_ext_quantise(float v, double origin, int shift) { return fxp_quantise(v, origin, (double)(1 << shift)); }
-long long pwo_ext_quantise_z(float v, double z0, int shift) {
-    return fxp_quantise_z(v, z0, kFxpQMax / (double)(1 << shift), (double)(1 << shift));
+long long pwo_ext_quantise(float v, double origin, int shift) { return fxp_quantise(v, origin, shift); }
+long long pwo_ext_quantise_z(float v, double z0, int shift, double zr) {
+    return fxp_quantise_z(v, z0, zr, shift);
 }
 double pwo_ext_z_origin(double lpr) { return fxp_z_origin(lpr); }
 

@@ -222,8 +222,9 @@ namespace {
 
 // The fixed-point contract of the plane-fit sums: every bin sums its points around an
 // ORIGIN, its polar centre rounded to 1/8 m (a sector wider than a quarter turn keeps the sensor), and the
-// shift s is the largest one <= 21 that keeps every point of every bin within 2^26 grid steps of its origin.
-void fxp_geometry(const PwppDevParams &d, std::vector<float2> &origin, int &shift) {
+// shift s is the largest one <= 30 that keeps every point of every bin within 2^35 grid steps of its origin (contract v4, `wide`;
+// v3 of rounds 3-5, option "exact_moments" = 0: <= 21 and 2^26).  Returns the z half-range ZR = 2^35 / 2^s (2^26 / 2^s) metres.
+double fxp_geometry(const PwppDevParams &d, std::vector<float2> &origin, int &shift, bool wide) {
     double rmax = 0.0;
     origin.clear();
     for (int z = 0; z < 4; ++z)
@@ -248,9 +249,11 @@ void fxp_geometry(const PwppDevParams &d, std::vector<float2> &origin, int &shif
                 origin.push_back(make_float2((float)cx, (float)cy));
                 rmax = std::max(rmax, far);
             }
-    int s = 21;
-    while (s > 0 && (rmax + 0.01) * (double)(1 << s) > 67108864.0) --s;
+    const double qmax = wide ? 34359738368.0 : 67108864.0;
+    int s = wide ? 30 : 21;
+    while (s > 0 && (rmax + 0.01) * (double)(1 << s) > qmax) --s;
     shift = s;
+    return qmax / (double)(1 << s);
 }
 
 // Bounding box {xmin, xmax, ymin, ymax} of every bin: an annular sector reaches its extremes at its four corners or where
@@ -1053,8 +1056,9 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
     if (device < 0 || device >= ndev) return fail(PWPP_E_ARG, "device %d out of range [0,%d)", device, ndev);
     HIPCHK(hipSetDevice(device));
     std::vector<float2> origin;
-    fxp_geometry(dp, origin, dp.fxp_shift);
-    dp.fxp_zr = (float)(67108864.0 / (double)(1 << dp.fxp_shift));
+    dp.fxp_wide = 1;  // contract v4 (option "exact_moments")
+    if (const char *e = std::getenv("PWPP_EXACT_MOMENTS")) dp.fxp_wide = std::atoi(e) != 0;
+    dp.fxp_zr = (float)fxp_geometry(dp, origin, dp.fxp_shift, dp.fxp_wide != 0);
     std::vector<float4> boxes;
     bin_boxes(dp, boxes);
     dp.hi_split = 0.6f;  // option "hi_split"
@@ -1081,6 +1085,7 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
         if (v > 0.0 && v <= 1024.0) h->one_pass_scale = v;
         else std::fprintf(stderr, "pwpp: ignoring PWPP_ONE_PASS_SCALE=%s (a positive number up to 1024 expected)\n", e);
     }
+    if (std::getenv("PWPP_EXACT_MOMENTS")) std::fprintf(stderr, "pwpp: exact_moments=%d taken from the environment (PWPP_EXACT_MOMENTS)\n", h->dp.fxp_wide);
     if (h->debug_flags || !h->fit_plan.empty() || h->fit_concurrent || h->no_one_pass || std::getenv("PWPP_ONE_PASS_MIN_FRAMES") ||
         std::getenv("PWPP_ONE_PASS_SCALE") || std::getenv("PWPP_OVERLAP") || std::getenv("PWPP_OVERLAP_RANGES") || std::getenv("PWPP_HI_SPLIT") ||
         std::getenv("PWPP_HI_SPLIT_ZONES"))
@@ -1595,7 +1600,7 @@ int pwpp_get_fxp_geometry(const pwpp_params *p, int *shift, float *out_xy, int c
     if (rc < 0) return rc;
     std::vector<float2> origin;
     int s = 0;
-    fxp_geometry(dp, origin, s);
+    (void)fxp_geometry(dp, origin, s, true);
     if (shift) *shift = s;
     if (out_xy) {
         if (capacity_bins < dp.num_bins) return fail(PWPP_E_ARG, "room for %d bins, %d needed", capacity_bins, dp.num_bins);
@@ -1819,6 +1824,14 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
                 h->masked_fit.push_back(st);
             }
         }
+    } else if (k == "exact_moments") {
+        // the width of the plane-fit sums (include/pwpp.h): "1" = contract v4, a 2^-30 m grid; "0" = rounds 3-5's 2^-21 m grid.
+        // The per-bin origins do not depend on it; shift and z half-range do.
+        const int v = std::atoi(value);
+        if ((v != 0 && v != 1) || (value[0] != '0' && value[0] != '1') || value[1] != 0) return fail(PWPP_E_ARG, "exact_moments=%s: 0 or 1 expected", value);
+        std::vector<float2> origin;
+        h->dp.fxp_wide = v;
+        h->dp.fxp_zr = (float)fxp_geometry(h->dp, origin, h->dp.fxp_shift, v != 0);
     } else if (k == "redo_whole_batch") {
         h->redo_whole_batch = std::atoi(value) != 0;
     } else if (k == "one_pass_min_frames") {

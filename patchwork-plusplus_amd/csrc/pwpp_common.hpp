@@ -224,11 +224,11 @@ __device__ void jacobi_svd3(const float a[9], float u[9], float sv[3]) {
 // in oracle/pwpp_oracle.cpp):
 //   Q_x(v) = rint(double(v) * 2^s - ox * 2^s), Q_y alike        (ox, oy: the bin's origin, multiples of 1/8 m)
 //   Q_z(v) = the same around z0 after clamping v to [z0 - ZR, z0 + ZR] in float
-//            (z0: the patch's first lowest-point representative rounded to 1/8 m, ZR = 2^(26-s) m)
-// |Q| <= 2^26 by construction of s (pwpp_capi.cpp, build_dev_params).
+//            (z0: the patch's first lowest-point representative rounded to 1/8 m, ZR = 2^(35-s) m; 2^(26-s) on the narrow grid)
+// |Q| <= 2^35 (2^26) by construction of s (pwpp_capi.cpp, fxp_geometry): s = 30 (21) with the default CZM.
 // One v_fma_f64 does the scaling, the subtraction and the rounding: added to 2^52 + 2^51 the exact
 // value double(v) * 2^s - O is rounded to an integer (ties to even, as rint) by the FMA itself, and
-// the low 32 bits of the result are that integer in two's complement.
+// the low bits of the result are that integer in two's complement (32 of them on the narrow grid, 51 on the wide one).
 // ------------------------------------------------------------------------------------------
 struct FxpOrg {
     double cx, cy, cz;  // 2^52 + 2^51 - origin * 2^s
@@ -265,12 +265,28 @@ __device__ __forceinline__ float key_z(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// Per-lane partial sums of the quantised coordinates.  Every product and every sum is a 64-bit integer
-// multiply-add (v_mad_i64_i32, full rate on gfx950 like v_fma_f64: tools/ubench/valu_rates.hip): exact
-// whatever the order, no conversion back and forth, no chunk-wise flush.  |Q| <= 2^26, so a lane may add up
-// 2^11 - 1 points before a second moment could leave int64; the kernels deal at most that many to a lane
-// (pwpp_launch_fit caps the classes) and k_fit_stream, which takes whatever is larger, sums in 128 bits.
-struct Moments {
+// Per-lane partial sums of the quantised coordinates, in the two widths of the contract (PwppDevParams.fxp_wide):
+//
+// MomentsT<false>  |Q| <= 2^26 (the 2^-21 m grid of rounds 3-5, option "exact_moments" = 0).  Every product and every sum
+//   is a 64-bit integer multiply-add (v_mad_i64_i32, full rate on gfx950 like v_fma_f64: tools/ubench/valu_rates.hip): exact
+//   whatever the order, no conversion back and forth, no chunk-wise flush.  A lane may add up 2^11 - 1 points before a second
+//   moment could leave int64; the kernels deal at most that many to a lane (pwpp_launch_fit caps the classes) and k_fit_stream,
+//   which takes whatever is larger, sums in 128 bits.
+//
+// MomentsT<true>   |Q| <= 2^35 (contract v4, the default: a 2^-30 m grid, on which every float of magnitude >= 2^-7 m lies --
+//   the sums are those of exact arithmetic on the reference's own floats).  Q = H * 2^9 + L with H = Q >> 9 (|H| <= 2^26) and
+//   L = Q & 511, both cut out of the FMA's bit pattern (v_alignbit_b32, v_and_b32), and
+//       Q_a Q_b = 2^18 H_a H_b + 2^9 (H_a L_b + L_a H_b) + L_a L_b
+//   is added up term by term: hh (v_mad_i64_i32, as above), hl (v_mad_i64_i32; |H L| < 2^35: 2^11 points leave 17 bits of
+//   head-room), ll (v_mad_u32_u24; < 2^18 each, 2^29 after 2^11 points).  First moments: the FMA result is the double
+//   2^52 + 2^51 + Q, whose BIT PATTERN is 0x4338000000000000 + Q as an integer -- the patterns are added up as they are
+//   (one 64-bit add per coordinate) and n times the constant is taken off at the end (mod 2^64: exact).
+//   21 multiply-adds + 6 bit operations + 3 adds per point against 9 + 0 + 0: the price of 36-bit values on a 32-bit multiplier.
+template <bool WIDE>
+struct MomentsT;
+
+template <>
+struct MomentsT<false> {
     long long n, s1[3], s2[6];
     __device__ __forceinline__ void clear() {
         n = 0;
@@ -300,7 +316,77 @@ struct Moments {
         n += 1;
         add_uncounted(x, y, z, scale, o);
     }
+    // this lane's sums once its pass is over (n final)
+    __device__ __forceinline__ long long first(int k) const { return s1[k]; }
+    __device__ __forceinline__ __int128 second(int k) const { return (__int128)s2[k]; }
 };
+
+template <>
+struct MomentsT<true> {
+    long long n;
+    unsigned long long s1b[3];  // sums of the bit patterns 0x4338000000000000 + Q
+    long long hh[6], hl[6];     // pairs (0,0) (0,1) (0,2) (1,1) (1,2) (2,2); hl of a diagonal pair holds H L once (doubled in second())
+    unsigned ll[6];
+    __device__ __forceinline__ void clear() {
+        n = 0;
+        s1b[0] = s1b[1] = s1b[2] = 0ull;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            hh[k] = 0;
+            hl[k] = 0;
+            ll[k] = 0u;
+        }
+    }
+    __device__ __forceinline__ void add_uncounted(float x, float y, float z, double scale, const FxpOrg &o) {
+        const unsigned long long tx = (unsigned long long)__double_as_longlong(__builtin_fma((double)x, scale, o.cx));
+        const unsigned long long ty = (unsigned long long)__double_as_longlong(__builtin_fma((double)y, scale, o.cy));
+        const unsigned long long tz = (unsigned long long)__double_as_longlong(__builtin_fma((double)__builtin_amdgcn_fmed3f(z, o.zlo, o.zhi), scale, o.cz));
+        s1b[0] += tx;
+        s1b[1] += ty;
+        s1b[2] += tz;
+        const int hx = (int)__builtin_amdgcn_alignbit((unsigned)(tx >> 32), (unsigned)tx, 9), lx = (int)((unsigned)tx & 511u);
+        const int hy = (int)__builtin_amdgcn_alignbit((unsigned)(ty >> 32), (unsigned)ty, 9), ly = (int)((unsigned)ty & 511u);
+        const int hz = (int)__builtin_amdgcn_alignbit((unsigned)(tz >> 32), (unsigned)tz, 9), lz = (int)((unsigned)tz & 511u);
+        hh[0] += (long long)hx * hx;
+        hh[1] += (long long)hx * hy;
+        hh[2] += (long long)hx * hz;
+        hh[3] += (long long)hy * hy;
+        hh[4] += (long long)hy * hz;
+        hh[5] += (long long)hz * hz;
+        hl[0] += (long long)hx * lx;
+        hl[1] += (long long)hx * ly;
+        hl[1] += (long long)hy * lx;
+        hl[2] += (long long)hx * lz;
+        hl[2] += (long long)hz * lx;
+        hl[3] += (long long)hy * ly;
+        hl[4] += (long long)hy * lz;
+        hl[4] += (long long)hz * ly;
+        hl[5] += (long long)hz * lz;
+        ll[0] += __umul24((unsigned)lx, (unsigned)lx);
+        ll[1] += __umul24((unsigned)lx, (unsigned)ly);
+        ll[2] += __umul24((unsigned)lx, (unsigned)lz);
+        ll[3] += __umul24((unsigned)ly, (unsigned)ly);
+        ll[4] += __umul24((unsigned)ly, (unsigned)lz);
+        ll[5] += __umul24((unsigned)lz, (unsigned)lz);
+    }
+    __device__ __forceinline__ void add(float x, float y, float z, double scale, const FxpOrg &o) {
+        n += 1;
+        add_uncounted(x, y, z, scale, o);
+    }
+    __device__ __forceinline__ long long first(int k) const {
+        const unsigned long long b = k == 0 ? s1b[0] : (k == 1 ? s1b[1] : s1b[2]);
+        return (long long)(b - (unsigned long long)n * 0x4338000000000000ull);
+    }
+    __device__ __forceinline__ __int128 second(int k) const {
+        const bool diag = k == 0 || k == 3 || k == 5;
+        return (__int128)hh[k] * 262144 + (__int128)hl[k] * (diag ? 1024 : 512) + (__int128)ll[k];
+    }
+};
+// the 36-bit Q itself (the kernels that walk a patch point by point: k_fit_stream)
+__device__ __forceinline__ long long fxp_q_wide(float v, double scale, double c) {
+    const long long t = __double_as_longlong(__builtin_fma((double)v, scale, c));
+    return (t << 13) >> 13;  // bits 0..50 of the pattern = Q mod 2^51, sign-extended
+}
 
 // ------------------------------------------------------------------------------------------
 // plane of ref :47-75 from the exact integer moments of a point set:

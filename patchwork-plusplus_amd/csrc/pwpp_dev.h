@@ -49,8 +49,9 @@ struct PwppDevParams {
     int32_t rings[4], sectors[4];
     int32_t bin_base[5];  // first bin of zone k; [4] = B
     int32_t num_bins;     // B
-    int32_t fxp_shift;    // s of the plane-fit arithmetic contract
-    float fxp_zr;         // 2^(26 - s) metres: a fit's z coordinates are clamped to z0 +- fxp_zr before they are quantised
+    int32_t fxp_shift;    // s of the plane-fit arithmetic contract: the sums run on a 2^-s m grid
+    int32_t fxp_wide;     // 1 (default, contract v4): |Q| <= 2^35, s <= 30; 0 (option "exact_moments" = 0, rounds 3-5's v3): |Q| <= 2^26, s <= 21
+    float fxp_zr;         // 2^(35 - s) / 2^(26 - s) metres: a fit's z coordinates are clamped to z0 +- fxp_zr before they are quantised
     float hi_split;       // metres above the ground level (-sensor_height) where the high part of a bin begins; huge = no high parts
     int32_t split_end;    // bins [0, split_end) are stored in two parts, the others keep all their points in the low part
     int32_t max_elev_storage, max_flat_storage;

@@ -49,6 +49,9 @@ constexpr int kPPT = 8;  // points per lane held in registers
 #ifndef PWPP_W16_OCC
 #define PWPP_W16_OCC 4  // waves per SIMD the 16-lane fit kernel is compiled for (3: 2 spilled registers instead of 77, 18 % slower alone -- profiles/r04_experiments.txt)
 #endif
+#ifndef PWPP_W16_WIDE_OCC
+#define PWPP_W16_WIDE_OCC 3  // ... on the wide grid (contract v4): sixteen totals per patch in LDS (12.4 KB per wave) allow three waves per SIMD anyway
+#endif
 #ifndef PWPP_FIT_PREFETCH
 #define PWPP_FIT_PREFETCH 0
 #endif
@@ -143,7 +146,7 @@ struct Row {
         return __builtin_bit_cast(long long, pair);
     }
     __device__ static __forceinline__ long long reduce16_scatter(const long long (&v)[16], int &slot) {
-        static_assert(G == 64, "rows of 64 lanes");
+        static_assert(G == 64 || G == 16, "rows of 64 or 16 lanes");  // (16: the first four steps are the whole reduction)
         const int ln = lane_id();
         const bool s2 = (ln & 4) != 0, s0 = (ln & 1) != 0, s1 = (ln & 2) != 0, s3 = (ln & 8) != 0;
         long long a[8], b[4], c[2], d;
@@ -166,8 +169,10 @@ struct Row {
             const long long keep = s3 ? c[1] : c[0], send = s3 ? c[0] : c[1];
             d = keep + xchg64<3>(send);
         }
-        d += xchg64<4>(d);
-        d += xchg64<5>(d);
+        if (G == 64) {
+            d += xchg64<4>(d);
+            d += xchg64<5>(d);
+        }
         slot = (s2 ? 8 : 0) + (s0 ? 4 : 0) + (s1 ? 2 : 0) + (s3 ? 1 : 0);
         return d;
     }
@@ -459,9 +464,9 @@ __device__ __forceinline__ unsigned chunk_slot(const PartSel &sel, int k, unsign
 //   no branch on the stage.  The test itself is  s < T  in float, T = plane_test_threshold(d, thr) of the pass
 //   (pwpp_common.hpp): bit for bit the reference's  double(s) + d < thr.  A point R-VPF removed has a NaN for its z
 //   (strip_point) and fails like any NaN; a slot beyond the part's end holds a stand-in record and is masked by `rem`.
-template <int G>
+template <int G, class M>
 __device__ __forceinline__ unsigned lane_stage_accum(const ChunkPts &cp, int kind, float T, float nx, float ny, float nz,
-                                                     double scale, const FxpOrg &org, Moments &m) {
+                                                     double scale, const FxpOrg &org, M &m) {
     const bool iter = kind == ST_ITER;
     const float tx = iter ? nx : 0.0f, ty = iter ? ny : 0.0f, tz = iter ? nz : 1.0f;
     unsigned gmask = 0;
@@ -572,15 +577,18 @@ __device__ void tiny_fit_row(const PatchRef &pts, bool on, int kind, float T, fl
 }
 
 // the sixteen values Row<64>::reduce16_scatter adds up for a patch: n, S1[3], lower and upper halves of S2[6]
-__device__ __forceinline__ void moments_to_16(const Moments &mm, long long (&v)[16]) {
+// (a lane's second moment: up to 2^63 on the narrow grid, 2^83 on the wide one -- the upper half fits int64 either way, and stays
+// there when 256 lanes are added up)
+template <class M>
+__device__ __forceinline__ void moments_to_16(const M &mm, long long (&v)[16]) {
     v[0] = mm.n;
-    v[1] = mm.s1[0];
-    v[2] = mm.s1[1];
-    v[3] = mm.s1[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[1 + k] = mm.first(k);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        v[4 + k] = mm.s2[k] & 0xffffffffLL;
-        v[10 + k] = mm.s2[k] >> 32;
+        const __int128 t = mm.second(k);
+        v[4 + k] = (long long)((unsigned long long)t & 0xffffffffull);
+        v[10 + k] = (long long)(t >> 32);
     }
 }
 __device__ __forceinline__ __int128 join_halves(long long lo, long long hi) { return ((__int128)hi << 32) + (__int128)lo; }
@@ -838,7 +846,7 @@ __device__ __forceinline__ void plane_clear(PlaneFit &pl) {
 // wave have similar trip counts.  A workgroup per big patch was tried and rejected: all but
 // one wave idle during the solve (2.5 + 7.5 ms per 1024 frames vs 2.6 ms for one wave each).
 // ------------------------------------------------------------------------------------------
-template <int G>
+template <int G, bool WIDE>
 __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, int b_hi, unsigned by /* block index among the row blocks */) {
     const int f = blockIdx.x;  // frame = fast grid dimension: most blocks of a frame's worst-case grid are empty, and with the
                                // frame in blockIdx.y the working blocks formed a pattern of period 32 = 8 XCDs x 4 SEs (3x slower)
@@ -864,7 +872,7 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
     const float4 bb = Bt.bin_bbox[bin];
     const bool use_cutoff = zone == 0;
     const double scale = (double)(1 << P.fxp_shift);
-    const bool wide = __any(n > 2047u);  // wave-uniform: some row's second moments may leave int64 in the cross-lane sum
+    const bool wide = WIDE || __any(n > 2047u);  // wave-uniform: some row's second moments may leave int64 in the cross-lane sum
     // the totals of the row's last R-GPF round (early termination, see k_fit_w64): n, S1[3], S2[6] as two 64-bit halves each
     __shared__ long long s_prev[kBlock / G][16];
     long long(&prev)[16] = s_prev[threadIdx.x / G];
@@ -903,7 +911,7 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
         // (early termination and the membership plane: see k_fit_w64 -- every R-GPF round from the second on, and the last one,
         // leaves its set in the plane; a round whose totals repeat the round before's ends the patch)
         const bool wbits = kind == ST_ITER && (last || it >= 1);
-        Moments m;
+        MomentsT<WIDE> m;
         m.clear();
         bool clamped = false;
         ChunkPts cp;
@@ -924,14 +932,16 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
             long long s1[3];
             __int128 s2[6];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) s1[k] = Row<G>::sum_i64(m.s1[k]);
+            for (int k = 0; k < 3; ++k) s1[k] = Row<G>::sum_i64(m.first(k));
             if (!wide) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) s2[k] = (__int128)Row<G>::sum_i64(m.s2[k]);  // <= 2047 points: fits int64
+                for (int k = 0; k < 6; ++k) s2[k] = (__int128)Row<G>::sum_i64((long long)m.second(k));  // narrow grid, <= 2047 points: fits int64
             } else {
 #pragma unroll
-                for (int k = 0; k < 6; ++k)
-                    s2[k] = join_halves(Row<G>::sum_i64(m.s2[k] & 0xffffffffLL), Row<G>::sum_i64(m.s2[k] >> 32));
+                for (int k = 0; k < 6; ++k) {
+                    const __int128 t = m.second(k);
+                    s2[k] = join_halves(Row<G>::sum_i64((long long)((unsigned long long)t & 0xffffffffull)), Row<G>::sum_i64((long long)(t >> 32)));
+                }
             }
             if (__any(kind == ST_ITER)) {  // this round's totals against the last round's, then they take their place (lane 0 of the row keeps them)
                 bool same = prev[0] == cnt;
@@ -1018,9 +1028,9 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
     }
 }
 
-template <int G>
+template <int G, bool WIDE>
 __global__ __launch_bounds__(kBlock, 3) void k_fit_srows(PwppBatch Bt, int b_lo, int b_hi) {
-    fit_srows_body<G>(Bt, b_lo, b_hi, blockIdx.y);
+    fit_srows_body<G, WIDE>(Bt, b_lo, b_hi, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1090,12 +1100,13 @@ struct W64Shared {
 // big bins), PW = patches owned by the wave = lanes active in the solve phase.
 // Moments per patch in LDS: rows of 16 lanes only see patches below 2048 points, whose ten totals fit
 // int64; 64-lane rows leave sixteen values (second moments as 32-bit halves, Row<64>::reduce16_scatter).
-template <int G, int PW>
-__global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : PWPP_W16_OCC) void k_fit_w64(PwppBatch Bt, int b_lo, int b_hi) {
+template <int G, int PW, bool WIDE>
+__global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_OCC : PWPP_W16_OCC)) void k_fit_w64(PwppBatch Bt, int b_lo, int b_hi) {
     // ONE WAVE PER WORKGROUP: the waves never talk to each other, and a workgroup of four only starts when a CU has
     // room for all four at once -- with waves of very different lifetimes the slots of the early finishers stood empty
     // (27 % of the wave slots of k_fit_w64<64,2>, profiles/).
-    constexpr int MW = G == 64 ? 16 : 10;
+    constexpr int MW = (G == 64 || WIDE) ? 16 : 10;  // (the wide grid: second moments beyond int64 -- sixteen values in 16-lane rows too)
+    typedef MomentsT<WIDE> Moments;
     __shared__ W64Shared<PW, G == 64, MW> sh;
     constexpr int R = 64 / G;      // patches per points-phase sub-batch
     constexpr int NSB = PW / R;    // sub-batches
@@ -1288,7 +1299,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : PWPP_W16_OCC) void k_f
             // fewer exchanges save: 0.868 -> 0.884 ms)
             // `same`: does the total this lane stores equal the one it replaces (the lanes that store nothing say yes)?
             auto row_totals = [&](const Moments &mm, long long (*dst)[MW], bool store, bool &same) {
-                if constexpr (G == 64) {
+                if constexpr (MW == 16) {
                     long long v[16];
                     moments_to_16(mm, v);
                     int slot16;
@@ -1385,7 +1396,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : PWPP_W16_OCC) void k_f
                     const long long s1[3] = {tot[1], tot[2], tot[3]};
                     __int128 s2[6];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) s2[k] = G == 64 ? join_halves(tot[4 + k], tot[MW == 16 ? 10 + k : 4 + k]) : (__int128)tot[4 + k];
+                    for (int k = 0; k < 6; ++k) s2[k] = MW == 16 ? join_halves(tot[4 + k], tot[MW == 16 ? 10 + k : 4 + k]) : (__int128)tot[4 + k];
                     mean_cov_from_totals(cnt, s1, s2, P.fxp_shift, sh.p[ln].ox, sh.p[ln].oy, O(z0), mean, c6);
                 }
             }
@@ -1499,6 +1510,7 @@ struct FitShared {
 
 // per-lane sums of the workgroup-per-patch kernel: it takes patches of any size, so the second moments are
 // kept in 128 bits (a lane of the other kernels never sees more than 2047 points, see Moments)
+template <bool WIDE>
 struct MomentsWide {
     long long n, s1[3];
     __int128 s2[6];
@@ -1509,18 +1521,21 @@ struct MomentsWide {
         for (int k = 0; k < 6; ++k) s2[k] = 0;
     }
     __device__ __forceinline__ void add(float x, float y, float z, double scale, const FxpOrg &o) {
-        const long long qx = fxp_q(x, scale, o.cx), qy = fxp_q(y, scale, o.cy);
-        const long long qz = fxp_q(__builtin_amdgcn_fmed3f(z, o.zlo, o.zhi), scale, o.cz);
+        const float zc = __builtin_amdgcn_fmed3f(z, o.zlo, o.zhi);
+        const long long qx = WIDE ? fxp_q_wide(x, scale, o.cx) : (long long)fxp_q(x, scale, o.cx);
+        const long long qy = WIDE ? fxp_q_wide(y, scale, o.cy) : (long long)fxp_q(y, scale, o.cy);
+        const long long qz = WIDE ? fxp_q_wide(zc, scale, o.cz) : (long long)fxp_q(zc, scale, o.cz);
         n += 1;
         s1[0] += qx;
         s1[1] += qy;
         s1[2] += qz;
-        s2[0] += (__int128)(qx * qx);
-        s2[1] += (__int128)(qx * qy);
-        s2[2] += (__int128)(qx * qz);
-        s2[3] += (__int128)(qy * qy);
-        s2[4] += (__int128)(qy * qz);
-        s2[5] += (__int128)(qz * qz);
+        // (36-bit values on the wide grid: the products need 128 bits; this kernel is the rare path, nothing here is tuned)
+        s2[0] += (__int128)qx * (__int128)qx;
+        s2[1] += (__int128)qx * (__int128)qy;
+        s2[2] += (__int128)qx * (__int128)qz;
+        s2[3] += (__int128)qy * (__int128)qy;
+        s2[4] += (__int128)qy * (__int128)qz;
+        s2[5] += (__int128)qz * (__int128)qz;
     }
 };
 
@@ -1529,7 +1544,8 @@ struct MomentsWide {
 // added up as three limbs (32 + 32 + 64 bits) and recombined: exact at any size.
 // `pts`, `iter`, `thr`: the set's membership test once more (R-GPF round: distance to the plane still in `sh` below th_dist = thr;
 // seed stages: z < thr) for the sets of 1-3 points, which follow the reference's float arithmetic (tiny_fit_row).
-__device__ void reduce_and_fit(FitShared &sh, const MomentsWide &m, int shift, float ox, float oy, float z0, const PatchRef &pts, bool iter,
+template <class M>
+__device__ void reduce_and_fit(FitShared &sh, const M &m, int shift, float ox, float oy, float z0, const PatchRef &pts, bool iter,
                                double thr, int debug = 0) {
     long long v[22];
     v[0] = m.n;
@@ -1828,7 +1844,9 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, bool use_hi, boo
     return keff ? sum / (double)keff : 0.0;  // ref :103
 }
 
+template <bool WIDE>
 __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &Bt, int b_lo, int b_hi, unsigned by /* block index among the patch blocks */) {
+    typedef MomentsT<WIDE> Moments;
     const int f = blockIdx.x;
     const PwppDevParams &P = Bt.P;
     const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
@@ -2050,9 +2068,10 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
     if ((Bt.debug & 4) && threadIdx.x == 0) atomicMax(&Bt.dbg[61], (wall_clock64() << 24) | (unsigned long long)n);
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(kBlock, 2) void k_fit_brows(PwppBatch Bt, int b_lo, int b_hi) {
     __shared__ BRowShared sh;
-    fit_brows_body(sh, Bt, b_lo, b_hi, blockIdx.y);
+    fit_brows_body<WIDE>(sh, Bt, b_lo, b_hi, blockIdx.y);
 }
 
 // k_fit_hybrid: the single-frame kernel.  A SIMD retires one instruction every ~5 cycles whoever it
@@ -2061,16 +2080,18 @@ __global__ __launch_bounds__(kBlock, 2) void k_fit_brows(PwppBatch Bt, int b_lo,
 // ~300 patches, the chip 256 CUs).  Here only the patches above `b_mid` get four waves (k_fit_brows'
 // body); the small ones, which fit one chunk of one wave anyway, go four to a workgroup, one wave each
 // (k_fit_srows<64>'s body) -- ~110 workgroups per frame, every one alone on its CU, in ONE launch.
+template <bool WIDE>
 __global__ __launch_bounds__(kBlock, 1) void k_fit_hybrid(PwppBatch Bt, int b_mid, int b_hi, unsigned nb_big) {
     __shared__ BRowShared sh;
     if (blockIdx.y < nb_big)
-        fit_brows_body(sh, Bt, b_mid, b_hi, blockIdx.y);
+        fit_brows_body<WIDE>(sh, Bt, b_mid, b_hi, blockIdx.y);
     else
-        fit_srows_body<64>(Bt, 0, b_mid, blockIdx.y - nb_big);
+        fit_srows_body<64, WIDE>(Bt, 0, b_mid, blockIdx.y - nb_big);
 }
 
 // the whole fit chain of one patch of any size by one workgroup (k_fit_stream: what exceeds the plan's classes;
 // k_fit_fixup: a patch that starts from the plane fitted before it, `init`)
+template <bool WIDE>
 __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch &Bt, int f, const PatchCtx &pc, const PwppPlaneState *init) {
     const PwppDevParams &P = Bt.P;
     const int bin = pc.bin, zone = pc.zone;
@@ -2108,7 +2129,7 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
             org = fxp_org(pc.ox, pc.oy, z0, scale, P.fxp_zr);
         }
     };
-    MomentsWide m;
+    MomentsWide<WIDE> m;
 
     // ---- R-VPF, ref :482-508
     if (P.enable_RVPF) {
@@ -2236,13 +2257,14 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
     }
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
     __shared__ FitShared sh;
     const int f = blockIdx.x;  // frame = fast grid dimension, see fit_srows_body
     const uint32_t *cs = Bt.cls_start + (size_t)f * PWPP_CLS_STRIDE;
     const unsigned slot = cs[b_lo] + blockIdx.y;
     if (slot >= cs[PWPP_NUM_BUCKETS]) return;
-    fit_stream_patch(sh, Bt, f, patch_ctx(Bt, f, slot, true), nullptr);
+    fit_stream_patch<WIDE>(sh, Bt, f, patch_ctx(Bt, f, slot, true), nullptr);
 }
 
 // k_fit_fixup: the patches of a frame that need the plane fitted before them (needs_previous_plane), in the reference's
@@ -2250,6 +2272,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_stream(PwppBatch Bt, int b_lo) {
 // of the stream's last frame at first (PwppPlaneState), then the final plane of every fitted patch it passes -- and
 // fits the marked ones from there.  Launched by the host for the frames whose flag is set when a batch lands (never,
 // for real scans); K5 and K6 follow for those frames.
+template <bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_fit_fixup(PwppBatch Bt) {
     __shared__ FitShared sh;
     __shared__ PwppPlaneState cur;
@@ -2284,7 +2307,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_fixup(PwppBatch Bt) {
             const float2 o = Bt.bin_origin[bin];
             pc.ox = o.x;
             pc.oy = o.y;
-            fit_stream_patch(sh, Bt, f, pc, &cur);
+            fit_stream_patch<WIDE>(sh, Bt, f, pc, &cur);
             __threadfence_block();
             __syncthreads();
         }
@@ -2305,7 +2328,8 @@ __global__ __launch_bounds__(kBlock) void k_fit_fixup(PwppBatch Bt) {
 
 extern "C" int pwpp_launch_fixup(const PwppBatch *batch, hipStream_t stream) {
     if (batch->num_frames <= 0) return 0;
-    hipLaunchKernelGGL(k_fit_fixup, dim3(batch->num_frames), dim3(kBlock), 0, stream, *batch);
+    if (batch->P.fxp_wide) hipLaunchKernelGGL(k_fit_fixup<true>, dim3(batch->num_frames), dim3(kBlock), 0, stream, *batch);
+    else hipLaunchKernelGGL(k_fit_fixup<false>, dim3(batch->num_frames), dim3(kBlock), 0, stream, *batch);
     return (int)hipGetLastError();
 }
 
@@ -2403,14 +2427,18 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
             const hipStream_t ls = (concurrent && slot >= 1) ? aux : stream;  // later classes beside the first one
             const unsigned patches = cap(n_lo);
             const dim3 grid(F, (patches * (unsigned)g + kBlock - 1) / kBlock);
-            if (mode == 'S' && g == 8) hipLaunchKernelGGL(k_fit_srows<8>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-            else if (mode == 'S' && g == 16) hipLaunchKernelGGL(k_fit_srows<16>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-            else if (mode == 'S' && g == 32) hipLaunchKernelGGL(k_fit_srows<32>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
-            else if (mode == 'S' && g == 64) hipLaunchKernelGGL(k_fit_srows<64>, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            // (every kernel exists for both widths of the arithmetic contract, PwppDevParams.fxp_wide)
+#define PWPP_LAUNCH2(kern, ...) do { if (B.P.fxp_wide) hipLaunchKernelGGL((kern<true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<false>), __VA_ARGS__); } while (0)
+#define PWPP_LAUNCH_T(kern, a, ...) do { if (B.P.fxp_wide) hipLaunchKernelGGL((kern<a, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<a, false>), __VA_ARGS__); } while (0)
+#define PWPP_LAUNCH_W(a, b, ...) do { if (B.P.fxp_wide) hipLaunchKernelGGL((k_fit_w64<a, b, true>), __VA_ARGS__); else hipLaunchKernelGGL((k_fit_w64<a, b, false>), __VA_ARGS__); } while (0)
+            if (mode == 'S' && g == 8) PWPP_LAUNCH_T(k_fit_srows, 8, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            else if (mode == 'S' && g == 16) PWPP_LAUNCH_T(k_fit_srows, 16, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            else if (mode == 'S' && g == 32) PWPP_LAUNCH_T(k_fit_srows, 32, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            else if (mode == 'S' && g == 64) PWPP_LAUNCH_T(k_fit_srows, 64, grid, dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'H') {  // "H64:<n>": up to n points a wave per patch, four waves above (up to 2^19 - 1 points), everything in one launch
                 const int k_top = pwpp_size_bucket(2023u * 256u + 1u);
                 const unsigned nb_big = cap(pwpp_bucket_floor(k_hi));
-                hipLaunchKernelGGL(k_fit_hybrid, dim3(F, nb_big + (patches + kWaves - 1) / kWaves), dim3(kBlock), 0, ls, B, k_hi, k_top, nb_big);
+                PWPP_LAUNCH2(k_fit_hybrid, dim3(F, nb_big + (patches + kWaves - 1) / kWaves), dim3(kBlock), 0, ls, B, k_hi, k_top, nb_big);
                 k_lo = k_top;
                 n_lo = pwpp_bucket_floor(k_top);
                 ++slot;
@@ -2418,16 +2446,16 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
                 if (*p == ',') ++p;
                 continue;
             }
-            else if (mode == 'B') hipLaunchKernelGGL(k_fit_brows, dim3(F, patches), dim3(kBlock), 0, ls, B, k_lo, k_hi);
+            else if (mode == 'B') PWPP_LAUNCH2(k_fit_brows, dim3(F, patches), dim3(kBlock), 0, ls, B, k_lo, k_hi);
             else if (mode == 'W') {  // "W<lanes per patch>.<patches per wave>"
                 if (pw == 0) pw = 64;
                 const dim3 wgrid(F, (patches + (unsigned)pw - 1) / (unsigned)pw), wblock(64);  // one wave per workgroup
-                if (g == 16 && pw == 64) hipLaunchKernelGGL((k_fit_w64<16, 64>), wgrid, wblock, 0, ls, B, k_lo, k_hi);
-                else if (g == 16 && pw == 32) hipLaunchKernelGGL((k_fit_w64<16, 32>), wgrid, wblock, 0, ls, B, k_lo, k_hi);
-                else if (g == 16 && pw == 16) hipLaunchKernelGGL((k_fit_w64<16, 16>), wgrid, wblock, 0, ls, B, k_lo, k_hi);
-                else if (g == 64 && pw == 8) hipLaunchKernelGGL((k_fit_w64<64, 8>), wgrid, wblock, 0, ls, B, k_lo, k_hi);
-                else if (g == 64 && pw == 4) hipLaunchKernelGGL((k_fit_w64<64, 4>), wgrid, wblock, 0, ls, B, k_lo, k_hi);
-                else if (g == 64 && pw == 2) hipLaunchKernelGGL((k_fit_w64<64, 2>), wgrid, wblock, 0, ls, B, k_lo, k_hi);
+                if (g == 16 && pw == 64) PWPP_LAUNCH_W(16, 64, wgrid, wblock, 0, ls, B, k_lo, k_hi);
+                else if (g == 16 && pw == 32) PWPP_LAUNCH_W(16, 32, wgrid, wblock, 0, ls, B, k_lo, k_hi);
+                else if (g == 16 && pw == 16) PWPP_LAUNCH_W(16, 16, wgrid, wblock, 0, ls, B, k_lo, k_hi);
+                else if (g == 64 && pw == 8) PWPP_LAUNCH_W(64, 8, wgrid, wblock, 0, ls, B, k_lo, k_hi);
+                else if (g == 64 && pw == 4) PWPP_LAUNCH_W(64, 4, wgrid, wblock, 0, ls, B, k_lo, k_hi);
+                else if (g == 64 && pw == 2) PWPP_LAUNCH_W(64, 2, wgrid, wblock, 0, ls, B, k_lo, k_hi);
                 else return (int)hipErrorInvalidValue;
             }
             else return (int)hipErrorInvalidValue;
@@ -2447,9 +2475,9 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
     if (!rest_possible) {
         // nothing left
     } else if (fork) {
-        hipLaunchKernelGGL(k_fit_stream, dim3(F, cap(n_lo)), dim3(kBlock), 0, aux, B, k_lo);
+        PWPP_LAUNCH2(k_fit_stream, dim3(F, cap(n_lo)), dim3(kBlock), 0, aux, B, k_lo);
     } else {
-        hipLaunchKernelGGL(k_fit_stream, dim3(F, cap(n_lo)), dim3(kBlock), 0, stream, B, k_lo);
+        PWPP_LAUNCH2(k_fit_stream, dim3(F, cap(n_lo)), dim3(kBlock), 0, stream, B, k_lo);
     }
     if (fork) {
         hipError_t e = hipEventRecord(aux_join, aux);

@@ -21,6 +21,7 @@ ARITH_EIGEN_F32 = 0   # float sums in storage order (plainest reading of Eigen)
 ARITH_FXP = 1         # the product's fixed-point contract (restatement only)
 ARITH_EXACT_F64 = 2   # reference-neutral arbiter: double sums of the unquantised floats
 ARITH_F32_PACKET4 = 3  # float sums, four partial sums (a SIMD reduction order)
+ARITH_FXP21 = 4       # contract v3 of rounds 3-5 (2^-21 m grid), restatement only: a witness
 REF_LIBS = {ARITH_EIGEN_F32: "libpwpp_ref.so", ARITH_EXACT_F64: "libpwpp_ref_exact.so",
             ARITH_F32_PACKET4: "libpwpp_ref_pk4.so"}
 
@@ -99,7 +100,7 @@ class _Lib:
             L.pwo_ext_quantise.restype = ctypes.c_longlong
             L.pwo_ext_quantise.argtypes = [ctypes.c_float, ctypes.c_double, ctypes.c_int]
             L.pwo_ext_quantise_z.restype = ctypes.c_longlong
-            L.pwo_ext_quantise_z.argtypes = [ctypes.c_float, ctypes.c_double, ctypes.c_int]
+            L.pwo_ext_quantise_z.argtypes = [ctypes.c_float, ctypes.c_double, ctypes.c_int, ctypes.c_double]
             L.pwo_ext_z_origin.restype = ctypes.c_double
             L.pwo_ext_z_origin.argtypes = [ctypes.c_double]
 

@@ -257,7 +257,7 @@ def test_fixed_point_geometry_matches_the_restatement(lib, oracle_built):
         xy = np.zeros((nb, 2), np.float32)
         assert lib.pwpp_get_fxp_geometry(ctypes.byref(p), ctypes.byref(shift), xy.ctypes.data_as(ctypes.c_void_p), nb) == nb
         sh, zr, ox, oy = ol.Estimator(ora, op, arith=ol.ARITH_FXP).fxp_geometry()
-        assert shift.value == sh and zr == 2.0 ** (26 - sh), (sect, rings, mn, mx)
+        assert shift.value == sh and zr == 2.0 ** (35 - sh), (sect, rings, mn, mx)  # contract v4: |Q| <= 2^35 on a 2^-sh m grid
         assert np.array_equal(xy[:, 0], ox) and np.array_equal(xy[:, 1], oy), (sect, rings, mn, mx)
 
 

@@ -163,25 +163,42 @@ def test_jacobi_is_an_eigen_decomposition(oracle_built):
 
 
 def test_fxp_contract_primitives(oracle_built):
-    """Shift, origins and quantisers of the fixed-point contract."""
+    """Shift, origins and quantisers of the fixed-point contract (DESIGN.md section 3.4): v4 = a 2^-30 m grid, |Q| <= 2^35;
+    the 2^-21 m grid of rounds 3-5 is still there as a witness (ARITH_FXP21)."""
     lib = oracle_built.restatement()
     L = lib.lib
     sh, zr, ox, oy = ol.Estimator(lib, arith=ol.ARITH_FXP).fxp_geometry()
-    assert sh == 21 and zr == 32.0 and len(ox) == 504  # default CZM: every bin within 32 m of its origin
+    assert sh == 30 and zr == 32.0 and len(ox) == 504  # default CZM: every bin within 32 m of its origin
+    sh3, zr3, ox3, oy3 = ol.Estimator(lib, arith=ol.ARITH_FXP21).fxp_geometry()
+    assert sh3 == 21 and zr3 == 32.0 and np.array_equal(ox, ox3) and np.array_equal(oy, oy3)
     assert (np.abs(ox * 8 - np.rint(ox * 8)) == 0).all() and (np.abs(oy * 8 - np.rint(oy * 8)) == 0).all()
     p = lib.default_params()
     p.max_range = 500.0
-    assert ol.Estimator(lib, p, arith=ol.ARITH_FXP).fxp_geometry()[0] == 20  # bigger bins, coarser grid
+    assert ol.Estimator(lib, p, arith=ol.ARITH_FXP).fxp_geometry()[0] == 29  # bigger bins, coarser grid
     for k in range(4):
         p.num_sectors_each_zone[k] = 1
     sh1, zr1, ox1, oy1 = ol.Estimator(lib, p, arith=ol.ARITH_FXP).fxp_geometry()
-    assert sh1 == 17 and not ox1.any() and not oy1.any()  # one sector per ring: the sensor is the origin
-    q = lambda v, o: L.pwo_ext_quantise(ctypes.c_float(v), o, 21)
-    assert q(1.0, 0.0) == 1 << 21 and q(-1.0, 0.0) == -(1 << 21) and q(10.125, 10.125) == 0
-    assert q(1.5 / (1 << 21), 0.0) == 2 and q(2.5 / (1 << 21), 0.0) == 2 and q(0.5 / (1 << 21), 0.0) == 0  # ties to even
-    assert q(30.0, 12.5) == int(17.5 * (1 << 21))
-    qz = lambda v, z0: L.pwo_ext_quantise_z(ctypes.c_float(v), z0, 21)
-    assert qz(-1.75, -1.75) == 0 and qz(1e30, -1.75) == 1 << 26 and qz(-1e30, -1.75) == -(1 << 26)
-    assert qz(float("inf"), 0.0) == 1 << 26 and qz(float("-inf"), 0.0) == -(1 << 26)
+    assert sh1 == 26 and not ox1.any() and not oy1.any()  # one sector per ring: the sensor is the origin
+    for s in (21, 30):
+        q = lambda v, o: L.pwo_ext_quantise(ctypes.c_float(v), o, s)
+        assert q(1.0, 0.0) == 1 << s and q(-1.0, 0.0) == -(1 << s) and q(10.125, 10.125) == 0
+        assert q(1.5 / (1 << s), 0.0) == 2 and q(2.5 / (1 << s), 0.0) == 2 and q(0.5 / (1 << s), 0.0) == 0  # ties to even
+        assert q(-1.5 / (1 << s), 0.0) == -2 and q(-2.5 / (1 << s), 0.0) == -2 and q(-0.5 / (1 << s), 0.0) == 0
+        assert q(30.0, 12.5) == int(17.5 * (1 << s))
+        # ONE rounding of the exact value: a hair above / below a tie next to a large origin (two roundings in double would tie)
+        tie = np.float32(0.5 / (1 << s))
+        up, dn = np.nextafter(tie, np.float32(1.0)), np.nextafter(tie, np.float32(0.0))
+        assert q(float(tie), 12.5) == -int(12.5 * (1 << s)) and q(float(up), 12.5) == -int(12.5 * (1 << s)) + 1 and q(float(dn), 12.5) == -int(12.5 * (1 << s))
+        assert q(float(np.float32(1e-30)), 3.0) == -(3 << s) and q(0.0, 3.0) == -(3 << s) and q(float(np.float32(-1e-42)), -3.0) == 3 << s
+        qz = lambda v, z0: L.pwo_ext_quantise_z(ctypes.c_float(v), z0, s, 32.0)
+        top = 32 << s
+        assert qz(-1.75, -1.75) == 0 and qz(1e30, -1.75) == top and qz(-1e30, -1.75) == -top
+        assert qz(float("inf"), 0.0) == top and qz(float("-inf"), 0.0) == -top and qz(float("nan"), 0.0) == -top
+    # v4: every float of magnitude >= 2^-7 m is on the grid -- Q * 2^-30 + origin gives the float back exactly
+    rng = np.random.default_rng(5)
+    for v in np.concatenate([rng.uniform(-30, 30, 200), rng.uniform(-1, 1, 200) * 2.0 ** -6, [2.0 ** -7, -2.0 ** -7]]).astype(np.float32):
+        if abs(v) >= 2.0 ** -7:
+            assert L.pwo_ext_quantise(ctypes.c_float(float(v)), 1.625, 30) == int(round((float(v) - 1.625) * (1 << 30)))
+            assert (L.pwo_ext_quantise(ctypes.c_float(float(v)), 1.625, 30) / (1 << 30)) + 1.625 == float(v)
     assert L.pwo_ext_z_origin(-1.73) == -1.75 and L.pwo_ext_z_origin(float("nan")) == 0.0
     assert L.pwo_ext_z_origin(float("inf")) == 0.0 and L.pwo_ext_z_origin(1e9) == 4096.0

@@ -1,5 +1,6 @@
-"""how often does the product's arithmetic contract (fixed-point sums; the HIP path equals its CPU restatement bit
-for bit -- asserted by the GPU suite) give exactly the ground set of the reference's own patchworkpp.cpp?  CPU only.
+"""How often does the product's arithmetic contract (exact integer moments on a 2^-30 m grid, contract v4; the HIP path equals its CPU
+restatement bit for bit -- asserted by the GPU suite) give exactly the ground set of the reference's own patchworkpp.cpp?  CPU only.
+(The 2^-21 m grid of rounds 3-5, contract v3, rides along as a witness: `contract_v3_*` in the report.)
 
 Three populations, each frame through the restatement (ARITH_FXP) and through the THREE builds of the reference under oracle/_ref
 (float sums in storage order, float sums in a 4-lane order, double sums rounded once):
@@ -44,6 +45,7 @@ def judge_frame(sets, mine):
     ref = sets
     agree = np.array_equal(ref["eigen_f32"], ref["f32_packet4"]) and np.array_equal(ref["eigen_f32"], ref["exact_f64"])
     return {"agree": bool(agree), "vs_exact": int(np.setxor1d(mine, ref["exact_f64"]).size), "vs_f32": int(np.setxor1d(mine, ref["eigen_f32"]).size),
+            "v3_vs_exact": int(np.setxor1d(ref["fxp21"], ref["exact_f64"]).size), "vs_pk4": int(np.setxor1d(mine, ref["f32_packet4"]).size),
             "f32_vs_exact": int(np.setxor1d(ref["eigen_f32"], ref["exact_f64"]).size), "pk4_vs_exact": int(np.setxor1d(ref["f32_packet4"], ref["exact_f64"]).size)}
 
 
@@ -53,7 +55,7 @@ def fresh_job(args):
     rs = ol.restatement()
     prm = (lambda lib: dense_params(lib)) if kind == "dense" else (lambda lib: None)
     mine = np.sort(ol.Estimator(rs, prm(rs), arith=ol.ARITH_FXP).run(pts).ground_idx)
-    sets = {}
+    sets = {"fxp21": np.sort(ol.Estimator(rs, prm(rs), arith=ol.ARITH_FXP21).run(pts).ground_idx)}  # (rounds 3-5's grid: a witness)
     for name, a in FLAV:
         lib = ol.reference(a)
         sets[name] = np.sort(ol.Estimator(lib, prm(lib), arith=a).run(pts).ground_idx)
@@ -65,14 +67,14 @@ def fresh_job(args):
 def seq_job(args):
     s, length = args
     rs = ol.restatement()
-    est = {"mine": ol.Estimator(rs, arith=ol.ARITH_FXP)}
+    est = {"mine": ol.Estimator(rs, arith=ol.ARITH_FXP), "fxp21": ol.Estimator(rs, arith=ol.ARITH_FXP21)}
     for name, a in FLAV:
         est[name] = ol.Estimator(ol.reference(a), arith=a)
     rows, hmax = [], 0.0
     for t in range(length):
         pts = pwpp_synth.varied_frame(100_000 + 1000 * s + t)
         out = {k: e.run(pts) for k, e in est.items()}
-        sets = {k: np.sort(out[k].ground_idx) for k, _ in FLAV}
+        sets = {k: np.sort(out[k].ground_idx) for k in [n for n, _ in FLAV] + ["fxp21"]}
         r = judge_frame(sets, np.sort(out["mine"].ground_idx))
         r.update(seq=s, t=t, points=int(pts.shape[0]))
         hmax = max(hmax, abs(out["mine"].sensor_height - out["exact_f64"].sensor_height))
@@ -92,7 +94,14 @@ def summarise(rows, what):
            "split_rate": len(split) / max(len(rows), 1), "split_rate_ci95": wilson(len(split), len(rows)),
            "contract_equals_unanimous_reference": eq, "rate": eq / max(len(cons), 1), "rate_ci95": wilson(eq, len(cons)),
            "misses": miss, "largest_miss_indices": max([m["vs_exact"] for m in miss], default=0),
+           "contract_v3_2e-21_grid_equals_unanimous_reference": sum(1 for r in cons if r["v3_vs_exact"] == 0),
+           "contract_v3_equals_exact_on_split": sum(1 for r in split if r["v3_vs_exact"] == 0),
            "contract_equals_exact_on_split": sum(1 for r in split if r["vs_exact"] == 0),
+           # (fit sets of 1-3 points follow the reference's own float arithmetic, determinate there: on such frames BOTH float builds agree with
+           # each other and with the contract, and the exact-f64 build -- double sums for those sets too -- is the odd one out)
+           "contract_equals_both_float_builds_on_split": sum(1 for r in split if r["vs_f32"] == 0 and r["vs_pk4"] == 0),
+           "contract_equals_some_reference_build_on_split": sum(1 for r in split if r["vs_exact"] == 0 or r["vs_f32"] == 0 or r["vs_pk4"] == 0),
+           "largest_distance_to_the_nearest_build_on_split": max([min(r["vs_exact"], r["vs_f32"], r["vs_pk4"]) for r in split], default=0),
            "contract_no_further_from_exact_than_the_float_builds_on_split": sum(1 for r in split if r["vs_exact"] <= max(r["f32_vs_exact"], r["pk4_vs_exact"])),
            "split_frames": [{k: r[k] for k in r if k != "agree"} for r in split][:60]}
     if rows and "height_vs_exact" in rows[0]:
@@ -108,7 +117,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=200)
     ap.add_argument("--dense", type=int, default=200)
     ap.add_argument("--workers", type=int, default=os.cpu_count() or 1)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_parity_statistics.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_parity_statistics.json"))
     a = ap.parse_args()
     ol.build()
     assert all(ol.reference(x) is not None for _, x in FLAV), "oracle/_ref is not built (make -C oracle, needs /root/reference)"
