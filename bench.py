@@ -404,23 +404,19 @@ def streams_leg(pwpp_hip, torch, dev, gpu_index, src_dev, ns_src, counts=(1, 64,
             row["gpu_us_min_max"] = [min(gpu), max(gpu)]
         out["by_streams"].append(row)
         h.close()
-    # 1024 streams as TWO groups of 512, one handle each, a lock-step of each group in flight (a stream's frames stay in order: its
-    # group's handle finishes frame t before it launches frame t + 1; the two groups are different sensors)
+    # 1024 streams as TWO groups of 512 through the library's pipe in PWPP_MODE_STREAMS (round 6: pwpp_pipe_submit takes the mode;
+    # handle g of the pipe owns group g's streams, submit k carries group k mod 2 -- a stream's frames stay in order on its handle,
+    # and the lock-step of one group runs under the other's)
     S = 512
-    hs = [pwpp_hip.Handle(device=gpu_index) for _ in range(2)]
-    bs = []
-    for g, h in enumerate(hs):
-        h.set_num_streams(S)
-        bs.append([h.make_device_batch([src_dev[(g * S + s + t) % K].data_ptr() for s in range(S)], [ns_src[(g * S + s + t) % K] for s in range(S)]) for t in range(K)])
+    pipe = pwpp_hip.Pipe(device=gpu_index, depth=2)
+    pipe.set_num_streams(S)
+    bs = [[pipe.handle(g).make_device_batch([src_dev[(g * S + s + t) % K].data_ptr() for s in range(S)], [ns_src[(g * S + s + t) % K] for s in range(S)])
+           for t in range(K)] for g in range(2)]
 
     def run(n):
         for k in range(n):
-            g = k % 2
-            if k >= 2:
-                hs[g].synchronize()
-            hs[g].launch_device_batch(bs[g][(k // 2) % K], cols=4, mode=pwpp_hip.MODE_STREAMS)
-        for h in hs:
-            h.synchronize()
+            pipe.submit_device_batch(bs[k % 2][(k // 2) % K], cols=4, mode=pwpp_hip.MODE_STREAMS)
+        pipe.drain()
 
     run(24)
     torch.cuda.synchronize()
@@ -429,10 +425,12 @@ def streams_leg(pwpp_hip, torch, dev, gpu_index, src_dev, ns_src, counts=(1, 64,
     run(n)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    lock = [r for r in out["by_streams"] if r["streams"] == 2 * S]
     out["two_groups_in_flight"] = {"streams": 2 * S, "groups": 2, "frames_per_s": S * n / dt, "ms_per_lockstep_of_a_group": 1000.0 * dt / n,
-                                   "what": "two handles of 512 streams each, alternating: the lock-step of one group under the other's"}
-    for h in hs:
-        h.close()
+                                   "vs_lockstep_of_all": (S * n / dt) / lock[0]["frames_per_s"] if lock else None,
+                                   "what": "pwpp_pipe_* in PWPP_MODE_STREAMS, depth 2: two groups of 512 streams, one pipe handle each, alternating -- "
+                                           "against ONE handle stepping all 1024 streams in lock-step (by_streams)"}
+    pipe.close()
     return out
 
 

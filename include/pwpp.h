@@ -324,13 +324,18 @@ PWPP_API int pwpp_get_redo_stats(pwpp_handle *h, int64_t *frames_one_pass, int64
  * and returns that handle: the caller reads the results through the usual getters after pwpp_synchronize(handle), any time before
  * the handle comes round again.  The ramp-up of one batch (binning, nothing to overlap with) then runs under the ramp-down of
  * the one before (last plane fits, index lists): 2.32-2.46 instead of 2.49-2.63 ms per 1024-frame batch with depth 2
- * (profiles/r05_pipelined_batches.txt; depth 3: +0.5 %).  Fresh state per frame only (PWPP_MODE_FRESH: a stream's frames must
- * stay in order on ONE handle); `mem` as in pwpp_estimate_ground_batch (PWPP_MEM_DEVICE or PWPP_MEM_HOST_PINNED to stay
- * asynchronous).  depth 1..4. */
+ * (profiles/r05_pipelined_batches.txt; depth 3: +0.5 %).  `mem` as in pwpp_estimate_ground_batch (PWPP_MEM_DEVICE or
+ * PWPP_MEM_HOST_PINNED to stay asynchronous), `mode` likewise: PWPP_MODE_FRESH, or PWPP_MODE_STREAMS (round 6) for stateful streams
+ * in disjoint GROUPS -- a stream's frames must stay in order on ONE handle, so handle g owns the streams of group g
+ * (pwpp_pipe_set_num_streams sizes every handle's group) and the caller submits the groups round robin: submit k carries the next
+ * frames of group k mod depth (reference use: demo_sequential.cpp:54-67, one long-lived object per stream).  depth 1..4.
+ * The handles belong to the pipe: a pointer from pwpp_pipe_handle / pwpp_pipe_submit is INVALID after pwpp_pipe_destroy. */
 typedef struct pwpp_pipe pwpp_pipe;
 PWPP_API int pwpp_pipe_create(const pwpp_params *p, int device, int depth, pwpp_pipe **out);
 PWPP_API int pwpp_pipe_submit(pwpp_pipe *pipe, const float *const *points, const int32_t *n, int frames, int cols, int layout, int mem,
-                              pwpp_handle **holder);
+                              int mode, pwpp_handle **holder);
+/* pwpp_set_num_streams(streams_per_handle) on every handle of the pipe: `depth` groups of that many fresh streams */
+PWPP_API int pwpp_pipe_set_num_streams(pwpp_pipe *pipe, int streams_per_handle);
 /* waits for every batch in flight */
 PWPP_API int pwpp_pipe_drain(pwpp_pipe *pipe);
 /* the pipe's handles (options, statistics, getters): index 0 .. depth - 1; NULL beyond */

@@ -851,6 +851,13 @@ int finish_pending(pwpp_handle *h) {
             // slots (a table built from much smaller frames) sends the whole batch through the compact layout.
             const int NP = PWPP_NUM_PARTS(h->dp.num_bins);
             bool in_place = !h->redo_whole_batch;
+            {   //  every run of neighbouring frames is a pipeline of its own -- four memsets and ten small launches, one after
+                // the other on one stream.  A cold or out-of-distribution batch with overflows all over it (353 of 512 frames once) is
+                // cheaper as ONE whole-batch redo on the two-pass path (~2.5 ms per 1024 frames) than as hundreds of those.
+                size_t runs = 0;
+                for (size_t i = 0; i < redo.size(); ++i) runs += i == 0 || redo[i] != redo[i - 1] + 1;
+                if (runs > 16 && (redo.size() > (size_t)h->frames / 8 || runs > 64)) in_place = false;
+            }
             for (int f : redo) {
                 const int64_t need = (int64_t)h->descs[(size_t)f].n + (int64_t)(PWPP_SLOT_ALIGN - 1) * NP + PWPP_SLOT_ALIGN;
                 if (need > h->slots_per_frame) in_place = false;
@@ -1069,7 +1076,10 @@ int pwpp_create(const pwpp_params *p, int device, pwpp_handle **out) {
     h->device = device;
     // The tuning / test switches: read once, here (not in the launch path), and said out loud.
     if (const char *e = std::getenv("PWPP_DEBUG_FLAGS")) h->debug_flags = std::atoi(e);
-    if ((h->debug_flags & 4) && (h->debug_flags & 8)) h->debug_flags &= ~8;  // (the two sets of timing probes share one array: the fit chain's win)
+    if ((h->debug_flags & 4) && (h->debug_flags & 8)) {  // (the two sets of timing probes share one array: pwpp_set_option refuses the pair, the environment path says what it does)
+        h->debug_flags &= ~8;
+        std::fprintf(stderr, "pwpp: PWPP_DEBUG_FLAGS has both timing-probe sets (4 and 8), which share one array: 8 dropped\n");
+    }
     if (const char *e = std::getenv("PWPP_FIT_PLAN")) h->fit_plan = e;
     h->fit_concurrent = std::getenv("PWPP_FIT_CONCURRENT") != nullptr;
     h->no_one_pass = std::getenv("PWPP_NO_ONE_PASS") != nullptr;
@@ -1804,6 +1814,10 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
         int n = 0, mode = 0;
         if (std::sscanf(value, "%d:%d", &n, &mode) < 1 || n < 0 || n >= 256 || (mode != 0 && mode != 1))
             return fail(PWPP_E_ARG, "cu_split=%s: N or N:mode with 0 <= N < 256, mode 0 or 1 expected", value);
+        //  mode 1 deals whole groups of 32 CUs: (i mod 8) < N / 32 is empty below 32 and everything at 256 -- an all-zero
+        // CU mask is not a stream the runtime can create
+        if (mode == 1 && n != 0 && (n % 32 != 0 || n < 32 || n > 224))
+            return fail(PWPP_E_ARG, "cu_split=%s: mode 1 takes N = 32, 64, ... 224 (whole groups of 32 CUs)", value);
         sync_all_streams(h);
         for (hipStream_t st : h->masked_fit) (void)hipStreamDestroy(st);
         h->masked_fit.clear();
@@ -1816,6 +1830,15 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
             for (int i = 0; i < 256; ++i) {
                 const bool to_mem = mode == 0 ? i < n : (i % 8) < n / 32;
                 (to_mem ? mm : mf)[i / 32] |= 1u << (i % 32);
+            }
+            bool mem_empty = true, fit_empty = true;
+            for (int w = 0; w < 8; ++w) {
+                mem_empty = mem_empty && mm[w] == 0u;
+                fit_empty = fit_empty && mf[w] == 0u;
+            }
+            if (mem_empty || fit_empty) {
+                h->cu_split_mem = 0;
+                return fail(PWPP_E_ARG, "cu_split=%s: one of the two CU masks comes out empty", value);
             }
             HIPCHK(hipExtStreamCreateWithCUMask(&h->masked_mem, 8, mm));
             for (int k2 = 0; k2 < 8; ++k2) {
@@ -2017,11 +2040,23 @@ int pwpp_pipe_create(const pwpp_params *p, int device, int depth, pwpp_pipe **ou
     return PWPP_OK;
 }
 
-int pwpp_pipe_submit(pwpp_pipe *pipe, const float *const *points, const int32_t *n, int frames, int cols, int layout, int mem, pwpp_handle **holder) {
+int pwpp_pipe_set_num_streams(pwpp_pipe *pipe, int streams_per_handle) {
+    if (!pipe || pipe->handles.empty()) return fail(PWPP_E_ARG, "null pipe");
+    for (pwpp_handle *h : pipe->handles) {
+        const int rc = pwpp_set_num_streams(h, streams_per_handle);
+        if (rc) return rc;
+    }
+    return PWPP_OK;
+}
+
+int pwpp_pipe_submit(pwpp_pipe *pipe, const float *const *points, const int32_t *n, int frames, int cols, int layout, int mem, int mode,
+                     pwpp_handle **holder) {
     if (!pipe || pipe->handles.empty()) return fail(PWPP_E_ARG, "null pipe");
     pwpp_handle *h = pipe->handles[(size_t)(pipe->submits % pipe->handles.size())];
-    // (pwpp_estimate_ground_batch first waits for this handle's own batch in flight: the one submitted `depth` submits ago)
-    const int rc = pwpp_estimate_ground_batch(h, points, n, frames, cols, layout, mem, PWPP_MODE_FRESH);
+    // (pwpp_estimate_ground_batch first waits for this handle's own batch in flight: the one submitted `depth` submits ago.
+    // PWPP_MODE_STREAMS: the handle owns the streams of ITS group -- submit k carries group k mod depth, so a stream's frames
+    // stay in order on one handle; the mode is checked there, together with the stream count)
+    const int rc = pwpp_estimate_ground_batch(h, points, n, frames, cols, layout, mem, mode);
     if (rc) return rc;
     ++pipe->submits;
     if (holder) *holder = h;

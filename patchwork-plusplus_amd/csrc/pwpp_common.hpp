@@ -353,13 +353,18 @@ struct MomentsT<true> {
         hh[3] += (long long)hy * hy;
         hh[4] += (long long)hy * hz;
         hh[5] += (long long)hz * hz;
+        // (two chained multiply-adds per mixed pair: the barrier keeps the compiler from forming a * b + c * d on the side and
+        // adding that to the accumulator with a third instruction)
         hl[0] += (long long)hx * lx;
         hl[1] += (long long)hx * ly;
+        asm volatile("" : "+v"(hl[1]));
         hl[1] += (long long)hy * lx;
         hl[2] += (long long)hx * lz;
+        asm volatile("" : "+v"(hl[2]));
         hl[2] += (long long)hz * lx;
         hl[3] += (long long)hy * ly;
         hl[4] += (long long)hy * lz;
+        asm volatile("" : "+v"(hl[4]));
         hl[4] += (long long)hz * ly;
         hl[5] += (long long)hz * lz;
         ll[0] += __umul24((unsigned)lx, (unsigned)lx);

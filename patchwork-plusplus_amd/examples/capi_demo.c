@@ -63,30 +63,59 @@ int main(int argc, char **argv) {
 
     /* Batches in flight (pwpp_pipe_*, no reference counterpart): four batches of three independent frames through a pipe of depth 2.
      * From pageable host memory a submit returns with the batch done (PWPP_MEM_HOST); device or pinned buffers make it asynchronous
-     * and the two handles overlap.  The handle a submit returns holds that batch until it comes round again. */
+     * and the two handles overlap.  The handle a submit returns holds that batch until it comes round again -- and belongs to the
+     * pipe: it is gone after pwpp_pipe_destroy. */
     {
         pwpp_pipe *pipe = NULL;
         const float *frames[3];
         int32_t ns[3];
-        int k, same = 1;
+        int k, same = 1, bad = 0;
         frames[0] = frames[1] = frames[2] = pts;
         ns[0] = ns[1] = ns[2] = n;
         if (pwpp_pipe_create(&params, 0, 2, &pipe) != PWPP_OK) return fail("pwpp_pipe_create");
-        for (k = 0; k < 4; ++k) {
+        for (k = 0; k < 4 && !bad; ++k) {
             pwpp_handle *holder = NULL;
             int32_t g = 0, ng = 0, np = 0;
             int fr;
-            if (pwpp_pipe_submit(pipe, frames, ns, 3, 4, PWPP_LAYOUT_ROW_MAJOR, PWPP_MEM_HOST, &holder) != PWPP_OK) return fail("pwpp_pipe_submit");
-            if (pwpp_synchronize(holder) != PWPP_OK) return fail("pwpp_synchronize");
-            if (holder != pwpp_pipe_handle(pipe, k % 2)) same = 0;
-            for (fr = 0; fr < 3; ++fr) {
-                if (pwpp_get_counts(holder, fr, &g, &ng, &np) != PWPP_OK) return fail("pwpp_get_counts");
+            if (pwpp_pipe_submit(pipe, frames, ns, 3, 4, PWPP_LAYOUT_ROW_MAJOR, PWPP_MEM_HOST, PWPP_MODE_FRESH, &holder) != PWPP_OK) bad = fail("pwpp_pipe_submit");
+            if (!bad && pwpp_synchronize(holder) != PWPP_OK) bad = fail("pwpp_synchronize");
+            if (!bad && holder != pwpp_pipe_handle(pipe, k % 2)) same = 0;
+            for (fr = 0; fr < 3 && !bad; ++fr) {
+                if (pwpp_get_counts(holder, fr, &g, &ng, &np) != PWPP_OK) bad = fail("pwpp_get_counts");
                 if (g != n_ground || ng != n_nonground || np != n_patches) same = 0;
             }
         }
-        if (pwpp_pipe_drain(pipe) != PWPP_OK) return fail("pwpp_pipe_drain");
-        printf("pipe depth 2: 4 batches of 3 frames, every frame %s the single call\n", same ? "equal to" : "DIFFERENT FROM");
-        pwpp_pipe_destroy(pipe);
+        if (!bad && pwpp_pipe_drain(pipe) != PWPP_OK) bad = fail("pwpp_pipe_drain");
+        if (!bad) printf("pipe depth 2: 4 batches of 3 frames, every frame %s the single call\n", same ? "equal to" : "DIFFERENT FROM");
+
+        /* The same pipe in PWPP_MODE_STREAMS (the reference's real use, demo_sequential.cpp:54-67: one long-lived object per sensor):
+         * two GROUPS of two stateful streams, handle g owns group g, submit k carries the next frame of every stream of group k mod 2.
+         * Every stream sees the same frame three times, so all four must end at the sensor height one handle reaches on its own. */
+        if (!bad) {
+            pwpp_handle *one = NULL;
+            double want = 0.0;
+            int step, ok = 1;
+            if (pwpp_create(&params, 0, &one) != PWPP_OK) bad = fail("pwpp_create");
+            for (step = 0; step < 3 && !bad; ++step)
+                if (pwpp_estimate_ground(one, pts, n, 4, PWPP_LAYOUT_ROW_MAJOR) != PWPP_OK) bad = fail("pwpp_estimate_ground");
+            if (!bad) want = pwpp_get_height(one);
+            pwpp_destroy(one);
+            if (!bad && pwpp_pipe_set_num_streams(pipe, 2) != PWPP_OK) bad = fail("pwpp_pipe_set_num_streams");
+            for (k = 0; k < 6 && !bad; ++k)  /* three steps of each of the two groups */
+                if (pwpp_pipe_submit(pipe, frames, ns, 2, 4, PWPP_LAYOUT_ROW_MAJOR, PWPP_MEM_HOST, PWPP_MODE_STREAMS, NULL) != PWPP_OK) bad = fail("pwpp_pipe_submit (streams)");
+            if (!bad && pwpp_pipe_drain(pipe) != PWPP_OK) bad = fail("pwpp_pipe_drain");
+            for (k = 0; k < 2 && !bad; ++k) {
+                pwpp_state st[2];
+                if (pwpp_get_state(pwpp_pipe_handle(pipe, k), 0, &st[0]) != PWPP_OK || pwpp_get_state(pwpp_pipe_handle(pipe, k), 1, &st[1]) != PWPP_OK) bad = fail("pwpp_get_state");
+                else if (st[0].sensor_height != want || st[1].sensor_height != want) ok = 0;
+            }
+            if (!bad) printf("pipe in stream mode: 2 groups of 2 streams, 3 steps each, every stream %s one handle's sensor height %.6f\n", ok ? "at" : "AWAY FROM", want);
+        }
+        pwpp_pipe_destroy(pipe); /* (also on the error paths above: the pipe owns two handles and their workspaces) */
+        if (bad) {
+            free(pts);
+            return bad;
+        }
     }
     free(pts);
     return 0;

@@ -116,7 +116,8 @@ def load():
         L.pwpp_get_one_pass_stats.argtypes = [vp, vp, vp]
         L.pwpp_get_redo_stats.argtypes = [vp, vp, vp]
         L.pwpp_pipe_create.argtypes = [vp, ci, ci, ctypes.POINTER(vp)]
-        L.pwpp_pipe_submit.argtypes = [vp, vp, vp, ci, ci, ci, ci, ctypes.POINTER(vp)]
+        L.pwpp_pipe_submit.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ctypes.POINTER(vp)]
+        L.pwpp_pipe_set_num_streams.argtypes = [vp, ci]
         L.pwpp_pipe_drain.argtypes = [vp]
         L.pwpp_pipe_handle.argtypes = [vp, ci]
         L.pwpp_pipe_handle.restype = vp
@@ -458,6 +459,7 @@ class Pipe:
         if key not in self._views:
             v = Handle.__new__(Handle)  # a view: the pipe owns the handle
             v._L, v.params, v._h, v._keep, v._borrowed = self._L, self.params, ctypes.c_void_p(key), None, True
+            v._pipe = self  #  a view keeps its pipe alive: the pipe owns the handle the view points at
             self._views[key] = v
         return self._views[key]
 
@@ -465,10 +467,17 @@ class Pipe:
         raw = self._L.pwpp_pipe_handle(self._p, index)
         return self._view(ctypes.c_void_p(raw)) if raw else None
 
-    def submit_device_batch(self, batch, cols=4, layout=LAYOUT_ROW_MAJOR):
+    def set_num_streams(self, streams_per_handle):
+        """MODE_STREAMS through the pipe: every handle owns one GROUP of `streams_per_handle` streams; submit k must carry the next
+        frames of group k mod depth."""
+        rc = self._L.pwpp_pipe_set_num_streams(self._p, streams_per_handle)
+        if rc < 0:
+            raise PwppError("pwpp error %d: %s" % (rc, self._L.pwpp_last_error().decode()))
+
+    def submit_device_batch(self, batch, cols=4, layout=LAYOUT_ROW_MAJOR, mode=MODE_FRESH):
         cp, cn, k = batch
         holder = ctypes.c_void_p()
-        rc = self._L.pwpp_pipe_submit(self._p, cp, cn, k, cols, layout, MEM_DEVICE, ctypes.byref(holder))
+        rc = self._L.pwpp_pipe_submit(self._p, cp, cn, k, cols, layout, MEM_DEVICE, mode, ctypes.byref(holder))
         if rc < 0:
             raise PwppError("pwpp error %d: %s" % (rc, self._L.pwpp_last_error().decode()))
         return self._view(holder)
@@ -483,6 +492,9 @@ class Pipe:
 
     def close(self):
         if self._p is not None:
+            for v in self._views.values():  #  the views' handles die with the pipe: a getter on one must fail, not crash
+                v._h = None
+                v._pipe = None
             self._L.pwpp_pipe_destroy(self._p)
             self._p = None
             self._views = {}

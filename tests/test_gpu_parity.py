@@ -577,6 +577,7 @@ def test_c_abi_demo_program(kitti, golden, tmp_path):
     assert [int(m.group(2)), int(m.group(3)), int(m.group(4))] == list(golden["f32/seq/0/counts"])
     assert abs(float(m.group(5)) - golden["f32/seq/0/state"][0]) < 1e-4
     assert "pipe depth 2: 4 batches of 3 frames, every frame equal to the single call" in out  # (pwpp_pipe_* from C)
+    assert re.search(r"pipe in stream mode: 2 groups of 2 streams, 3 steps each, every stream at one handle's sensor height", out), out
 
 
 def test_one_pass_binning_and_its_overflow_fallback(kitti, oracle):
@@ -1176,7 +1177,10 @@ def test_schedules_and_binning_variants_give_one_result(kitti, oracle):
     assert_frame_equal(holders[3], 77, refs[(77 + 3) % 6], frames_b[77].shape[0], check_state=False)  # batch b
     with pytest.raises(pwpp_hip.PwppError, match="depth"):
         pwpp_hip.Pipe(depth=9)
+    view = holders[4]
     pipe.close()
+    with pytest.raises(pwpp_hip.PwppError):  #  a view of a closed pipe's handle fails, it does not touch the freed handle
+        view.counts(0)
     one = pwpp_hip.Handle()
     for flags in (0, 256, 0):
         one.set_option("debug_flags", flags)
@@ -1681,3 +1685,38 @@ def test_rccl_code_path_with_a_single_rank_group():
                          text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     assert "aggregate (1.5, 7)" in out.stdout and "gather [3.25]" in out.stdout and "rccl single-rank ok" in out.stdout
+
+
+def test_pipe_in_stream_mode(kitti, oracle):
+    """pwpp_pipe_submit with PWPP_MODE_STREAMS (round 6): two groups of stateful streams, handle g of the pipe owns group g, submit k
+    carries the next frames of group k mod 2 -- batches in flight for the reference's real use (one long-lived object per sensor,
+    demo_sequential.cpp:54-67).  Every stream against its own sequential run of the restatement: lists, planes, state, histories.
+    Small groups (3 streams: the latency plan) and groups of 70 (the throughput kernels with stream state)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    bufs = [torch.from_numpy(f).to(dev) for f in kitti]
+    for S, T in ((3, 4), (70, 3)):
+        pipe = pwpp_hip.Pipe(depth=2)
+        pipe.set_num_streams(S)
+        ests = [[ol.Estimator(oracle, arith=ol.ARITH_FXP) for _ in range(S)] for _ in range(2)]
+        src = lambda g, s, t: (5 * g + s + t) % 6
+        batches = [[pipe.handle(g).make_device_batch([bufs[src(g, s, t)].data_ptr() for s in range(S)], [kitti[src(g, s, t)].shape[0] for s in range(S)])
+                    for t in range(T)] for g in range(2)]
+        with pytest.raises(pwpp_hip.PwppError, match="streams"):  # a group larger than the handle's stream count
+            pipe.submit_device_batch(pipe.handle(0).make_device_batch([bufs[0].data_ptr()] * (S + 1), [kitti[0].shape[0]] * (S + 1)), mode=pwpp_hip.MODE_STREAMS)
+        holders = []
+        for k in range(2 * T):  # all submits first: two lock-steps in flight
+            holders.append(pipe.submit_device_batch(batches[k % 2][k // 2], mode=pwpp_hip.MODE_STREAMS))
+            if k >= 1:  # the batch submitted one step ago is complete once its handle is synchronised; check it before it comes round again
+                g, t = (k - 1) % 2, (k - 1) // 2
+                hv = holders[k - 1]
+                hv.synchronize()
+                for s in (range(S) if S <= 8 else (0, 1, S // 2, S - 1)):
+                    while len(getattr(ests[g][s], "_done", [])) <= t:
+                        done = getattr(ests[g][s], "_done", [])
+                        done.append(ests[g][s].run(kitti[src(g, s, len(done))]))
+                        ests[g][s]._done = done
+                    assert_frame_equal(hv, s, ests[g][s]._done[t], kitti[src(g, s, t)].shape[0], state_index=s)
+        pipe.drain()
+        assert holders[0]._h.value == holders[2]._h.value != holders[1]._h.value
+        pipe.close()
