@@ -60,7 +60,9 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        const size_t want = n + n / 8 + 64;
+        // (head-room so that sizes creeping up do not reallocate every call: an eighth, at most 4 M elements -- an eighth of the
+        // bin-ordered planes of a 1024-frame batch was 0.7 GB of nothing)
+        const size_t want = n + (n / 8 < ((size_t)4 << 20) ? n / 8 : ((size_t)4 << 20)) + 64;
         hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
         if (e != hipSuccess) return fail(PWPP_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
         cap = want;
@@ -150,7 +152,9 @@ struct pwpp_handle {
     // one-pass binning (fixed bin segments, DESIGN.md section 3 K1'): state of the batch in flight
     bool one_pass = false;           // the batch in flight uses fixed segments; overflow flags are checked when it lands
     int one_pass_holdoff = 0;        // batches to run on the two-pass path after an overflow
-    int64_t slots_per_frame = 0;     // of the current capacity table
+    int64_t slots_per_frame = 0;     // of the current capacity table: the parts' segments + the frame's overflow arena
+    uint32_t arena_base = 0, arena_slots = 0, arena_spill = 0;  // the arena of the current table (pwpp_dev.h): first slot, slots (0: none), room for spilled records
+    DevBuf<uint2> d_arena_tag;       // [frames][arena_spill]
     int cap_max_n = -1;              // largest frame the capacity table on the device was built for
     bool cap_few = false;            // ... and whether it was built with the head-room of calls of a few frames
     int max_n = 0;
@@ -407,40 +411,56 @@ int grow_stream_histories(pwpp_handle *h, int new_cap) {
     return PWPP_OK;
 }
 
-// Segment sizes of the one-pass path.  A bin's segment holds 1.5 x the largest count that bin has had in any frame
-// this handle has seen (d_bin_max, kept by k_czm_scan; before the first batch a histogram of a few sample frames
-// fills it: probe_histogram) plus 256 slots -- ~2.7 slots per point of a KITTI frame, 54 B per point.  (Round 1
-// gave every bin 4 x its even share of its zone and the two pseudo-bins a whole frame each: 20 slots, 410 B per
-// point, 52 GB for the 1024-frame batch.)  one_pass_scale scales the 1.5 (tests use a tiny one to force overflows).
-// A bin that outgrows its segment raises the frame's overflow flag; the batch is then redone on the exact two-pass
-// path, whose counts enter d_bin_max, and the table is rebuilt.
+// Segment sizes of the one-pass path.  Round 6: a part's segment holds 1.125 x the largest count that part has had in any frame
+// this handle has seen (d_bin_max, kept by k_czm_scan; before the first batch a histogram of up to 256 sample frames fills it:
+// probe_histogram) + 4 sqrt(that) + 32 slots, and every frame has an OVERFLOW ARENA behind its segments (pwpp_dev.h): a part that
+// outgrows its segment is moved there by k_czm_scan, on the device, at the cost of a copy of that part -- ~1.5 slots per point of a
+// KITTI frame, 24 B per point.  (Rounds 2-5: 1.5 x + 256 slots and no arena -- 2.7 slots per point, every overflow a frame binned
+// twice by the host; round 1: 20 slots per point.)  one_pass_scale scales the 1.125 (tests use a tiny one to force overflows).
+// A frame whose arena runs out raises the overflow flag and is binned again on the exact two-pass path, whose counts enter
+// d_bin_max, and the table is rebuilt.
 int build_capacity_table(pwpp_handle *h, int max_n) {
     const PwppDevParams &P = h->dp;
     const int NB = PWPP_NUM_PARTS(P.num_bins);  // one segment per part
     // A FEW frames per call (a single sensor's stream, the reference's own use): memory is no concern there (2 048 slots more per part
-    // are 40 MB per frame), but every overflow is a frame binned twice, and a handle that has seen a handful of frames knows little
-    // about its bins -- 2.5 x the head-room (round 5: 43 of 180 frames of six varied streams were redone with the batch table).
+    // are 40 MB per frame), but every overflow is a frame binned twice (the fused binning + scan kernel of fewer than eight frames has
+    // no arena), and a handle that has seen a handful of frames knows little about its bins -- 3.75 x the largest count + 2048.
     const bool few = h->frames <= 16 && h->one_pass_scale >= 1.0;
     h->cap_few = few;
-    const double scale = (few ? 3.75 : 1.5) * h->one_pass_scale / 4.0;
+    const double scale = (few ? 3.75 : 1.125) * h->one_pass_scale / 4.0;
     std::vector<uint32_t> off((size_t)NB + 1);
     h->cap_table.assign((size_t)NB, 0u);
     uint64_t run = 0;
     for (int b = 0; b < NB; ++b) {
         off[(size_t)b] = (uint32_t)run;
-        double cap = scale * (double)h->observed[(size_t)b] + (h->one_pass_scale >= 1.0 ? (few ? 2048.0 : 256.0) : 16.0);
+        const double seen = (double)h->observed[(size_t)b];
+        double cap = scale * seen + (h->one_pass_scale >= 1.0 ? (few ? 2048.0 : 4.0 * std::sqrt(seen) + 32.0) : 16.0);
         if (cap > (double)max_n + 16.0) cap = (double)max_n + 16.0;
         uint64_t c = ((uint64_t)cap + (PWPP_SLOT_ALIGN - 1)) & ~(uint64_t)(PWPP_SLOT_ALIGN - 1);
         if (b < 2 * P.num_bins && (b & 1) && b / 2 >= P.split_end) c = 0;  // the high part of a bin that is not split: never used
         h->cap_table[(size_t)b] = (uint32_t)c;
         run += c;
-        if (run >= ((uint64_t)1 << 32)) return fail(PWPP_E_NOMEM, "one-pass capacity table overflows 32-bit offsets");
+        if (run >= ((uint64_t)1 << 31)) return fail(PWPP_E_NOMEM, "one-pass capacity table overflows 31-bit offsets");
     }
     off[(size_t)NB] = (uint32_t)run;
+    // the arena: room for the largest part to move as a whole, plus a sixteenth of the largest frame -- 4 096 slots at least; a
+    // quarter of it (2 048 at least) may fill with spilled records
+    uint64_t arena = 0;
+    if (!few && !(h->debug_flags & 2048)) {  // (debug 2048: no arena -- rounds 2-5's behaviour on today's segments, for tests and A/B runs)
+        uint32_t biggest = 0;
+        for (int b = 0; b < NB; ++b) biggest = h->observed[(size_t)b] > biggest ? h->observed[(size_t)b] : biggest;
+        arena = (uint64_t)biggest + biggest / 4 + (uint64_t)max_n / 16 + 4096;
+        if (h->one_pass_scale < 1.0) arena = (uint64_t)((double)arena * h->one_pass_scale);  // (tests: a small arena overflows too)
+        arena = (arena + (PWPP_SLOT_ALIGN - 1)) & ~(uint64_t)(PWPP_SLOT_ALIGN - 1);
+        if (run + arena >= ((uint64_t)1 << 31)) arena = 0;
+    }
     int rc = h->d_cap_off.ensure((size_t)NB + 1);
     if (rc) return rc;
     HIPCHK(hipMemcpy(h->d_cap_off.p, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    h->slots_per_frame = (int64_t)run;
+    h->arena_base = (uint32_t)run;
+    h->arena_slots = (uint32_t)arena;
+    h->arena_spill = (uint32_t)(arena / 4 > 2048 ? arena / 4 : (arena < 2048 ? arena : 2048));
+    h->slots_per_frame = (int64_t)(run + arena);
     h->cap_max_n = max_n;
     h->table_stale = false;
     return PWPP_OK;
@@ -581,6 +601,9 @@ void fill_batch(pwpp_handle *h, PwppBatch &bt) {
     bt.dbg = h->d_dbg.p;
 
     bt.bin_max = h->d_bin_max.p;
+    bt.arena_base = 0xffffffffu;  // (launch_prepared sets the arena of a one-pass batch)
+    bt.arena_slots = bt.arena_spill = 0u;
+    bt.arena_tag = nullptr;
     {   // k_emit: one wave per bin copies a list of a few thousand entries well; the bins of a dense cloud get more
         uint32_t biggest = 0;  // (observed: per part; a bin's two parts are neighbours, the pseudo-bins the last two entries)
         for (size_t b = 0; b + 1 < h->observed.size(); b += 2) {
@@ -631,6 +654,7 @@ PwppBatch frame_range(const pwpp_handle *h, const PwppBatch &bt, int f0, int nf)
     v.results += f0;
     v.results_host += f0;
     if (v.order_work) v.order_work += (size_t)f0 * (size_t)(1 + 2 * NB);
+    if (v.arena_tag) v.arena_tag += (size_t)f0 * v.arena_spill;
     v.next_part_count += (size_t)f0 * NP;  // (the other copy: same frame, same slab stride)
     v.next_results += f0;
     return v;
@@ -646,7 +670,7 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     for (int f = 0; f < frames; ++f) {
         PwppFrameDesc &d = h->descs[(size_t)f];
         d.sbase = one_pass ? (int64_t)f * h->slots_per_frame : base;
-        d.mbase = d.sbase / 8 + (int64_t)PWPP_MEMBER_PAD * NP * f;  // (sbase is a multiple of PWPP_SLOT_ALIGN in both layouts)
+        d.mbase = d.sbase / 8 + (int64_t)2 * PWPP_MEMBER_PAD * NP * f;  // (sbase is a multiple of PWPP_SLOT_ALIGN in both layouts; a pad per part, and one more for a part moved into the arena)
         // compact layout: every part starts at a multiple of PWPP_SLOT_ALIGN slots (k_czm_scan)
         base += ((int64_t)d.n + (PWPP_SLOT_ALIGN - 1) * (int64_t)NP + (PWPP_SLOT_ALIGN - 1)) & ~(int64_t)(PWPP_SLOT_ALIGN - 1);
     }
@@ -675,6 +699,12 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     bt.no_clear = pre_cleared ? 1 : 0;
 
     bt.cap_off = one_pass ? h->d_cap_off.p : nullptr;
+    if (one_pass) {
+        bt.arena_base = h->arena_base;
+        bt.arena_slots = h->arena_slots;
+        bt.arena_spill = h->arena_spill;
+        bt.arena_tag = h->arena_slots ? h->d_arena_tag.p : nullptr;
+    }
     if (one_pass && h->mode == PWPP_MODE_STREAMS) {  // what a redo after a segment overflow starts from: copied by the binning kernel
         bt.snap_scalar = h->d_st_snap.p;
         bt.snap_hist = h->d_hist_snap.p;
@@ -930,6 +960,12 @@ int finish_pending(pwpp_handle *h) {
                 if (!(h->h_results.p[f].overflow & 2)) continue;
                 PwppBatch v = frame_range(h, bt, f, 1);
                 v.cap_off = was_one_pass && !h->frame_two_pass[(size_t)f] ? h->d_cap_off.p : nullptr;  // (a frame redone in place is in the compact layout)
+                if (v.cap_off) {  // (where its moved parts' bits live: pwpp_member_offset)
+                    v.arena_base = h->arena_base;
+                    v.arena_slots = h->arena_slots;
+                    v.arena_spill = h->arena_spill;
+                    v.arena_tag = h->arena_slots ? h->d_arena_tag.p + (size_t)f * h->arena_spill : nullptr;
+                }
                 const int lrc = pwpp_launch_pipeline(&v, h->stream, nullptr, nullptr, nullptr, nullptr, ordered ? h->d_ord_a.p : nullptr,
                                                      ordered ? h->d_ord_b.p : nullptr, 2 | 4 | 8);
                 if (lrc != 0) return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
@@ -1167,6 +1203,7 @@ int pwpp_destroy(pwpp_handle *h) {
     h->h_bin_max.release();
     h->d_frames_probe.release();
     h->d_member.release();
+    h->d_arena_tag.release();
     h->d_out.release();
     h->d_ord_a.release();
     h->d_ord_b.release();
@@ -1400,7 +1437,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     }
 
     // ---- 4. the bin-ordered buffers (slack: the fit kernels fetch whole chunks, up to 512 points beyond a patch's end)
-    const size_t member_pads = (size_t)frames * (size_t)NP * PWPP_MEMBER_PAD + 4096;
+    const size_t member_pads = (size_t)frames * (size_t)NP * 2 * PWPP_MEMBER_PAD + 4096;
     if (one_pass && (h->d_sorted_z.ensure(bin_slots + 1024) || h->d_sorted_xy.ensure(bin_slots + 1024) || h->d_sorted_idx.ensure(bin_slots) ||
                      h->d_member.ensure(bin_slots / 8 + member_pads))) {  // (the membership plane is part of the trial, not a hard error after it)
         one_pass = false;  // the big allocation failed after all (fragmentation): compact layout, two-pass binning
@@ -1411,6 +1448,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     if ((rc = h->d_sorted_xy.ensure(bin_slots + 1024))) return rc;
     if ((rc = h->d_sorted_idx.ensure(bin_slots))) return rc;
     if ((rc = h->d_member.ensure(bin_slots / 8 + member_pads))) return rc;
+    if (one_pass && h->arena_slots && (rc = h->d_arena_tag.ensure((size_t)frames * h->arena_spill))) return rc;
 
     h->frames = frames;
     h->mode = mode;
@@ -1915,7 +1953,7 @@ int64_t pwpp_get_workspace_bytes(pwpp_handle *h) {
     auto b = [](size_t cap, size_t elt) { return (int64_t)(cap * elt); };
     return b(h->d_frames.cap, sizeof(PwppFrameDesc)) + b(h->d_frames_probe.cap, sizeof(PwppFrameDesc)) + b(h->d_in.cap, 4) + b(h->d_codes.cap, 2) +
            b(h->d_sorted_z.cap, 4) + b(h->d_sorted_xy.cap, 8) + b(h->d_sorted_idx.cap, 4) + b(h->d_bin_origin.cap, 8) + b(h->d_bin_bbox.cap, 16) +
-           b(h->d_member.cap, 1) + b(h->d_out.cap, 4) + b(h->d_ord_a.cap, 8) + b(h->d_ord_b.cap, 8) + b(h->d_ord_work.cap, 4) + b(h->d_bins.cap, 4) + b(h->d_parts.cap, 4) +
+           b(h->d_member.cap, 1) + b(h->d_arena_tag.cap, 8) + b(h->d_out.cap, 4) + b(h->d_ord_a.cap, 8) + b(h->d_ord_b.cap, 8) + b(h->d_ord_work.cap, 4) + b(h->d_bins.cap, 4) + b(h->d_parts.cap, 4) +
            b(h->d_cls_start.cap, 4) + b(h->d_cap_off.cap, 4) + b(h->d_emit_long.cap, 1) + b(h->d_bin_max.cap, 4) + b(h->d_cls_list.cap, 2) +
            b(h->d_recs.cap, sizeof(PwppPatchRec)) + b(h->d_centers.cap, 4) + b(h->d_normals.cap, 4) + b(h->d_results.cap, sizeof(PwppFrameResult)) +
            b(h->d_xyz.cap, 4) + b(h->d_dbg.cap, 8) + b(h->d_st_stream.cap, sizeof(PwppStateScalar)) + b(h->d_st_fresh.cap, sizeof(PwppStateScalar)) +
@@ -1937,6 +1975,7 @@ int pwpp_trim_workspace(pwpp_handle *h) {
     h->d_sorted_xy.release();
     h->d_sorted_idx.release();
     h->d_member.release();
+    h->d_arena_tag.release();
     h->d_out.release();
     h->d_ord_a.release();
     h->d_ord_b.release();

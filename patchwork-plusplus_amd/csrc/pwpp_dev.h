@@ -34,6 +34,16 @@
 #define PWPP_PART_LO(bin) (2 * (bin))
 #define PWPP_PART_HI(bin) (2 * (bin) + 1)
 #define PWPP_NUM_PARTS(B) (2 * (B) + 2)
+// One-pass binning with an OVERFLOW ARENA (round 6): a part's fixed segment holds ~1.125 x the largest count the part has had, and
+// every frame owns PwppBatch.arena_slots more slots behind its segments.  A point whose part is full is written into the arena
+// instead (k_czm_bin_scatter reserves a run per workgroup with one atomic on the frame's cursor -- bits 8.. of PwppFrameResult.overflow
+// -- and tags the record with its part and its rank inside the part); k_czm_scan then MOVES every part that outgrew its segment into a
+// contiguous region of the arena behind the spilled records (the first `capacity` points from the segment, the others by their tags)
+// and points part_off at it: the fit kernels and k_emit see a contiguous part as always.  Only a frame whose arena runs out (or with
+// more than PWPP_MAX_RELOC overflowing parts) raises the overflow flag and is binned again by the host.  The bits of a moved part
+// live PWPP_MEMBER_PAD * parts bytes further on in the membership plane (the moved parts are placed in part order, so the plane's
+// "slot / 8 + pad * part" addressing stays collision-free): pwpp_member_offset.
+#define PWPP_MAX_RELOC 64
 #define PWPP_EMIT_LONG_BLOCKS 8   // blocks of 512 list entries the main wave of a "long" bin copies in k_emit; the rest goes to the extra waves
 #define PWPP_EMIT_LONG_MIN 8192   // a bin whose count has exceeded this in some frame of the handle is "long"
 
@@ -75,7 +85,7 @@ struct PwppFrameDesc {
     int32_t step;      // PWPP_LAYOUT_FIELDS: bytes from one point to the next (sensor_msgs/PointCloud2 point_step) ...
     int32_t off[4];    // ... and the byte offsets of x, y, z, intensity inside a point (intensity < 0: none)
     int32_t pad2_;
-    int64_t mbase;     // first byte of this frame in the membership plane (= sbase / 8 + PWPP_MEMBER_PAD * parts * frame index)
+    int64_t mbase;     // first byte of this frame in the membership plane (= sbase / 8 + 2 * PWPP_MEMBER_PAD * parts * frame index)
     int64_t sbase;     // first slot of this frame in the part-ordered buffers (sorted_*): compact on the two-pass
                        // path, frame * slots_per_frame on the one-pass path (see cap_off)
 };
@@ -115,10 +125,17 @@ struct PwppPatchRec {  // one per (frame, bin); written by k_patch_fit, finished
                     // fitted LAST (the patch before it, or the frame before): nothing was fitted yet, k_fit_fixup does it
 };
 
+// first byte of a part's bits in its frame's share of the membership plane (see PWPP_SLOT_ALIGN / the overflow arena above)
+__host__ __device__ inline uint32_t pwpp_member_offset(uint32_t off, int part, uint32_t arena_base, int num_parts) {
+    return (off >> 3) + (uint32_t)(PWPP_MEMBER_PAD * (part + (off >= arena_base ? num_parts : 0)));
+}
+
 struct PwppFrameResult {
     int32_t n_ground, n_nonground, n_patches, n_rnr, n_oor, n_dropped;
     int32_t hist_state;  // (entries of the fullest A-GLE history after this frame << 1) | a push found its slab full
-    int32_t overflow;  // bit 0: one-pass binning: some bin of this frame outgrew its segment (the batch is redone on the two-pass
+    int32_t overflow;  // (bits 8..: scratch of the binning kernels -- the fused scan's tickets, or the cursor of the frame's overflow arena;
+                       // zero again when k_czm_scan is done)
+                       // bit 0: one-pass binning: some bin of this frame outgrew its segment AND the arena (the batch is redone on the two-pass
                        // path); bit 1: some patch of the frame needs the plane fitted before it (PwppPatchRec.valid bit 2): K5 and K6
                        // leave the frame alone and the host runs k_fit_fixup + K5 + K6 for it when the batch lands; bit 2: the final
                        // ground set of some patch held a height outside z0 +- ZR (clamped before it was quantised: pwpp_get_clamped_frames)
@@ -139,7 +156,11 @@ struct PwppBatch {
     int32_t no_clear;            // the caller already launched k_clear for these frames (overlap mode: two frame ranges, two streams)
     int32_t fixup_run;           // this launch finishes frames whose patches needed the plane fitted before them (k_fit_fixup ran): K5 / K6 do not skip them
     const uint32_t *cap_off;     // one-pass binning: [2B+3] first slot of every PART's fixed segment inside a frame
-                                 // (cap_off[2B+2] = slots per frame); null on the two-pass path
+                                 // (cap_off[2B+2] = end of the segments = first slot of the frame's overflow arena); null on the two-pass path
+    uint32_t arena_base;         // = cap_off[2B+2] on the one-pass path, 0xffffffff otherwise (no part lies at or beyond it)
+    uint32_t arena_slots;        // slots of a frame's overflow arena (0: none -- a full segment raises the overflow flag as in rounds 1-5)
+    uint32_t arena_spill;        // ... of which the first arena_spill may hold spilled records (the tags' capacity); moved parts follow them
+    uint2 *arena_tag;            // [frames][arena_spill] {part, rank inside the part} of every spilled record
     PwppStateScalar *st_scalar;  // [num_states]
     double *st_hist;             // [num_states][2][4][hist_cap]
     PwppPlaneState *st_plane;    // [num_states] the plane members after the state's last frame (zero for a new object)

@@ -305,6 +305,8 @@ struct PatchRef {
     const int *idx;
     unsigned off_lo, n_lo, off_hi, n_hi;
     int bin;  // (names the bits of its two parts in the membership plane: member_offset)
+    unsigned arena_base;  // ... together with where the frame's overflow arena begins and the number of parts (pwpp_member_offset)
+    int num_parts;
 };
 // Chunks are numbered through the low part and then through the high part; a pass that skips the high part
 // (stage_needs_hi) simply finds no points in the chunks above the low part's.
@@ -313,7 +315,7 @@ struct PartSel {
     unsigned moff;       // first byte of the part's bits in the frame's share of the membership plane (only the passes that write them use it)
 };
 // membership plane (pwpp_dev.h, PWPP_SLOT_ALIGN): where the bits of a part begin, relative to the frame's first byte
-__device__ __forceinline__ unsigned member_offset(unsigned off, int part) { return (off >> 3) + (unsigned)(PWPP_MEMBER_PAD * part); }
+__device__ __forceinline__ unsigned member_offset(const PatchRef &p, unsigned off, int part) { return pwpp_member_offset(off, part, p.arena_base, p.num_parts); }
 // slot of the i-th point of the patch, low part first (the kernels that walk a patch point by point)
 __device__ __forceinline__ unsigned patch_slot(const PatchRef &p, unsigned i) { return i < p.n_lo ? p.off_lo + i : p.off_hi + (i - p.n_lo); }
 template <int G>
@@ -330,7 +332,7 @@ __device__ __forceinline__ PartSel chunk_sel(const PatchRef &p, unsigned c, bool
     s.off = h ? p.off_hi : p.off_lo;
     s.n = !on ? 0u : (h ? (use_hi ? p.n_hi : 0u) : p.n_lo);
     s.c = h ? c - nc_lo : c;
-    s.moff = member_offset(s.off, h ? PWPP_PART_HI(p.bin) : PWPP_PART_LO(p.bin));
+    s.moff = member_offset(p, s.off, h ? PWPP_PART_HI(p.bin) : PWPP_PART_LO(p.bin));
     return s;
 }
 // The membership bits of one chunk of a row of G lanes: lane j's byte = its eight points (bit k = point k of the chunk, set = the
@@ -476,7 +478,9 @@ __device__ __forceinline__ unsigned lane_stage_accum(const ChunkPts &cp, int kin
     for (int k = 0; k < kPPT; ++k) {
         if ((int)(plane_s(tx, ty, tz, cp.x[k], cp.y[k], cp.z[k]) < T) & (int)(k_off<G>(k) < cp.rem)) {  // (a branch on purpose: a seed pass includes about half of the points, an R-GPF round ~60 %)
             gmask |= 1u << k;
+#ifndef PWPP_ABLATE_NO_ACCUM  // (timing experiments only: the pass without its sums)
             m.add_uncounted(cp.x[k], cp.y[k], cp.z[k], scale, org);
+#endif
         }
     }
     m.n += __popc(gmask);
@@ -607,6 +611,9 @@ __device__ __forceinline__ __int128 join_halves(long long lo, long long hi) { re
 template <int G>
 __device__ double srow_lpr(const PatchRef &pts, bool need, bool use_cutoff, double cutoff,
                            int num_lpr, int force = 0 /* tests: 1 = take the second pass, 2 = and the exact extraction (PWPP_DEBUG_FLAGS 16384 / 32768) */) {
+#ifdef PWPP_ABLATE_NO_LPR  // (timing experiments only: no lowest-point pass)
+    return -1.75;
+#endif
     const int j = lane_id() & (G - 1);
     const unsigned INF = 0xFFFFFFFFu;
     unsigned k0 = INF, k1 = INF, k2 = INF, k3 = INF, dropped = INF;
@@ -800,6 +807,8 @@ __device__ __forceinline__ PatchRef patch_ref(const PwppBatch &Bt, const PwppFra
                                               int bin = 0) {
     PatchRef r;
     r.bin = bin;
+    r.arena_base = Bt.arena_base;
+    r.num_parts = PWPP_NUM_PARTS(Bt.P.num_bins);
     r.z = Bt.sorted_z + fd.sbase;
     r.xy = Bt.sorted_xy + fd.sbase;
     r.idx = Bt.sorted_idx + fd.sbase;
@@ -1176,6 +1185,32 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
     }
     wave_lds_sync();
 
+    // Phase profile (build with -DPWPP_PHASE_PROBE, option debug_flags = 4: tools/fit_phases.py): shader-clock cycles every wave spends in
+    // each phase of its loop, added up over all waves in Bt.dbg[16 + 8 * (G == 64) + phase] -- 0 set-up, 1 lowest points, 2 publish,
+    // 3 points phase, 4 solve (tiny fits included), 5 R-VPF strip, 6 state step; [32 + ...]: the waves counted.
+#ifdef PWPP_PHASE_PROBE
+    long long probe_t = (long long)clock64();
+#define PWPP_PHASE(ph)                                                                                                   \
+    do {                                                                                                                 \
+        const long long now_ = (long long)clock64();                                                                     \
+        if ((Bt.debug & 4) && ln == 0) atomicAdd(&Bt.dbg[16 + (G == 64 ? 8 : 0) + (ph)], (unsigned long long)(now_ - probe_t)); \
+        probe_t = now_;                                                                                                  \
+    } while (0)
+    if ((Bt.debug & 4) && ln == 0) atomicAdd(&Bt.dbg[32 + (G == 64 ? 8 : 0)], 1ull);
+    long long sub_t = 0;
+#define PWPP_SUB_BEGIN() do { sub_t = (long long)clock64(); } while (0)
+#define PWPP_SUB(k)                                                                                                       \
+    do {                                                                                                                 \
+        const long long now_ = (long long)clock64();                                                                     \
+        if ((Bt.debug & 4) && ln == 0) atomicAdd(&Bt.dbg[(G == 64 ? 48 : 56) + (k)], (unsigned long long)(now_ - sub_t)); \
+        sub_t = now_;                                                                                                    \
+    } while (0)
+#else
+#define PWPP_PHASE(ph) do { } while (0)
+#define PWPP_SUB_BEGIN() do { } while (0)
+#define PWPP_SUB(k) do { } while (0)
+#endif
+    PWPP_PHASE(0);
     for (int guard = 0; guard < 4 * P.num_iter + 8; ++guard) {
         if (!__any(O(kind) != ST_DONE)) break;
 
@@ -1204,6 +1239,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
             }
         }
 
+        PWPP_PHASE(1);
         // ---- B. publish the stage of every patch
         const bool dual_now = DUAL && O(kind) == ST_VPF;                         // this round's pass also fills the stash
         const bool from_stash = DUAL && O(kind) == ST_SEED && O(stash_valid) != 0;  // no pass: totals come from the stash
@@ -1246,6 +1282,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
         const int nact = __popcll(act_mask);
         wave_lds_sync();
 
+        PWPP_PHASE(2);
         // ---- C. points phase: R patches at a time, G lanes each
         for (int sb = 0; R * sb < nact; ++sb) {
             const bool row_on = R * sb + row < nact;
@@ -1333,8 +1370,10 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
             if (__any(clamped && (last || conv)) && ln == 0) flag_clamped(Bt, f);  // (only a FINAL ground set counts, pwpp_get_clamped_frames)
         }
         wave_lds_sync();
+        PWPP_PHASE(3);
 
         // ---- D. solve phase: lane p fits patch p (ref :47-75)
+        PWPP_SUB_BEGIN();
         long long cnt = 0;
         bool tiny = false;  // contract v3: a fit set of 1-3 points follows the reference's float arithmetic (tiny_fit_row)
         bool conv = false;  // early termination: this round's totals repeat the last round's, the plane in force is the final one
@@ -1368,6 +1407,11 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
             }
             wave_lds_sync();
         }
+        // (Round 6, measured and not adopted: the totals -> (mean, covariance) step of the 64-lane kernels spread over the idle lanes,
+        // one output per lane -- 64-lane rows leave 56+ lanes idle in this phase.  Bit-exact, and SLOWER (k_fit_w64<64,4> 0.885 -> 0.897 ms):
+        // the phase is a chain of dependent 64-bit operations whose LENGTH is the same for one output as for nine interleaved ones, plus
+        // two hand-overs through LDS.  tools/fit_phases.py, profiles/r06_fit_phases.txt.)
+        PWPP_SUB(1);
         if (O(kind) != ST_DONE) {
             float mean[3], c6[6];
             if (tiny) {
@@ -1392,7 +1436,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
                     }
                     O(stash_valid) = !(stash_cnt >= 1 && stash_cnt <= 3);  // (1-3 seeds: that stage gathers the points, it needs its own pass)
                 }
-                if (cnt > 0) {
+                if (cnt > 0 && !conv) {
                     const long long s1[3] = {tot[1], tot[2], tot[3]};
                     __int128 s2[6];
 #pragma unroll
@@ -1400,9 +1444,11 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
                     mean_cov_from_totals(cnt, s1, s2, P.fxp_shift, sh.p[ln].ox, sh.p[ln].oy, O(z0), mean, c6);
                 }
             }
+            PWPP_SUB(2);
             if (cnt > 0 && !conv) {  // empty set: the previous plane stays (ref :49); converged: the solve would return the plane in force
                 PlaneFit npl;
                 plane_from_mean_c6(mean, c6, Bt.debug, npl);
+                PWPP_SUB(3);
                 O(pl) = npl;
                 O(fitted) = 1;
             }
@@ -1412,7 +1458,9 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
             }
             O(cnt) = cnt;
         }
+        PWPP_SUB(4);
 
+        PWPP_PHASE(4);
         // ---- E. R-VPF strip (ref :489-505) for the zone-0 patches whose plane came out vertical
         const bool vertical = O(kind) == ST_VPF && (double)O(pl).nz < P.uprightness_thr;
         const unsigned long long v_mask = __ballot(vertical);
@@ -1464,6 +1512,7 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
             }
         }
 
+        PWPP_PHASE(5);
         // ---- what comes next for the patch of this lane
         const int kind = O(kind);
         if (kind == ST_VPF) {
@@ -1486,7 +1535,11 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
             O(it) = it + 1;
         }
         if (OWN_LDS) wave_lds_sync();  // (the owner state is LDS: ordered like every other hand-over between the phases)
+        PWPP_PHASE(6);
     }
+#undef PWPP_PHASE
+#undef PWPP_SUB
+#undef PWPP_SUB_BEGIN
 #undef O
 }
 
@@ -2197,7 +2250,7 @@ __device__ __forceinline__ void fit_stream_patch(FitShared &sh, const PwppBatch 
     // The split goes to the membership plane in the layout of a 64-lane fit row (pwpp_dev.h: byte c * 64 + j, bit k = point
     // c * 512 + (k / 4) * 256 + 4 j + k % 4 of the part).  This kernel walks a patch point by point, so the last round sets single
     // bits (atomicOr on the word around the byte) in areas zeroed first -- slow, and irrelevant: the path is rare.
-    const unsigned mo[2] = {member_offset(pc.off_lo, PWPP_PART_LO(bin)), member_offset(pc.off_hi, PWPP_PART_HI(bin))};
+    const unsigned mo[2] = {member_offset(pts, pc.off_lo, PWPP_PART_LO(bin)), member_offset(pts, pc.off_hi, PWPP_PART_HI(bin))};
     const unsigned mwords[2] = {((pc.n_lo + 511u) >> 9) * 16u, ((pc.n_hi + 511u) >> 9) * 16u};
     for (int h = 0; h < 2; ++h)
         for (unsigned wd = threadIdx.x; wd < mwords[h]; wd += kBlock) reinterpret_cast<uint32_t *>(frame_member + mo[h])[wd] = 0u;

@@ -345,6 +345,13 @@ __device__ __forceinline__ void czm_scan_frame(const PwppBatch &Bt, const int f,
     probe();
     unsigned *pcnt = Bt.part_count + (size_t)f * NP;
     unsigned *poff = Bt.part_off + (size_t)f * NP;
+    // the parts that outgrew their segments (overflow arena, pwpp_dev.h): up to PWPP_MAX_RELOC of them are moved into the arena
+    __shared__ unsigned s_nov, s_reloc_fail;
+    __shared__ unsigned short s_ovp[PWPP_MAX_RELOC];
+    __shared__ unsigned s_ovoff[PWPP_MAX_RELOC];
+    const bool arena = !FUSED && Bt.cap_off && Bt.arena_slots > 0u;
+    if (threadIdx.x == 0) s_nov = s_reloc_fail = 0u;
+    if (arena) __syncthreads();
     if (Bt.cap_off) {  // one-pass binning: fixed segments; a part never reports more points than its segment holds
         // four parts per thread at a time, their loads (segment table, count, observed maximum) all in flight before the first
         // is used: as a plain loop every iteration was an L2 round trip of its own (4 x 0.3 us of a single frame's chain, and
@@ -373,9 +380,14 @@ __device__ __forceinline__ void czm_scan_frame(const PwppBatch &Bt, const int f,
                 // point it meets, stored or not), so the table is right after ONE overflow, redo or not
                 if (c[q] > mx[q]) atomicMax(&Bt.bin_max[p], c[q]);
                 if (c[q] > cap) {
-                    c[q] = cap;
-                    pcnt[p] = cap;
-                    Bt.results[f].overflow = 1;
+                    if (arena) {  // its points beyond the segment are in the arena: the part is moved there as a whole below
+                        const unsigned k = atomicAdd(&s_nov, 1u);
+                        if (k < PWPP_MAX_RELOC) s_ovp[k] = (unsigned short)p;
+                    } else {
+                        c[q] = cap;
+                        pcnt[p] = cap;
+                        atomicOr((unsigned *)&Bt.results[f].overflow, 1u);  // (other workgroups of a fused launch touch this word with atomics)
+                    }
                 }
                 s_pc[p] = c[q];
                 s_po[p] = seg[q];
@@ -415,6 +427,75 @@ __device__ __forceinline__ void czm_scan_frame(const PwppBatch &Bt, const int f,
         }
     }
     __syncthreads();
+    if (arena) {
+        const unsigned word = (unsigned)Bt.results[f].overflow;
+        const unsigned spilled = word >> 8, nov = s_nov;  // (workgroup-uniform)
+        if (nov > 0u || spilled > 0u) {
+            float *sz = Bt.sorted_z + Bt.frames[f].sbase;
+            float2 *sxy = Bt.sorted_xy + Bt.frames[f].sbase;
+            int *sidx = Bt.sorted_idx + Bt.frames[f].sbase;
+            const unsigned real_parts = (unsigned)(2 * B);  // (pseudo-bins: cloud indices only)
+            if (threadIdx.x == 0) {
+                bool fail = nov > PWPP_MAX_RELOC || spilled > Bt.arena_spill || (word & 1u) != 0u;
+                if (!fail) {
+                    // in PART order (pwpp_member_offset: the bits of the moved parts must follow each other as the parts do)
+                    for (unsigned i = 1; i < nov; ++i) {
+                        const unsigned short v = s_ovp[i];
+                        unsigned j = i;
+                        for (; j > 0u && s_ovp[j - 1u] > v; --j) s_ovp[j] = s_ovp[j - 1u];
+                        s_ovp[j] = v;
+                    }
+                    unsigned long long run = (spilled + (PWPP_SLOT_ALIGN - 1u)) & ~(unsigned long long)(PWPP_SLOT_ALIGN - 1u);
+                    for (unsigned i = 0; i < nov; ++i) {
+                        s_ovoff[i] = Bt.arena_base + (unsigned)run;
+                        run += ((unsigned long long)s_pc[s_ovp[i]] + (PWPP_SLOT_ALIGN - 1u)) & ~(unsigned long long)(PWPP_SLOT_ALIGN - 1u);
+                    }
+                    fail = run > (unsigned long long)Bt.arena_slots;
+                }
+                s_reloc_fail = fail ? 1u : 0u;
+            }
+            __syncthreads();
+            if (s_reloc_fail) {  // the frame goes back to the host: clamp the counts to what the segments hold, as without an arena
+                for (int p = threadIdx.x; p < NP; p += kBlock) {
+                    const unsigned cap = Bt.cap_off[p + 1] - Bt.cap_off[p];
+                    if (s_pc[p] > cap) {
+                        s_pc[p] = cap;
+                        pcnt[p] = cap;
+                    }
+                }
+                if (threadIdx.x == 0) atomicOr((unsigned *)&Bt.results[f].overflow, 1u);
+            } else {
+                for (unsigned i = 0; i < nov; ++i) {  // the part's first `capacity` points: segment -> its new place
+                    const unsigned p = s_ovp[i], src = s_po[p], dst = s_ovoff[i], cap = Bt.cap_off[p + 1] - Bt.cap_off[p];
+                    for (unsigned k = threadIdx.x; k < cap; k += kBlock) {
+                        if (p < real_parts) {
+                            sz[dst + k] = sz[src + k];
+                            sxy[dst + k] = sxy[src + k];
+                        }
+                        sidx[dst + k] = sidx[src + k];
+                    }
+                }
+                __syncthreads();
+                for (unsigned i = threadIdx.x; i < nov; i += kBlock) {
+                    s_po[s_ovp[i]] = s_ovoff[i];
+                    poff[s_ovp[i]] = s_ovoff[i];
+                }
+                __syncthreads();
+                const uint2 *tag = Bt.arena_tag + (size_t)f * Bt.arena_spill;
+                for (unsigned a = threadIdx.x; a < spilled; a += kBlock) {  // the spilled points: arena record -> rank `y` of part `x`
+                    const uint2 t = tag[a];
+                    const unsigned src = Bt.arena_base + a, dst = s_po[t.x] + t.y;
+                    if (t.x < real_parts) {
+                        sz[dst] = sz[src];
+                        sxy[dst] = sxy[src];
+                    }
+                    sidx[dst] = sidx[src];
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAnd((unsigned *)&Bt.results[f].overflow, 255u);  // the cursor has served
+        }
+    }
     probe();  // 1: part counts and offsets
     if (!Bt.cap_off)  // the exact path's counts enter the observed maxima too (one-pass: done above)
         for (int p = threadIdx.x; p < NP; p += kBlock)
@@ -634,6 +715,7 @@ __global__ __launch_bounds__(BLOCK, FUSE ? 2 : 8) void k_czm_bin_scatter(PwppBat
     float2 *sorted_xy = Bt.sorted_xy + fd.sbase;
     int *sorted_idx = Bt.sorted_idx + fd.sbase;
     bool over = false;
+    unsigned over_mask = 0;  // the points of this thread whose part is full
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const unsigned code = pc[j] & 0xffffu;
@@ -648,10 +730,46 @@ __global__ __launch_bounds__(BLOCK, FUSE ? 2 : 8) void k_czm_bin_scatter(PwppBat
                 sorted_idx[seg + r] = first + j * kBlock + (int)threadIdx.x;
             } else {
                 over = true;
+                over_mask |= 1u << j;
             }
         }
     }
-    if (__any(over) && lane_id() == 0) atomicOr((unsigned *)&Bt.results[f].overflow, 1u);
+    if (FUSE || Bt.arena_slots == 0u) {  // no arena (a few frames: generous segments, and the fused scan's tickets live where the arena's cursor would)
+        if (__any(over) && lane_id() == 0) atomicOr((unsigned *)&Bt.results[f].overflow, 1u);
+    } else if (__syncthreads_or(over ? 1 : 0)) {
+        // The overflow arena (pwpp_dev.h): the workgroup's spilled points take a run of the frame's arena -- one atomic on the cursor
+        // in bits 8.. of the overflow word -- and go there with {part, rank inside the part} beside them; k_czm_scan moves the parts
+        // that outgrew their segments.  Rare by construction of the segments (none in a steady stream of similar frames).
+        __shared__ unsigned s_spill_n, s_spill_base;
+        if (threadIdx.x == 0) s_spill_n = 0u;
+        __syncthreads();
+        const unsigned mine = over_mask ? atomicAdd(&s_spill_n, (unsigned)__popc(over_mask)) : 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) s_spill_base = atomicAdd((unsigned *)&Bt.results[f].overflow, s_spill_n << 8) >> 8;
+        __syncthreads();
+        unsigned a = s_spill_base + mine;
+        uint2 *tag = Bt.arena_tag + (size_t)f * Bt.arena_spill;
+        bool lost = false;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            if (over_mask >> j & 1u) {
+                const unsigned code = pc[j] & 0xffffu;
+                if (a < Bt.arena_spill) {
+                    const unsigned sl = Bt.arena_base + a;
+                    if (code < (unsigned)NB - 2u) {
+                        sorted_z[sl] = pz[j];
+                        sorted_xy[sl] = make_float2(px[j], py[j]);
+                    }
+                    sorted_idx[sl] = first + j * kBlock + (int)threadIdx.x;
+                    tag[a] = make_uint2(code, s_cnt[code] + (pc[j] >> 16));
+                } else {
+                    lost = true;  // the arena is full too: the frame is binned again (k_czm_scan sees the cursor beyond the arena)
+                }
+                ++a;
+            }
+        }
+        if (lost) atomicOr((unsigned *)&Bt.results[f].overflow, 1u);
+    }
     probe();  // 4: stores issued
     if ((Bt.debug & 8) && threadIdx.x == 0) atomicMax(&Bt.dbg[8], wall_clock64());
     if constexpr (FUSE) {
@@ -1878,8 +1996,8 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, unsigned l
         // bin the counts simply run along.  A high part the last fit pass skipped (rec.valid bit 1) is non-ground unread.
         const uint8_t *mb = Bt.member + fd.mbase;
         const unsigned part_lo = seg < B ? PWPP_PART_LO(seg) : B + seg;
-        const uint8_t *m_lo = mb + (off >> 3) + (unsigned)(PWPP_MEMBER_PAD * part_lo);
-        const uint8_t *m_hi = mb + (off_hi >> 3) + (unsigned)(PWPP_MEMBER_PAD * (part_lo + 1));
+        const uint8_t *m_lo = mb + pwpp_member_offset(off, part_lo, Bt.arena_base, PWPP_NUM_PARTS(B));
+        const uint8_t *m_hi = mb + pwpp_member_offset(off_hi, part_lo + 1, Bt.arena_base, PWPP_NUM_PARTS(B));
         const bool hi_bits = !(rec_valid & 2);
         const unsigned n_hi = n - n_lo;
         const unsigned nb_lo = (n_lo + 511u) >> 9, nb = nb_lo + ((n_hi + 511u) >> 9);

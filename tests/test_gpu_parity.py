@@ -1720,3 +1720,75 @@ def test_pipe_in_stream_mode(kitti, oracle):
         pipe.drain()
         assert holders[0]._h.value == holders[2]._h.value != holders[1]._h.value
         pipe.close()
+
+
+def test_overflow_arena_moves_parts_on_the_device(kitti, oracle):
+    """Round 6: a part's segment holds ~1.125 x its largest count so far, and a frame's OVERFLOW ARENA takes what does not fit -- the
+    binning kernel spills the points with {part, rank} tags, k_czm_scan moves every overgrown part into the arena as a whole (pwpp_dev.h).
+    Two frames of 72 get 40 % more points in one sector than the handle has ever seen there: ~25 parts each outgrow their segments,
+    nothing is binned again by the host, and both frames (their neighbours too) are the oracle's bit for bit -- lists, patch records,
+    planes, state.  The same batches with the arena switched off (debug_flags 2048) do go back to the host: the overflow was real.
+    Then through the overlap schedule (two frame ranges) and as stateful streams."""
+    rng = np.random.default_rng(11)
+
+    def denser(src, lo, hi, factor):
+        a = np.arctan2(src[:, 1], src[:, 0])
+        sel = np.where((a > lo) & (a < hi))[0]
+        extra = src[rng.choice(sel, int(len(sel) * factor), replace=True)].copy()
+        extra[:, :3] += rng.normal(0.0, 0.004, (len(extra), 3)).astype(np.float32)
+        return np.ascontiguousarray(np.concatenate([src, extra]).astype(np.float32))
+
+    est = lambda p: ol.Estimator(oracle, arith=ol.ARITH_FXP).run(p)
+    refs = [est(k) for k in kitti]
+    F = 72
+    base = [kitti[i % 6] for i in range(F)]
+    d0, d1 = denser(kitti[0], 0.3, 0.6, 0.4), denser(kitti[3], -2.2, -1.9, 0.4)
+    odd = list(base)
+    odd[10], odd[40] = d0, d1
+    special = {10: est(d0), 40: est(d1)}
+    for arena in (True, False):
+        h = pwpp_hip.Handle()
+        if not arena:
+            h.set_option("debug_flags", 2048)
+        h.estimate_ground_batch(base, mode=pwpp_hip.MODE_FRESH)
+        assert h.redo_stats() == (F, 0)
+        h.estimate_ground_batch(odd, mode=pwpp_hip.MODE_FRESH)
+        if arena:
+            assert h.redo_stats() == (2 * F, 0), h.redo_stats()
+        else:
+            assert h.redo_stats()[0] == 2 * F and h.redo_stats()[1] >= 1, h.redo_stats()  # (frame 10 for sure; frame 40's sector is sparser)
+        for i in (9, 10, 11, 39, 40, 41, 0, F - 1):
+            assert_frame_equal(h, i, special.get(i, refs[i % 6]), odd[i].shape[0])
+        if arena:  # the moved parts' true counts sized the table: the same batch fits its segments now, and the results stand
+            h.estimate_ground_batch(odd, mode=pwpp_hip.MODE_FRESH)
+            assert h.redo_stats() == (3 * F, 0)
+            for i in (10, 40):
+                assert_frame_equal(h, i, special[i], odd[i].shape[0])
+    # two frame ranges on the handle's streams (150 frames), the dense frames in different ranges; reference-ordered lists
+    F2 = 150
+    base2 = [kitti[i % 6] for i in range(F2)]
+    odd2 = list(base2)
+    odd2[5], odd2[140] = d0, d1
+    for ordered in (False, True):
+        h = pwpp_hip.Handle()
+        h.set_output_order(ordered)
+        h.estimate_ground_batch(base2, mode=pwpp_hip.MODE_FRESH)
+        h.estimate_ground_batch(odd2, mode=pwpp_hip.MODE_FRESH)
+        assert h.redo_stats() == (2 * F2, 0)
+        for i, r in ((5, special[10]), (140, special[40]), (4, refs[4 % 6]), (141, refs[141 % 6])):
+            assert_frame_equal(h, i, r, odd2[i].shape[0], check_state=False)
+            if ordered:
+                assert np.array_equal(odd2[i][h.ground_indices(i), 2], odd2[i][r.ground_idx, 2])
+    # stateful streams: 70 in lock-step, stream 33 meets the dense frame at step 2 -- no state restore, no redo
+    S = 70
+    hs = pwpp_hip.Handle()
+    hs.set_num_streams(S)
+    e33, e34 = ol.Estimator(oracle, arith=ol.ARITH_FXP), ol.Estimator(oracle, arith=ol.ARITH_FXP)
+    for t in range(4):
+        frames = [kitti[(s + t) % 6] for s in range(S)]
+        if t == 2:
+            frames[33] = d0
+        hs.estimate_ground_batch(frames, mode=pwpp_hip.MODE_STREAMS)
+        assert_frame_equal(hs, 33, e33.run(frames[33]), frames[33].shape[0], state_index=33)
+        assert_frame_equal(hs, 34, e34.run(frames[34]), frames[34].shape[0], state_index=34)
+    assert hs.redo_stats()[1] == 0
