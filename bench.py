@@ -193,6 +193,22 @@ def ingest_leg(pwpp_hip, src, gpu_index, chunk=256, chunks=8):
             "what": "page-locked host slabs -> H2D -> pipeline -> D2H of all index lists, two handles double-buffered (PWPP_MEM_HOST_PINNED)"}
 
 
+def estimate_memory_gb(args):
+    """What one rank's GPU must hold (checked before RCCL is initialised): the input buffers of every batch in flight and the workspaces
+    of the handles -- per point 16 B of input and ~26 B of workspace per handle (bin-ordered planes at ~1.5 slots per point, index
+    lists, codes), frames of ~125 k points (64-beam) or ~480 k (dense); the extra legs of a single-GPU run (1024 dense frames on two
+    handles) are the larger item there."""
+    pts = 480e3 if args.workload == "dense" else 125e3
+    handles = 1 + max(1, min(4, args.in_flight))
+    if args.workload == "streams":
+        return (6 * args.frames * pts * 16 + args.frames * pts * 30) / 1e9 + 1.0
+    main = args.frames * pts * (16.0 * max(1, min(4, args.in_flight)) + 30.0 * handles)
+    extras = 0.0
+    if args.gpus == 1 and not args.skip_extras and args.workload == "kitti":
+        extras = max(args.dense_frames * 480e3 * (16.0 + 2 * 30.0), args.distinct_frames * 125e3 * (2 * 16.0 + 3 * 36.0))
+    return (main + extras) / 1e9 + 2.0
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks under torch.distributed.run
     (static rendezvous on 127.0.0.1 and a free port: the container's hostname may not resolve).  Returns the exit code."""
@@ -206,6 +222,32 @@ def spawn_ranks(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, PWPP_BENCH_SELF_SPAWNED="1")
     return subprocess.call(cmd, env=env)
+
+
+def mask_sha256(n, ground_idx):
+    import hashlib
+    m = np.zeros(n, np.uint8)
+    m[np.asarray(ground_idx)] = 1
+    return hashlib.sha256(np.packbits(m).tobytes()).hexdigest()
+
+
+def hash_spot_check(h, kind, frame_of, ns):
+    """Ground masks of a few frames of a synthetic leg against tests/golden/frame_hashes.json (written by tests/golden/make_frame_hashes.py
+    from the CPU restatement of the contract; data only -- nothing under oracle/ runs here).  frame_of: golden frame number -> batch index."""
+    path = os.path.join(ROOT, "tests", "golden", "frame_hashes.json")
+    if not os.path.exists(path):
+        return None
+    gold = json.load(open(path))[kind]
+    checked, bad = [], []
+    for key, g in gold.items():
+        i = frame_of(int(key))
+        if i is None:
+            continue
+        checked.append(int(key))
+        if ns[i] != g["points"] or mask_sha256(ns[i], h.ground_indices(i)) != g["sha256"]:
+            bad.append(int(key))
+    return {"frames_checked": checked, "mismatches": bad, "ok": len(checked) > 0 and not bad,
+            "against": "tests/golden/frame_hashes.json: SHA-256 of the ground mask per frame, from the CPU restatement of the contract"}
 
 
 def two_in_flight(pwpp_hip, torch, h0, batch0, make_second, frames, n, gpu_index, params=None):
@@ -236,16 +278,23 @@ def two_in_flight(pwpp_hip, torch, h0, batch0, make_second, frames, n, gpu_index
     return rate, redone
 
 
-def dense_leg(pwpp_hip, torch, dev, gpu_index, frames=256, steps=5):
-    """BASELINE.json configs[4] on this GPU, outside the timed region: dense synthetic 128-beam ~480k-point frames, 36-sector CZM."""
+def dense_leg(pwpp_hip, torch, dev, gpu_index, frames=1024, steps=5, distinct=64):
+    """BASELINE.json configs[4] on this GPU, outside the timed region: dense synthetic 128-beam ~480k-point frames, 36-sector CZM --
+    `frames` device buffers filled from `distinct` different clouds (pwpp_synth.dense_frame(0..distinct-1), generated by worker
+    processes), the headline's schedule, a spot check of the ground masks against committed hashes."""
     import pwpp_synth
-    src = [pwpp_synth.make_dense_cloud(1000 + k) for k in range(4)]
-    ns = [src[i % 4].shape[0] for i in range(frames)]
+    t0 = time.perf_counter()
+    distinct = max(1, min(distinct, frames))
+    src = pwpp_synth.dense_frames(distinct)
+    gen_s = time.perf_counter() - t0
+    ns = [src[i % distinct].shape[0] for i in range(frames)]
     offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
     big = torch.empty((int(offs[-1]), 4), dtype=torch.float32, device=dev)
-    sd = [torch.from_numpy(a).to(dev) for a in src]
-    for i in range(frames):
-        big[offs[i]:offs[i + 1]].copy_(sd[i % 4])
+    for k in range(distinct):
+        t = torch.from_numpy(src[k]).to(dev)
+        for i in range(k, frames, distinct):
+            big[offs[i]:offs[i + 1]].copy_(t)
+        del t
     torch.cuda.synchronize()
     params = pwpp_hip.default_params()
     for k in range(4):
@@ -258,11 +307,15 @@ def dense_leg(pwpp_hip, torch, dev, gpu_index, frames=256, steps=5):
         h.synchronize()
 
     step()
+    redo_cold = h.redo_stats()[1]
     counts = h.all_counts()
     for i in range(frames):
         assert counts[i, 0] + counts[i, 1] + counts[i, 5] == ns[i], "dense leg: partition property violated in frame %d" % i
+    parity = hash_spot_check(h, "dense", lambda k: k if k < distinct and k < frames else None, ns)
+    assert parity is None or parity["ok"] or os.environ.get("PWPP_BENCH_NO_SELFCHECK"), "dense leg: ground masks differ from the committed hashes: %r" % parity
     for _ in range(3):  # (warm-up after the host-side check, which leaves the GPU idle)
         step()
+    r0 = h.redo_stats()[1]
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -270,15 +323,17 @@ def dense_leg(pwpp_hip, torch, dev, gpu_index, frames=256, steps=5):
     b_alg = float(sum(20 * ns[i] + 24 * int(counts[i, 2]) for i in range(frames)))
     ws = h.workspace_bytes() / 1e9
     dptrs = [big.data_ptr() + int(offs[i]) * 16 for i in range(frames)]
-    fps2, _ = two_in_flight(pwpp_hip, torch, h, batch, lambda hh: hh.make_device_batch(dptrs, ns), frames, 2 * steps, gpu_index, params)
+    fps2, redo_second = two_in_flight(pwpp_hip, torch, h, batch, lambda hh: hh.make_device_batch(dptrs, ns), frames, 2 * steps, gpu_index, params)
+    redone_steady = h.redo_stats()[1] - r0
     h.close()
     dt_sync, dt = dt, frames / fps2
     return {"schedule": "as the headline: two batches in flight, one handle each", "synchronous": {"frames_per_s": frames / dt_sync, "ms_per_step": 1000.0 * dt_sync},
-            "workload": "configs[4] on one GPU: %d dense synthetic 128-beam frames (~%d points each), 36-sector CZM, device-resident, fresh state"
-                        % (frames, int(np.mean(ns))),
-            "frames": frames, "steps": steps, "frames_per_s": frames / dt, "ms_per_step": 1000.0 * dt,
+            "workload": "configs[4] on one GPU: %d dense synthetic 128-beam frames (~%d points each) from %d distinct clouds, 36-sector CZM, device-resident "
+                        "(%.2f GB), fresh state" % (frames, int(np.mean(ns)), distinct, offs[-1] * 16 / 1e9),
+            "frames": frames, "distinct_clouds": distinct, "steps": steps, "frames_per_s": frames / dt, "ms_per_step": 1000.0 * dt,
             "algorithmic_bytes_per_step": b_alg, "pipeline_achieved_GBps": b_alg / dt / 1e9, "pipeline_frac": b_alg / dt / 1e9 / HBM_PEAK_GBS,
-            "workspace_gb": ws, "note": "a batch of a few hundred dense frames does not fill the chip the way 1024 do (profiles/r04_bench_dense_1024.json)"}
+            "redone_frames": {"first_batch_cold_handle": redo_cold, "steady_state": redone_steady, "second_cold_handle": redo_second},
+            "parity": parity, "workspace_gb": ws, "generated_in_s": gen_s}
 
 
 def distinct_leg(pwpp_hip, torch, dev, gpu_index, frames=1024, steps=10):
@@ -314,6 +369,8 @@ def distinct_leg(pwpp_hip, torch, dev, gpu_index, frames=1024, steps=10):
     counts = h.all_counts()
     for i in range(frames):
         assert counts[i, 0] + counts[i, 1] + counts[i, 5] == ns[i], "distinct leg: partition property violated in frame %d" % i
+    parity = hash_spot_check(h, "varied", lambda k: k if k < frames else None, ns)  # (not only the partition property)
+    assert parity is None or parity["ok"] or os.environ.get("PWPP_BENCH_NO_SELFCHECK"), "distinct leg: ground masks differ from the committed hashes: %r" % parity
     for _ in range(3):
         run(whole)
     r0 = h.redo_stats()[1]
@@ -362,7 +419,7 @@ def distinct_leg(pwpp_hip, torch, dev, gpu_index, frames=1024, steps=10):
            "frames": frames, "steps": steps, "frames_per_s": fps_in_flight, "ms_per_step": 1000.0 * frames / fps_in_flight,
            "schedule": "as the headline: two batches in flight, one handle each (a second, cold handle joins: its redone frames = %d)" % redone_second,
            "synchronous": {"frames_per_s": frames / dt, "ms_per_step": 1000.0 * dt},
-           "redone_frames_steady": h.redo_stats()[1] - r0,
+           "redone_frames_steady": h.redo_stats()[1] - r0, "parity": parity,
            "first_batch": {"frames": half, "ms": ms_first, "redone_frames": redo_first, "what": "cold handle: allocations, 32-frame histogram probe, first launch"},
            "unseen_batch": {"frames": frames - half, "ms": ms_unseen, "redone_frames": redo_unseen,
                             "what": "frames this handle has never seen, segments sized from the first batch's counts"},
@@ -517,7 +574,8 @@ def main():
                          "as two frame ranges on two streams")
     ap.add_argument("--overlap", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--profile-steps", type=int, default=7, help="steps of the separate single-stream pass that measures per-kernel times")
-    ap.add_argument("--dense-frames", type=int, default=256, help="frames of the configs[4] leg (outside the timed region, N = 1 only)")
+    ap.add_argument("--dense-frames", type=int, default=1024, help="frames of the configs[4] leg (outside the timed region, N = 1 only)")
+    ap.add_argument("--dense-distinct", type=int, default=64, help="distinct clouds the configs[4] leg's buffers are filled from")
     ap.add_argument("--in-flight", type=int, default=2, help="batches kept enqueued in the timed region, one handle each (1 = synchronous steps on one handle)")
     ap.add_argument("--distinct-frames", type=int, default=1024, help="frames of the non-replayed leg (outside the timed region, N = 1 only; 0 = skip)")
     ap.add_argument("--skip-latency", action="store_true")
@@ -552,6 +610,14 @@ def main():
     backend = os.environ.get("PWPP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(gpu_index)
     dev = torch.device("cuda", gpu_index)
+    # Before any collective is set up: does this rank's GPU have the memory the workload will take?  An
+    # out-of-memory inside rank k of 8, minutes into a run, is the dullest way for the first multi-GPU run to die.
+    need_gb = estimate_memory_gb(args)
+    free_b, total_b = torch.cuda.mem_get_info(gpu_index)
+    if free_b / 1e9 < need_gb:
+        raise SystemExit("bench.py: rank %s: GPU %d has %.1f GB free of %.1f GB, this workload needs about %.1f GB (inputs + %d workspaces): "
+                         "free the device or lower --frames" % (os.environ.get("RANK", "0"), gpu_index, free_b / 1e9, total_b / 1e9, need_gb,
+                                                              1 + max(1, min(4, args.in_flight))))
     world, rank, local_rank = pwpp_dist.init(backend, dev)  # "nccl" = RCCL over xGMI; no-op for a single process
     if args.gpus != world:
         raise SystemExit("bench.py --gpus %d was started as %d process(es): launch it with torch.distributed.run --nproc-per-node %d"
@@ -697,6 +763,28 @@ def main():
         sync_leg = {"ms_per_step": 1000.0 * dts, "frames_per_s": F / dts, "steps": 10,
                     "what": "ONE batch at a time on one handle (launch, wait), library default schedule (two frame ranges over three streams): "
                             "the step rounds 1-4 reported as `value`; also the latency of one 1024-frame batch"}
+    # The same schedule with the plane-fit sums on rounds 3-5's 2^-21 m grid (option exact_moments = 0): what contract v4 -- sums exact
+    # on the reference's own floats, the default -- costs.  Outside the timed region.
+    exact_off = None
+    if D > 1 and not args.skip_extras:
+        p0 = pwpp_hip.Pipe(params, device=gpu_index, depth=D)
+        for d in range(D):
+            p0.handle(d).set_option("exact_moments", "0")
+        for k in range(6):
+            p0.submit_device_batch(batches[k % D], cols=4)
+        p0.drain()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n0 = 40
+        for k in range(n0):
+            p0.submit_device_batch(batches[k % D], cols=4)
+        p0.drain()
+        torch.cuda.synchronize()
+        dt0 = (time.perf_counter() - t1) / n0
+        exact_off = {"ms_per_step": 1000.0 * dt0, "frames_per_s": F / dt0, "steps": n0,
+                     "what": "pwpp_set_option(exact_moments, 0): integer moments on a 2^-21 m grid (contract v3 of rounds 3-5) -- faster, and off the "
+                             "reference by 1-31 indices on 0.2 % of varied frames (profiles/r06_parity_statistics_10k.json); the headline runs the default, exact_moments = 1"}
+        p0.close()
     prof, prof_all = {}, {}
     if not args.no_profile_events:  # kernel times of the single-stream schedule, outside the timed region
         # Two untimed steps first, then the MEDIAN of the steps' own values per kernel: the first launches of a kernel with scratch
@@ -741,6 +829,8 @@ def main():
     lat_rows.sort(key=lambda r: r["source"])
 
     per_gpu = pwpp_dist.gather_values(F * args.steps / my_elapsed, dev if backend == "nccl" else None)  # every rank's own frames/s
+    per_gpu_redone = pwpp_dist.gather_values(float(sum(hh.redo_stats()[1] for hh in H)), dev if backend == "nccl" else None)
+    per_gpu_ws = pwpp_dist.gather_values(float(sum(hh.workspace_bytes() for hh in H)) / 1e9, dev if backend == "nccl" else None)
     dist_info = pwpp_dist.describe(backend, dev)  # backend, world size, RCCL version, every rank's GPU (all-gather)
     dist_info["launcher"] = "bench.py spawned its own ranks (torch.distributed.run)" if os.environ.get("PWPP_BENCH_SELF_SPAWNED") else \
         ("torch.distributed.run" if world > 1 else "single process")
@@ -773,7 +863,7 @@ def main():
     dense = None
     if world == 1 and args.workload == "kitti" and not args.skip_extras:
         try:
-            dense = dense_leg(pwpp_hip, torch, dev, gpu_index, frames=args.dense_frames)
+            dense = dense_leg(pwpp_hip, torch, dev, gpu_index, frames=args.dense_frames, distinct=args.dense_distinct)
         except Exception as e:
             dense = {"frames_per_s": None, "error": str(e)}
 
@@ -826,9 +916,11 @@ def main():
                               "what": "median of 30 calls per source frame; gpu_us = between HIP events on the library's stream, first kernel to last"}
         if sync_leg is not None:
             out["synchronous"] = sync_leg
-        out["per_gpu"] = [{"rank": r, "frames_per_s": v} for r, v in enumerate(per_gpu)]
+        out["per_gpu"] = [{"rank": r, "frames_per_s": v, "redone_frames": int(per_gpu_redone[r]), "workspace_gb": per_gpu_ws[r]} for r, v in enumerate(per_gpu)]
         out["dist"] = dist_info
         out["selfcheck"] = bool(selfcheck)
+        if exact_off is not None:
+            out["exact_moments_off"] = exact_off
         if parity is not None:
             out["parity_check"] = parity
         if ref_order is not None:
