@@ -781,9 +781,11 @@ __global__ __launch_bounds__(BLOCK, FUSE ? 2 : 8) void k_czm_bin_scatter(PwppBat
         __shared__ int s_last;
         if (threadIdx.x == 0) {
             const unsigned tiles = (unsigned)((fd.n + kOnePassPts - 1) / kOnePassPts);
-            const unsigned old = atomicAdd((unsigned *)&Bt.results[f].overflow, 256u);
+            // (release what this workgroup did -- its count atomics, its overflow flag -- and acquire what the others did, at
+            // agent scope, instead of relying on the order in which gfx950 happens to perform relaxed atomics)
+            const unsigned old = __hip_atomic_fetch_add((unsigned *)&Bt.results[f].overflow, 256u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             s_last = (old >> 8) + 1u == tiles;
-            if (s_last) atomicAnd((unsigned *)&Bt.results[f].overflow, 255u);
+            if (s_last) (void)__hip_atomic_fetch_and((unsigned *)&Bt.results[f].overflow, 255u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (s_last) czm_scan_frame<true>(Bt, f, 0);

@@ -1792,3 +1792,36 @@ def test_overflow_arena_moves_parts_on_the_device(kitti, oracle):
         assert_frame_equal(hs, 33, e33.run(frames[33]), frames[33].shape[0], state_index=33)
         assert_frame_equal(hs, 34, e34.run(frames[34]), frames[34].shape[0], state_index=34)
     assert hs.redo_stats()[1] == 0
+
+
+def test_exact_moments_option(kitti, oracle):
+    """The width of the plane-fit sums is a handle option: exact_moments = 1 (default; contract v4, a 2^-30 m grid on which the reference's
+    floats lie) or 0 (rounds 3-5's 2^-21 m grid, faster).  Either way the HIP path is its restatement bit for bit -- single frames (the
+    four-waves / hybrid kernels), a batch of 70 (the throughput kernels), a stateful stream -- and switching back and forth on one
+    handle changes nothing else.  The two grids themselves differ by a few float ulps in the planes (and, off KITTI, by an index now
+    and then: tools/parity_statistics.py)."""
+    h = pwpp_hip.Handle()
+    assert h._L.pwpp_get_fxp_shift(h._h) == 30
+    for value, arith, shift in ((0, ol.ARITH_FXP21, 21), (1, ol.ARITH_FXP, 30), (0, ol.ARITH_FXP21, 21)):
+        h.set_option("exact_moments", value)
+        assert h._L.pwpp_get_fxp_shift(h._h) == shift
+        refs = [ol.Estimator(oracle, arith=arith).run(k) for k in kitti]
+        for k in (0, 2, 5):
+            h.estimate_ground_batch([kitti[k]], mode=pwpp_hip.MODE_FRESH)
+            assert_frame_equal(h, 0, refs[k], kitti[k].shape[0])
+        frames = [kitti[i % 6] for i in range(70)]
+        h.estimate_ground_batch(frames, mode=pwpp_hip.MODE_FRESH)
+        for i in (0, 1, 33, 69):
+            assert_frame_equal(h, i, refs[i % 6], frames[i].shape[0], check_state=False)
+    hs = pwpp_hip.Handle()
+    hs.set_option("exact_moments", 0)
+    est = ol.Estimator(oracle, arith=ol.ARITH_FXP21)
+    for t in range(5):
+        hs.estimate_ground(kitti[t % 6])
+        assert_frame_equal(hs, 0, est.run(kitti[t % 6]), kitti[t % 6].shape[0], state_index=0)
+    with pytest.raises(pwpp_hip.PwppError):
+        hs.set_option("exact_moments", 2)
+    a = ol.Estimator(oracle, arith=ol.ARITH_FXP).run(kitti[0])
+    b = ol.Estimator(oracle, arith=ol.ARITH_FXP21).run(kitti[0])
+    assert np.array_equal(np.sort(a.ground_idx), np.sort(b.ground_idx)) and not np.array_equal(a.normals, b.normals)
+    assert np.abs(a.normals - b.normals).max() < 1e-4

@@ -23,6 +23,7 @@ import pwpp_synth  # noqa: E402
 from test_gpu_parity import assert_frame_equal, to_oracle_params  # noqa: E402
 
 LAST = ""
+ARITH = ol.ARITH_FXP
 PLANS = ["", "", "", "W16:1023,W64.2:65535", "W16.16:1023,S64:65535", "S16:255,S64:65535", "B64:65535", "S8:63,S16:255,S32:1023,S64:4095",
          "W16.32:511,W64.4:65535", "H64:255", "S16:100", "W16:255,W64.8:65535"]
 
@@ -137,6 +138,11 @@ def one_case(seed, oracle):
         h.set_option("one_pass_min_frames", 1)
         if rng.random() < 0.5:
             h.set_option("one_pass_scale", float(rng.choice([0.02, 0.2, 1.0])))  # segments far too small: overflow, exact redo
+    global ARITH
+    ARITH = ol.ARITH_FXP  # contract v4 (the default); one case in six runs rounds 3-5's narrow grid behind its option
+    if rng.random() < 0.17:
+        h.set_option("exact_moments", 0)
+        ARITH = ol.ARITH_FXP21
     ordered = rng.random() < 0.2   # the reference's own order inside the lists (ties among equal heights aside)
     h.set_output_order(ordered)
     fortran = rng.random() < 0.2   # column-major matrices (Eigen's storage)
@@ -160,10 +166,18 @@ def one_case(seed, oracle):
         distinct = [random_cloud(rng, p.sensor_height) for _ in range(int(rng.integers(2, 6)))]
         if len({f.shape[1] for f in distinct}) > 1:
             distinct = [np.ascontiguousarray(f[:, :3]) for f in distinct]
-        refs = [ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(f) for f in distinct]
+        refs = [ol.Estimator(oracle, to_oracle_params(p), arith=ARITH).run(f) for f in distinct]
         nfr = int(rng.choice([65, 72, 100, 129, 136, 160]))
         pick = [int(rng.integers(0, len(distinct))) for _ in range(nfr)]
-        for rep in range(2):  # (the second call knows the bins with long lists)
+        seen = max(1, len(distinct) // 2)
+        for rep in range(3):  # (the first call only holds half of the clouds: the second meets bins fuller than any the handle has seen --
+            # overflow arena, parts moved on the device, or a redo; the third knows the bins with long lists)
+            if rep == 0:
+                pick0 = [k % seen for k in pick]
+                h.estimate_ground_batch([lay(distinct[k]) for k in pick0], mode=pwpp_hip.MODE_FRESH)
+                for i in (0, nfr // 2, nfr - 1):
+                    check(i, refs[pick0[i]], distinct[pick0[i]], check_state=False)
+                continue
             h.estimate_ground_batch([lay(distinct[k]) for k in pick], mode=pwpp_hip.MODE_FRESH)
             for i in sorted(set(int(x) for x in rng.integers(0, nfr, 24)) | {0, nfr - 1}):
                 check(i, refs[pick[i]], distinct[pick[i]], check_state=False)
@@ -174,10 +188,10 @@ def one_case(seed, oracle):
             frames = [np.ascontiguousarray(f[:, :3]) for f in frames]
         h.estimate_ground_batch([lay(f) for f in frames], mode=pwpp_hip.MODE_FRESH)
         for i, pts in enumerate(frames):
-            check(i, ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP).run(pts), pts)
+            check(i, ol.Estimator(oracle, to_oracle_params(p), arith=ARITH).run(pts), pts)
         return "batch of %d" % len(frames)
     if mode < 0.78:  # one stateful stream, frame after frame
-        est = ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP)
+        est = ol.Estimator(oracle, to_oracle_params(p), arith=ARITH)
         n = int(rng.integers(2, 6))
         for _ in range(n):
             pts = random_cloud(rng, p.sensor_height)
@@ -186,7 +200,7 @@ def one_case(seed, oracle):
         return "sequence of %d" % n
     streams = int(rng.integers(2, 5))  # several streams in lock step
     h.set_num_streams(streams)
-    ests = [ol.Estimator(oracle, to_oracle_params(p), arith=ol.ARITH_FXP) for _ in range(streams)]
+    ests = [ol.Estimator(oracle, to_oracle_params(p), arith=ARITH) for _ in range(streams)]
     cols = 3 if rng.random() < 0.2 else 4
     for _ in range(int(rng.integers(2, 4))):
         frames = [random_cloud(rng, p.sensor_height) for _ in range(streams)]
