@@ -384,7 +384,7 @@ void fill_default_state(const pwpp_handle *h, PwppStateScalar &s) {
 }
 
 int finish_pending(pwpp_handle *h);
-extern "C" const char *pwpp_big_batch_plan(int max_n, int num_bins);  // pwpp_fit.hip
+extern "C" const char *pwpp_big_batch_plan(int max_n, int num_bins, int wide);  // pwpp_fit.hip
 
 // every stream a schedule may have put work on (error paths, pwpp_destroy): the main stream alone is not the join of a
 // schedule that stopped half way

@@ -2388,11 +2388,18 @@ extern "C" int pwpp_launch_fixup(const PwppBatch *batch, hipStream_t stream) {
 
 // launches of K4; ev (optional) = 7 events recorded around up to six launches
 #define PWPP_DEFAULT_FIT_PLAN "W16:1023,W64.4:65535"
+#define PWPP_DEFAULT_FIT_PLAN_WIDE "W16:1023,W64.8:65535"
 #define PWPP_DENSE_FIT_PLAN "W16:1023,W64.2:65535"
 // the plan of a big batch: four big bins per wave share a solve on scans of KITTI density; with several times more points
-// per bin (dense 128-beam frames) a wave's chain gets too long and two per wave win (profiles/r03_bench_dense_1024.json)
-extern "C" const char *pwpp_big_batch_plan(int max_n, int num_bins) {
-    return (double)max_n / (double)(num_bins > 0 ? num_bins : 1) < 500.0 ? PWPP_DEFAULT_FIT_PLAN : PWPP_DENSE_FIT_PLAN;
+// per bin (dense 128-beam frames) a wave's chain gets too long and two per wave win (profiles/r03_bench_dense_1024.json).
+// On the wide grid (contract v4) the 64-lane kernel is bound by its instruction issue (93 % of the SIMDs' issue cycles,
+// profiles/r06_pmc_summary.json), and the phases that run on one lane per patch -- solve, thresholds, lowest points -- are 46 % of
+// its wave time (profiles/r06_fit_phases.txt): EIGHT big bins per wave halve those instructions per patch.  Alone the kernel is no
+// faster (0.90 vs 0.88 ms), two batches in flight are: 2.49-2.50 instead of 2.56 ms per step (profiles/r06_plan_sweep_wide.txt);
+// dense frames: no difference between 2, 4 and 8 (r06_plan_sweep_dense.txt).
+extern "C" const char *pwpp_big_batch_plan(int max_n, int num_bins, int wide) {
+    if (!((double)max_n / (double)(num_bins > 0 ? num_bins : 1) < 500.0)) return PWPP_DENSE_FIT_PLAN;
+    return wide ? PWPP_DEFAULT_FIT_PLAN_WIDE : PWPP_DEFAULT_FIT_PLAN;
 }
 #define PWPP_LATENCY_FIT_PLAN "H64:1023"
 // `aux` (optional): a second stream + two events, for the fit_concurrent option (classes of a plan side by side).
@@ -2444,7 +2451,7 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
              : eff <= 576.0 ? "W16.16:1023,W64.2:65535"
              : eff <= 704.0 ? "W16.32:1023,W64.2:65535"
              : eff <= 896.0 ? (B.max_n / (nb > 0 ? nb : 1) >= 500 ? "W16.32:1023,W64.2:65535" : "W16.32:1023,W64.4:65535")
-                            : pwpp_big_batch_plan(B.max_n, nb);
+                            : pwpp_big_batch_plan(B.max_n, nb, B.P.fxp_wide);
     }
     int k_lo = 0, slot = 0;
     unsigned n_lo = 1;
@@ -2506,6 +2513,7 @@ extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEv
                 if (g == 16 && pw == 64) PWPP_LAUNCH_W(16, 64, wgrid, wblock, 0, ls, B, k_lo, k_hi);
                 else if (g == 16 && pw == 32) PWPP_LAUNCH_W(16, 32, wgrid, wblock, 0, ls, B, k_lo, k_hi);
                 else if (g == 16 && pw == 16) PWPP_LAUNCH_W(16, 16, wgrid, wblock, 0, ls, B, k_lo, k_hi);
+                else if (g == 64 && pw == 16) PWPP_LAUNCH_W(64, 16, wgrid, wblock, 0, ls, B, k_lo, k_hi);
                 else if (g == 64 && pw == 8) PWPP_LAUNCH_W(64, 8, wgrid, wblock, 0, ls, B, k_lo, k_hi);
                 else if (g == 64 && pw == 4) PWPP_LAUNCH_W(64, 4, wgrid, wblock, 0, ls, B, k_lo, k_hi);
                 else if (g == 64 && pw == 2) PWPP_LAUNCH_W(64, 2, wgrid, wblock, 0, ls, B, k_lo, k_hi);
