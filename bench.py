@@ -420,6 +420,8 @@ def distinct_leg(pwpp_hip, torch, dev, gpu_index, frames=1024, steps=10):
            "schedule": "as the headline: two batches in flight, one handle each (a second, cold handle joins: its redone frames = %d)" % redone_second,
            "synchronous": {"frames_per_s": frames / dt, "ms_per_step": 1000.0 * dt},
            "redone_frames_steady": h.redo_stats()[1] - r0, "parity": parity,
+           "frames_with_parts_moved_into_the_arena": {"all_calls_of_this_handle": h.arena_stats()[0], "frames_processed": h.redo_stats()[0]},
+           "slots_per_point": h.arena_stats()[1] / float(np.mean(ns)),
            "first_batch": {"frames": half, "ms": ms_first, "redone_frames": redo_first, "what": "cold handle: allocations, 32-frame histogram probe, first launch"},
            "unseen_batch": {"frames": frames - half, "ms": ms_unseen, "redone_frames": redo_unseen,
                             "what": "frames this handle has never seen, segments sized from the first batch's counts"},
@@ -904,6 +906,8 @@ def main():
                                    + "; kernel_ms / roofline.kernel_ms: median over a separate single-stream pass of %d steps (after 2 untimed ones) outside the timed region" % args.profile_steps},
             "binning": {"one_pass_batches": h.one_pass_stats()[0], "redone_two_pass": h.one_pass_stats()[1],
                         "one_pass_frames": h.redo_stats()[0], "redone_frames": h.redo_stats()[1],
+                        "frames_with_parts_moved_into_the_arena": sum(hh.arena_stats()[0] for hh in H),
+                        "slots_per_point": H[-1].arena_stats()[1] / float(np.mean(ns)), "arena_slots_per_frame": H[-1].arena_stats()[2],
                         "workspace_gb": h.workspace_bytes() / 1e9, "input_gb": float(offs[-1]) * 16 / 1e9,
                         "workspace_gb_all_handles": sum(hh.workspace_bytes() for hh in H) / 1e9},
         }

@@ -315,6 +315,11 @@ PWPP_API int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *
  * in place, while the other frames' results stand; only a frame too large for its own slots of the one-pass layout
  * (or the option "redo_whole_batch") sends the whole batch through the two-pass path, and then every frame counts. */
 PWPP_API int pwpp_get_redo_stats(pwpp_handle *h, int64_t *frames_one_pass, int64_t *frames_redone);
+/* ... and what keeps that rare (round 6): a part's segment holds ~1.06 x the largest count the part has had, and every frame owns an
+ * OVERFLOW ARENA behind its segments -- a part that outgrows its segment is moved there as a whole by the scan kernel, on the device
+ * (the cost of copying that part), and only a frame whose arena runs out goes back to the host.  frames_with_moved_parts counts the
+ * frames that took that path; slots_per_frame / arena_slots describe the current table (0 before the first one-pass batch). */
+PWPP_API int pwpp_get_arena_stats(pwpp_handle *h, int64_t *frames_with_moved_parts, int64_t *slots_per_frame, int64_t *arena_slots);
 
 
 /* ---- batches in flight (no reference counterpart; round 5) --------------------------------------------------------------------

@@ -165,6 +165,7 @@ struct pwpp_handle {
     std::vector<uint8_t> frame_two_pass;  // frames of the last one-pass batch that were redone in place (compact layout at their own first slot)
     bool redo_whole_batch = false;        // option "redo_whole_batch": an overflow redoes every frame of the batch (rounds 1-4; tests, A/B)
     long long fixed_up_frames = 0;   // frames finished by k_fit_fixup (a patch needed the plane fitted before it)
+    long long arena_frames = 0;      // frames in which k_czm_scan moved overgrown parts into the overflow arena (PwppFrameResult.overflow bit 3)
     long long clamped_frames = 0;    // frames with a patch whose final ground set spanned more than z0 +- ZR (PwppFrameResult.overflow bit 2)
 
     // workspace
@@ -192,7 +193,7 @@ struct pwpp_handle {
     DevBuf<uint8_t> d_emit_long;   // k_emit's table of long bins: B + 2 flags, then (4-byte aligned) the list of those bins as uint16
     std::vector<uint8_t> emit_long_flags;
     int emit_long_n = 0, emit_long_parts = 1;
-    std::vector<uint32_t> observed, cap_table;  // host copies: d_bin_max as last read; capacities of the table on the device
+    std::vector<uint32_t> observed, cap_table, cap_seen;  // host copies: d_bin_max as last read; capacities of the table on the device and the counts it was built from
     bool have_observation = false, table_stale = true;
     DevBuf<PwppFrameDesc> d_frames_probe;
     PinnedBuf<uint32_t> h_bin_max;
@@ -411,12 +412,12 @@ int grow_stream_histories(pwpp_handle *h, int new_cap) {
     return PWPP_OK;
 }
 
-// Segment sizes of the one-pass path.  Round 6: a part's segment holds 1.125 x the largest count that part has had in any frame
+// Segment sizes of the one-pass path.  Round 6: a part's segment holds 1.0625 x the largest count that part has had in any frame
 // this handle has seen (d_bin_max, kept by k_czm_scan; before the first batch a histogram of up to 256 sample frames fills it:
-// probe_histogram) + 4 sqrt(that) + 32 slots, and every frame has an OVERFLOW ARENA behind its segments (pwpp_dev.h): a part that
-// outgrows its segment is moved there by k_czm_scan, on the device, at the cost of a copy of that part -- ~1.5 slots per point of a
-// KITTI frame, 24 B per point.  (Rounds 2-5: 1.5 x + 256 slots and no arena -- 2.7 slots per point, every overflow a frame binned
-// twice by the host; round 1: 20 slots per point.)  one_pass_scale scales the 1.125 (tests use a tiny one to force overflows).
+// probe_histogram) + 2 sqrt(that) + 16 slots, and every frame has an OVERFLOW ARENA behind its segments (pwpp_dev.h): a part that
+// outgrows its segment is moved there by k_czm_scan, on the device, at the cost of a copy of that part -- ~1.7 slots per point of a
+// KITTI frame, 27 B per point.  (Rounds 2-5: 1.5 x + 256 slots and no arena -- 2.7 slots per point, every overflow a frame binned
+// twice by the host; round 1: 20 slots per point.)  one_pass_scale scales the 1.0625 (tests use a tiny one to force overflows).
 // A frame whose arena runs out raises the overflow flag and is binned again on the exact two-pass path, whose counts enter
 // d_bin_max, and the table is rebuilt.
 int build_capacity_table(pwpp_handle *h, int max_n) {
@@ -427,14 +428,15 @@ int build_capacity_table(pwpp_handle *h, int max_n) {
     // no arena), and a handle that has seen a handful of frames knows little about its bins -- 3.75 x the largest count + 2048.
     const bool few = h->frames <= 16 && h->one_pass_scale >= 1.0;
     h->cap_few = few;
-    const double scale = (few ? 3.75 : 1.125) * h->one_pass_scale / 4.0;
+    const double scale = (few ? 3.75 : 1.0625) * h->one_pass_scale / 4.0;
     std::vector<uint32_t> off((size_t)NB + 1);
     h->cap_table.assign((size_t)NB, 0u);
+    h->cap_seen = h->observed;
     uint64_t run = 0;
     for (int b = 0; b < NB; ++b) {
         off[(size_t)b] = (uint32_t)run;
         const double seen = (double)h->observed[(size_t)b];
-        double cap = scale * seen + (h->one_pass_scale >= 1.0 ? (few ? 2048.0 : 4.0 * std::sqrt(seen) + 32.0) : 16.0);
+        double cap = scale * seen + (h->one_pass_scale >= 1.0 ? (few ? 2048.0 : 2.0 * std::sqrt(seen) + 16.0) : 16.0);
         if (cap > (double)max_n + 16.0) cap = (double)max_n + 16.0;
         uint64_t c = ((uint64_t)cap + (PWPP_SLOT_ALIGN - 1)) & ~(uint64_t)(PWPP_SLOT_ALIGN - 1);
         if (b < 2 * P.num_bins && (b & 1) && b / 2 >= P.split_end) c = 0;  // the high part of a bin that is not split: never used
@@ -872,6 +874,10 @@ int finish_pending(pwpp_handle *h) {
         h->one_pass = false;
         h->frame_two_pass.assign((size_t)h->frames, 0);
         if (!redo.empty()) {
+            {   // the exact path needs the per-point codes (not held for one-pass batches)
+                const int rc = h->d_codes.ensure((size_t)(h->total_points > 0 ? h->total_points : 1));
+                if (rc) return rc;
+            }
             ++h->one_pass_redone;
             h->one_pass_holdoff = 0;  // (the redo's exact counts enter d_bin_max and the table is rebuilt: no need to stay away)
             h->table_stale = true;
@@ -974,17 +980,20 @@ int finish_pending(pwpp_handle *h) {
             HIPCHK(hipStreamSynchronize(h->stream));
         }
     }
-    for (int f = 0; f < h->frames; ++f)
+    for (int f = 0; f < h->frames; ++f) {
         if (h->h_results.p[f].overflow & 4) ++h->clamped_frames;
+        if ((h->h_results.p[f].overflow & 8) && !(h->frame_two_pass.size() > (size_t)f && h->frame_two_pass[(size_t)f])) ++h->arena_frames;
+    }
     h->have_results = true;
     if (redone_in_place) {  // the exact counts of the redone frames are in d_bin_max now: they size the next table
         const int rc = read_observed(h);
         if (rc) return rc;
     } else if (was_one_pass) {
-        // a bin that came within 10 % of its segment's capacity: grow the table before the next batch
+        // a part that held more points than the table was built for (it ate into its head-room, or was moved into the arena): size
+        // the table anew before the next batch
         h->observed.assign(h->h_bin_max.p, h->h_bin_max.p + h->cap_table.size());
         for (size_t b = 0; b < h->cap_table.size() && !h->table_stale; ++b)
-            if ((uint64_t)h->observed[b] * 10u > (uint64_t)h->cap_table[b] * 9u) h->table_stale = true;
+            if (h->observed[b] > (b < h->cap_seen.size() ? h->cap_seen[b] : 0u) && h->cap_table[b] > 0u) h->table_stale = true;
     }
     if (h->mode == PWPP_MODE_STREAMS) {
         // The reference's history vectors are unbounded (update_flatness_thr stops trimming the higher rings while a
@@ -1329,7 +1338,8 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     if ((rc = h->d_frames.ensure((size_t)frames))) return rc;
     if ((rc = h->h_frames.ensure((size_t)frames))) return rc;
     if ((rc = h->h_base.ensure((size_t)frames + 1))) return rc;
-    if ((rc = h->d_codes.ensure(tp))) return rc;
+    // (the per-point codes are the two-pass path's: a one-pass batch only needs them for its histogram probe and for a frame that is
+    // binned again -- allocated there, 2 bytes per point less to hold otherwise)
     if ((rc = h->d_out.ensure(tp))) return rc;
     if (h->output_order == PWPP_ORDER_REFERENCE) {
         if ((rc = h->d_ord_a.ensure(tp))) return rc;
@@ -1419,6 +1429,7 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
             h->have_observation = false;
         }
         if (!h->have_observation) {
+            if ((rc = h->d_codes.ensure(tp))) return rc;
             if ((rc = probe_histogram(h))) return rc;
             h->table_stale = true;
         }
@@ -1448,6 +1459,11 @@ int estimate_batch(pwpp_handle *h, const float *const *points, const int32_t *n,
     if ((rc = h->d_sorted_xy.ensure(bin_slots + 1024))) return rc;
     if ((rc = h->d_sorted_idx.ensure(bin_slots))) return rc;
     if ((rc = h->d_member.ensure(bin_slots / 8 + member_pads))) return rc;
+    if (one_pass) {
+        h->d_codes.release();  // (a cold handle's probe needed them; a redo gets them back: finish_pending)
+    } else if ((rc = h->d_codes.ensure(tp))) {
+        return rc;
+    }
     if (one_pass && h->arena_slots && (rc = h->d_arena_tag.ensure((size_t)frames * h->arena_spill))) return rc;
 
     h->frames = frames;
@@ -2029,6 +2045,17 @@ int pwpp_get_one_pass_stats(pwpp_handle *h, int64_t *batches, int64_t *redone) {
     if ((rc = finish_pending(h))) return rc;
     if (batches) *batches = h->one_pass_batches;
     if (redone) *redone = h->one_pass_redone;
+    return PWPP_OK;
+}
+
+int pwpp_get_arena_stats(pwpp_handle *h, int64_t *frames_with_moved_parts, int64_t *slots_per_frame, int64_t *arena_slots) {
+    if (!h) return fail(PWPP_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = finish_pending(h))) return rc;
+    if (frames_with_moved_parts) *frames_with_moved_parts = h->arena_frames;
+    if (slots_per_frame) *slots_per_frame = h->slots_per_frame;
+    if (arena_slots) *arena_slots = h->arena_slots;
     return PWPP_OK;
 }
 

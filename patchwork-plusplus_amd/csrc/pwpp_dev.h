@@ -34,7 +34,7 @@
 #define PWPP_PART_LO(bin) (2 * (bin))
 #define PWPP_PART_HI(bin) (2 * (bin) + 1)
 #define PWPP_NUM_PARTS(B) (2 * (B) + 2)
-// One-pass binning with an OVERFLOW ARENA (round 6): a part's fixed segment holds ~1.125 x the largest count the part has had, and
+// One-pass binning with an OVERFLOW ARENA (round 6): a part's fixed segment holds ~1.06 x the largest count the part has had, and
 // every frame owns PwppBatch.arena_slots more slots behind its segments.  A point whose part is full is written into the arena
 // instead (k_czm_bin_scatter reserves a run per workgroup with one atomic on the frame's cursor -- bits 8.. of PwppFrameResult.overflow
 // -- and tags the record with its part and its rank inside the part); k_czm_scan then MOVES every part that outgrew its segment into a
@@ -138,7 +138,8 @@ struct PwppFrameResult {
                        // bit 0: one-pass binning: some bin of this frame outgrew its segment AND the arena (the batch is redone on the two-pass
                        // path); bit 1: some patch of the frame needs the plane fitted before it (PwppPatchRec.valid bit 2): K5 and K6
                        // leave the frame alone and the host runs k_fit_fixup + K5 + K6 for it when the batch lands; bit 2: the final
-                       // ground set of some patch held a height outside z0 +- ZR (clamped before it was quantised: pwpp_get_clamped_frames)
+                       // ground set of some patch held a height outside z0 +- ZR (clamped before it was quantised: pwpp_get_clamped_frames);
+                       // bit 3: k_czm_scan moved parts of this frame into the overflow arena (statistics only: pwpp_get_arena_stats)
 };
 
 // everything a launch needs, by value in the kernarg segment

@@ -493,7 +493,10 @@ __device__ __forceinline__ void czm_scan_frame(const PwppBatch &Bt, const int f,
                 }
             }
             __syncthreads();
-            if (threadIdx.x == 0) atomicAnd((unsigned *)&Bt.results[f].overflow, 255u);  // the cursor has served
+            if (threadIdx.x == 0) {
+                atomicAnd((unsigned *)&Bt.results[f].overflow, 255u);  // the cursor has served
+                if (!s_reloc_fail) atomicOr((unsigned *)&Bt.results[f].overflow, 8u);  // (statistics: parts of this frame were moved, pwpp_get_arena_stats)
+            }
         }
     }
     probe();  // 1: part counts and offsets

@@ -118,6 +118,7 @@ def load():
         L.pwpp_pipe_create.argtypes = [vp, ci, ci, ctypes.POINTER(vp)]
         L.pwpp_pipe_submit.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ctypes.POINTER(vp)]
         L.pwpp_pipe_set_num_streams.argtypes = [vp, ci]
+        L.pwpp_get_arena_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         L.pwpp_pipe_drain.argtypes = [vp]
         L.pwpp_pipe_handle.argtypes = [vp, ci]
         L.pwpp_pipe_handle.restype = vp
@@ -423,6 +424,12 @@ class Handle:
     def set_overlap(self, on):
         """True: batches of 128+ frames run as two frame ranges on the handle's two streams (same results)."""
         self._check(self._L.pwpp_set_overlap(self._h, 1 if on else 0))
+
+    def arena_stats(self):
+        """(frames whose overgrown parts were moved into the overflow arena on the device, slots per frame, arena slots per frame)."""
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self._check(self._L.pwpp_get_arena_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
 
     def redo_stats(self):
         """(frames that went through one-pass binning, frames redone on the two-pass path after a segment overflow)"""
