@@ -168,7 +168,7 @@ PWPP_API int pwpp_set_num_streams(pwpp_handle *h, int streams); /* (re)creates `
 PWPP_API int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32_t *n_nonground, int32_t *n_patches);
 /* getGroundIndices()/getNongroundIndices(), reference patchworkpp.h:159-160, patchworkpp.cpp:18-26.
  * The index SETS are those of the reference's control flow with the plane-fit sums of patchworkpp.cpp:56-60
- * evaluated (contract v3)
+ * evaluated (contract v4)
  *   - for a fit set of 1, 2 or 3 points: in the reference's own float arithmetic, which is determinate there (Eigen
  *     reduces fewer elements than one SIMD packet sequentially; two terms commute) -- points in the order of the
  *     reference's z-sorted bin, equal heights in cloud order (the reference's std::sort is stable only for bins of up
@@ -177,25 +177,25 @@ PWPP_API int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32
  *     tests/test_tiny_fits.py records the behaviour with duplicated heights).  All three builds of the reference under oracle/_ref agree
  *     on such sets and this library agrees with them: identical ground sets under the ROS launch file's parameters,
  *     num_min_pts 0-3, num_lpr 1-3 on the KITTI samples (tests/test_tiny_fits.py, CPU and GPU);
- *   - for 4 points and more: in exact arithmetic (integer moments on a 2^-21 m grid around per-bin / per-patch origins,
- *     z clamped to z0 +- 2^(26-s) m = 32 m with the default CZM -- see pwpp_get_fxp_geometry), because Eigen's float
- *     summation order there depends on the vector width it was built for.  Bit-identical to the CPU restatement of the
- *     contract (oracle/); identical to the "exact-f64" build of the reference on every scan of the GPU test suite (rates off it: below).  A float
- *     build of the reference adds those sums up in float; its own rounding then moves a point that lies within ~1e-4 m
- *     of a threshold now and then (measured: 0-2 of 480 000 indices on dense synthetic clouds, none on the KITTI
- *     samples; plane normals agree to 1e-4 except for ill-conditioned patches, where a float build departs from exact
- *     arithmetic by more than this library does).
- *     Measured on 10 400 frames against all three builds of the reference (float sums in two orders, exact sums; tools/parity_statistics.py,
- *     profiles/r05_parity_statistics_10k.json -- CPU restatement of the contract, which the HIP path equals bit for bit): 6 000 varied 64-beam
+ *   - for 4 points and more: in EXACT arithmetic on the reference's own floats -- integer moments on a 2^-30 m grid around
+ *     per-bin / per-patch origins, on which every float of magnitude >= 2^-7 m lies (smaller ones are rounded to it: an error of
+ *     at most 2^-31 m); z clamped to z0 +- 2^(35-s) m = 32 m with the default CZM (pwpp_get_fxp_geometry).  Eigen's float
+ *     summation order there depends on the vector width it was built for; exact sums do not depend on any order, and they are what
+ *     every order approximates.  Bit-identical to the CPU restatement of the contract (oracle/).
+ *     Measured on 10 400 frames against all three builds of the reference (float sums in two orders, exact-f64 sums; tools/parity_statistics.py,
+ *     profiles/r06_parity_statistics_10k.json -- CPU restatement of the contract, which the HIP path equals bit for bit): 6 000 varied 64-beam
  *     frames with fresh state, 20 stateful sequences of 200 frames, 400 dense 128-beam frames with the 36-sector CZM.  The builds are
- *     unanimous on 5 829 / 3 869 / 334 of them; this library returns exactly their ground set on 5 819 (99.83 %, 95 % interval
- *     99.68-99.91), 3 861 (99.79 %, 99.59-99.90) and 334 (100 %, >= 98.9); the eighteen misses are 1-31 indices of ~120 000 (median 2)
- *     -- the 2^-21 m grid of the sums moves a plane by a few float ulps, and a point 1e-7 m from th_dist (or one small patch
- *     at the edge of a GLE decision) changes sides.  Where the builds differ among themselves (2.9 % / 3.3 % / 16.5 % of the frames)
- *     there is no single reference result; the library equals the exact build on 127 of 171, 84 of 131 and 59 of 66 of those and is
- *     further from it than both float builds on 4 of the 368.  Adaptive sensor height over the 200-frame sequences: within 1.2e-3 m of
- *     the exact build -- one differing patch decision enters the elevation history; the float build of the reference: the same 1.2e-3 m
- *     (3.3e-7 m against 8.5e-7 m over the first ten sequences).  On the reference's own KITTI samples: identical index sets, every build.
+ *     unanimous on 5 829 / 3 869 / 334 of them, and this library returns exactly their ground set on EVERY one of those 10 032 frames.
+ *     Where the builds differ among themselves (2.9 % / 3.3 % / 16.5 % of the frames: there is no single reference result) the library
+ *     equals one of the builds on all 368: the exact-f64 build on 303, both float builds on 63 (frames where a fit set of 1-3 points
+ *     decides -- the reference sums those in float, determinately; the exact-f64 build is the odd one out there), one float build on 2.
+ *     Adaptive sensor height over the 200-frame sequences: within 1.2e-3 m of the exact build, as the float build of the reference is
+ *     (a split frame's differing patch decision enters the elevation history).  On the reference's own KITTI samples: identical index
+ *     sets with every build, plane normals within 3.1e-5 of the float build's and 6e-8 of the exact build's.
+ *     Option "exact_moments" = 0 selects rounds 3-5's coarser 2^-21 m grid (contract v3: |Q| <= 2^26, nine multiply-adds per point instead of
+ *     twenty-one): 8-9 % faster on 1024-frame batches (2.34 vs 2.54 ms per batch on one MI355X), 6-9 us on a single frame -- and off the unanimous
+ *     reference by 1-31 indices of ~120 000 on 0.2 % of varied frames (18 of the 10 032 above), because that grid is coarser than the float
+ *     ulp of heights around -1.7 m and of |x|, |y| < 4 m.  Both widths are tested bit for bit against their restatements.
  * (NaN heights are undefined in the reference itself: it sorts bins with `a.z < b.z`.)
  * The order inside a list is not the reference's unless pwpp_set_output_order asks for it. */
 PWPP_API int pwpp_get_ground_indices(pwpp_handle *h, int frame, int32_t *out);
@@ -240,10 +240,12 @@ PWPP_API int64_t pwpp_get_fixed_up_frames(pwpp_handle *h);
  * the default CZM), i.e. a fit of 4+ points whose z coordinates were clamped before they were quantised (see
  * pwpp_get_fxp_origins): that patch's plane is the plane of the clamped heights, not the reference's.  No ground patch is
  * that tall; a steep facade or cliff filling a bin can be (it is rejected as "not upright" either way with the default
- * parameters).  0 on every scan of the test suite. */
+ * parameters).  0 on every scan of the test suite.  (2^(35-s) with the default "exact_moments" = 1, 2^(26-s) with 0: 32 m either way
+ * for the default CZM, s = 30 / 21.) */
 PWPP_API int64_t pwpp_get_clamped_frames(pwpp_handle *h);
 /* Host only (no device needed): shift and per-bin origins {ox, oy} of the fixed-point plane-fit sums a handle created with
- * these parameters would use (= pwpp_get_fxp_shift / pwpp_get_fxp_origins of that handle).  The CPU tests compare them with
+ * these parameters uses by default (= pwpp_get_fxp_shift / pwpp_get_fxp_origins of that handle; contract v4: s <= 30, |Q| <= 2^35.
+ * The origins do not depend on the option "exact_moments"; the shift does -- pwpp_get_fxp_shift reports the handle's current one).  The CPU tests compare them with
  * the restatement's for many CZM shapes.  Returns the number of bins; shift / out_xy may be NULL. */
 PWPP_API int pwpp_get_fxp_geometry(const pwpp_params *p, int *shift, float *out_xy, int capacity_bins);
 /* Host only (no device needed): the axis-aligned box {xmin, xmax, ymin, ymax} the library assumes around every CZM bin of
@@ -285,7 +287,7 @@ PWPP_API const char *pwpp_kernel_name(int k);
 /* the fixed-point contract of the plane-fit sums for this handle: the shift s (grid 2^-s m) ... */
 PWPP_API int pwpp_get_fxp_shift(pwpp_handle *h);
 /* ... and every bin's origin (its polar centre rounded to 1/8 m): out_xy = B x {x, y}; returns B (out_xy = NULL: only B).
- * The z coordinates of a fit of 4+ points are clamped to z0 +- 2^(26-s) m (32 m with the default CZM; z0 = the patch's first
+ * The z coordinates of a fit of 4+ points are clamped to z0 +- 2^(35-s) m (32 m with the default CZM; z0 = the patch's first
  * lowest-point representative rounded to 1/8 m) before they are quantised: a fit set that spans more than that vertically --
  * no ground patch does; a facade that R-VPF did not strip could -- gets the plane of the clamped heights. */
 PWPP_API int pwpp_get_fxp_origins(pwpp_handle *h, float *out_xy, int capacity_bins);
@@ -349,9 +351,12 @@ PWPP_API int pwpp_pipe_destroy(pwpp_pipe *pipe);
 
 /* Tuning and test switches (no reference counterpart).  The environment variables PWPP_DEBUG_FLAGS,
  * PWPP_FIT_PLAN, PWPP_FIT_CONCURRENT, PWPP_NO_ONE_PASS, PWPP_ONE_PASS_MIN_FRAMES, PWPP_ONE_PASS_SCALE,
- * PWPP_OVERLAP, PWPP_OVERLAP_MODE, PWPP_OVERLAP_RANGES, PWPP_FIT_STREAMS, PWPP_BIN_BLOCK, PWPP_HI_SPLIT and
- * PWPP_HI_SPLIT_ZONES set the same options ONCE, in pwpp_create (which says so on stderr); nothing reads the
- * environment afterwards.  None of them changes a result.
+ * PWPP_OVERLAP, PWPP_OVERLAP_MODE, PWPP_OVERLAP_RANGES, PWPP_FIT_STREAMS, PWPP_BIN_BLOCK, PWPP_HI_SPLIT,
+ * PWPP_HI_SPLIT_ZONES and PWPP_EXACT_MOMENTS set the same options ONCE, in pwpp_create (which says so on stderr); nothing reads the
+ * environment afterwards.  None of them changes a result, except the one that says so:
+ *   "exact_moments"       "1" (default): the plane-fit sums of 4+ points exact on the reference's floats (2^-30 m grid, contract v4);
+ *                         "0": rounds 3-5's 2^-21 m grid -- 8-9 % faster, off the reference by a few indices on 0.2 % of varied frames
+ *                         (see pwpp_get_ground_indices above).  May be changed between calls.
  *   "fit_plan"            which fit kernel handles which patch sizes, e.g. "W16:1023,W64.2:65535"; "" = automatic
  *   "fit_concurrent"      "1": the classes of a plan side by side on two streams
  *   "one_pass"            "0": always the two-pass binning
@@ -359,7 +364,8 @@ PWPP_API int pwpp_pipe_destroy(pwpp_pipe *pipe);
  *                         the frames that overflowed
  *   "one_pass_min_frames" smallest batch that takes the one-pass binning (default 1; rounds 1-3: 5 for stream batches, whose state
  *                         must be copied aside for a redo -- the binning pipeline now copies it itself, off the chain)
- *   "one_pass_scale"      segment size of a bin in multiples of its even share of a frame (default 4)
+ *   "one_pass_scale"      scales the head-room of the one-pass segments (default 4 = 1.0625 x the largest count seen + 2 sqrt + 16 slots; tests
+ *                         use small values to force overflows: first the arena, then the host's redo)
  *   "overlap_ranges"      frame ranges of the overlap mode (default 2; more were slower: 3.38 ms vs 2.86 ms with 4)
  *   "overlap_mode"        "1" (default): binning and lists on the main stream, the ranges' fits on "fit_streams" more;
  *                         "0": every range as a whole pipeline, alternating between two streams
@@ -379,6 +385,7 @@ PWPP_API int pwpp_pipe_destroy(pwpp_pipe *pipe);
  *                         binning kernel to finish a frame runs it in place);
  *                         64: before a call that skips the clearing kernel (the last call's K5 zeroed this call's counters),
  *                         read the counters back and fail with PWPP_E_STATE unless every word is zero;
+ *                         2048: no overflow arena (a full segment sends its frame back to the host, as in rounds 2-5);
  *                         16384 / 32768: force the fall-back paths of the lowest-point selection
  * Returns PWPP_E_ARG for an unknown name or a value out of range. */
 PWPP_API int pwpp_set_option(pwpp_handle *h, const char *name, const char *value);

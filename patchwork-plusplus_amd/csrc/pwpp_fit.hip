@@ -2401,7 +2401,8 @@ extern "C" const char *pwpp_big_batch_plan(int max_n, int num_bins, int wide) {
     if (!((double)max_n / (double)(num_bins > 0 ? num_bins : 1) < 500.0)) return PWPP_DENSE_FIT_PLAN;
     return wide ? PWPP_DEFAULT_FIT_PLAN_WIDE : PWPP_DEFAULT_FIT_PLAN;
 }
-#define PWPP_LATENCY_FIT_PLAN "H64:1023"
+#define PWPP_LATENCY_FIT_PLAN "H64:511"  // (round 6, both grids: four waves from 512 points up -- frames 4 and 5 of the KITTI samples 102 -> 94 and 144 -> 123 us,
+                                         // the others unchanged: profiles/r06_latency_plans.txt; rounds 3-5: from 1024 up)
 // `aux` (optional): a second stream + two events, for the fit_concurrent option (classes of a plan side by side).
 extern "C" int pwpp_launch_fit(const PwppBatch *batch, hipStream_t stream, hipEvent_t *ev, hipStream_t aux,
                                hipEvent_t aux_fork, hipEvent_t aux_join) {
