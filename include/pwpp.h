@@ -193,7 +193,7 @@ PWPP_API int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32
  *     (a split frame's differing patch decision enters the elevation history).  On the reference's own KITTI samples: identical index
  *     sets with every build, plane normals within 3.1e-5 of the float build's and 6e-8 of the exact build's.
  *     Option "exact_moments" = 0 selects rounds 3-5's coarser 2^-21 m grid (contract v3: |Q| <= 2^26, nine multiply-adds per point instead of
- *     twenty-one): 8-9 % faster on 1024-frame batches (2.34 vs 2.54 ms per batch on one MI355X), 6-9 us on a single frame -- and off the unanimous
+ *     twenty-one): 7 % faster on 1024-frame batches (2.36 vs 2.52 ms per batch on one MI355X), 5-6 us on a single frame -- and off the unanimous
  *     reference by 1-31 indices of ~120 000 on 0.2 % of varied frames (18 of the 10 032 above), because that grid is coarser than the float
  *     ulp of heights around -1.7 m and of |x|, |y| < 4 m.  Both widths are tested bit for bit against their restatements.
  * (NaN heights are undefined in the reference itself: it sorts bins with `a.z < b.z`.)
@@ -355,7 +355,7 @@ PWPP_API int pwpp_pipe_destroy(pwpp_pipe *pipe);
  * PWPP_HI_SPLIT_ZONES and PWPP_EXACT_MOMENTS set the same options ONCE, in pwpp_create (which says so on stderr); nothing reads the
  * environment afterwards.  None of them changes a result, except the one that says so:
  *   "exact_moments"       "1" (default): the plane-fit sums of 4+ points exact on the reference's floats (2^-30 m grid, contract v4);
- *                         "0": rounds 3-5's 2^-21 m grid -- 8-9 % faster, off the reference by a few indices on 0.2 % of varied frames
+ *                         "0": rounds 3-5's 2^-21 m grid -- 7 % faster, off the reference by a few indices on 0.2 % of varied frames
  *                         (see pwpp_get_ground_indices above).  May be changed between calls.
  *   "fit_plan"            which fit kernel handles which patch sizes, e.g. "W16:1023,W64.2:65535"; "" = automatic
  *   "fit_concurrent"      "1": the classes of a plan side by side on two streams
