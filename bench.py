@@ -205,7 +205,9 @@ def estimate_memory_gb(args):
     main = args.frames * pts * (16.0 * max(1, min(4, args.in_flight)) + 30.0 * handles)
     extras = 0.0
     if args.gpus == 1 and not args.skip_extras and args.workload == "kitti":
-        extras = max(args.dense_frames * 480e3 * (16.0 + 2 * 30.0), args.distinct_frames * 125e3 * (2 * 16.0 + 3 * 36.0))
+        # (measured, round 6: 1024 dense frames from 64 clouds hold 48 GB per handle -- the segments follow every part's largest count over
+        # all clouds -- 1024 varied 64-beam frames 15 GB; both legs keep two handles)
+        extras = max(args.dense_frames * 480e3 * (16.0 + 2 * 100.0), args.distinct_frames * 125e3 * (2 * 16.0 + 2 * 125.0 + 2 * 36.0))
     return (main + extras) / 1e9 + 2.0
 
 

@@ -598,6 +598,128 @@ __device__ __forceinline__ void moments_to_16(const M &mm, long long (&v)[16]) {
 __device__ __forceinline__ __int128 join_halves(long long lo, long long hi) { return ((__int128)hi << 32) + (__int128)lo; }
 
 
+// The 64 keys a 16-lane row kept (four per lane, ascending in every lane) in ascending order over element 4 * lane + register: a
+// bitonic merge network, lane pairs -> quads -> eights -> the row.  A merge of two ascending halves is one compare-exchange with the
+// MIRRORED element (i <-> 2m - 1 - i: the partner lane's registers in reverse) followed by half-cleaners at distances m / 2 ... 1.
+// Lane distances 1, 2 (quad_perm), 4 (row_shl / row_shr under bank masks), 8 (row_ror:8), mirrors of 4, 8, 16 lanes (quad_perm [3,2,1,0],
+// row_half_mirror, row_mirror) are DPP moves inside the row -- 13 cross-lane steps of four registers and 8 in-lane ones, ~250 dependent-
+// chain-short VALU instructions where the extraction of the 20 lowest took 20 rounds of ~30 with a row reduction each (round 6).
+#define PWPP_DPPU(x, ctrl) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ unsigned dpp_lane_xor4(unsigned x) {
+    int t = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x104 /* row_shl:4 */, 0xF, 0x5, false);  // lanes 0-3, 8-11 <- lane + 4
+    t = __builtin_amdgcn_update_dpp(t, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xA, false);           // lanes 4-7, 12-15 <- lane - 4
+    return (unsigned)t;
+}
+__device__ __forceinline__ unsigned cex_keep(unsigned x, unsigned p, bool keep_min) { return keep_min ? (p < x ? p : x) : (p > x ? p : x); }
+__device__ __forceinline__ void row16_sort64(unsigned &k0, unsigned &k1, unsigned &k2, unsigned &k3) {
+    const int l = lane_id() & 15;
+    auto in_lane = [&]() {  // distances 2 and 1 inside the lane's four elements
+        ce(k0, k2);
+        ce(k1, k3);
+        ce(k0, k1);
+        ce(k2, k3);
+    };
+#define PWPP_MIRROR_STEP(ctrl, keep)                                                                          \
+    {                                                                                                         \
+        const unsigned p0 = PWPP_DPPU(k3, ctrl), p1 = PWPP_DPPU(k2, ctrl), p2 = PWPP_DPPU(k1, ctrl), p3 = PWPP_DPPU(k0, ctrl); \
+        k0 = cex_keep(k0, p0, keep);                                                                          \
+        k1 = cex_keep(k1, p1, keep);                                                                          \
+        k2 = cex_keep(k2, p2, keep);                                                                          \
+        k3 = cex_keep(k3, p3, keep);                                                                          \
+    }
+#define PWPP_XOR_STEP(MOVE, keep)                                                                             \
+    {                                                                                                         \
+        const unsigned p0 = MOVE(k0), p1 = MOVE(k1), p2 = MOVE(k2), p3 = MOVE(k3);                            \
+        k0 = cex_keep(k0, p0, keep);                                                                          \
+        k1 = cex_keep(k1, p1, keep);                                                                          \
+        k2 = cex_keep(k2, p2, keep);                                                                          \
+        k3 = cex_keep(k3, p3, keep);                                                                          \
+    }
+#define PWPP_MV_X1(x) PWPP_DPPU(x, PWPP_DPP_XOR1)
+#define PWPP_MV_X2(x) PWPP_DPPU(x, PWPP_DPP_XOR2)
+#define PWPP_MV_X4(x) dpp_lane_xor4(x)
+#define PWPP_MV_X8(x) PWPP_DPPU(x, 0x128 /* row_ror:8 */)
+    const bool b0 = (l & 1) == 0, b1 = (l & 2) == 0, b2 = (l & 4) == 0, b3 = (l & 8) == 0;
+    // pairs of lanes (8 elements)
+    PWPP_MIRROR_STEP(PWPP_DPP_XOR1, b0)
+    in_lane();
+    // quads (16)
+    PWPP_MIRROR_STEP(0x1B /* quad_perm [3,2,1,0] */, b1)
+    PWPP_XOR_STEP(PWPP_MV_X1, b0)
+    in_lane();
+    // eights (32)
+    PWPP_MIRROR_STEP(PWPP_DPP_HMIR, b2)
+    PWPP_XOR_STEP(PWPP_MV_X2, b1)
+    PWPP_XOR_STEP(PWPP_MV_X1, b0)
+    in_lane();
+    // the row (64)
+    PWPP_MIRROR_STEP(PWPP_DPP_MIR, b3)
+    PWPP_XOR_STEP(PWPP_MV_X4, b2)
+    PWPP_XOR_STEP(PWPP_MV_X2, b1)
+    PWPP_XOR_STEP(PWPP_MV_X1, b0)
+    in_lane();
+    // (a 16-lane row that holds a BITONIC sequence of 64 keys -- 32 ascending in lanes 0-7, 32 descending in lanes 8-15 -- is sorted by
+    // the half-cleaners alone: row16_clean64 below, used to merge the lowest keys of two rows of a 64-lane row)
+#undef PWPP_MIRROR_STEP
+#undef PWPP_XOR_STEP
+#undef PWPP_MV_X1
+#undef PWPP_MV_X2
+#undef PWPP_MV_X4
+#undef PWPP_MV_X8
+}
+__device__ __forceinline__ void row16_clean64(unsigned &k0, unsigned &k1, unsigned &k2, unsigned &k3) {
+    const int l = lane_id() & 15;
+    const bool b0 = (l & 1) == 0, b1 = (l & 2) == 0, b2 = (l & 4) == 0, b3 = (l & 8) == 0;
+    auto xstep = [&](auto mover, bool keep) {
+        const unsigned p0 = mover(k0), p1 = mover(k1), p2 = mover(k2), p3 = mover(k3);
+        k0 = cex_keep(k0, p0, keep);
+        k1 = cex_keep(k1, p1, keep);
+        k2 = cex_keep(k2, p2, keep);
+        k3 = cex_keep(k3, p3, keep);
+    };
+    xstep([](unsigned x) { return PWPP_DPPU(x, 0x128 /* row_ror:8 */); }, b3);
+    xstep([](unsigned x) { return dpp_lane_xor4(x); }, b2);
+    xstep([](unsigned x) { return PWPP_DPPU(x, PWPP_DPP_XOR2); }, b1);
+    xstep([](unsigned x) { return PWPP_DPPU(x, PWPP_DPP_XOR1); }, b0);
+    ce(k0, k2);
+    ce(k1, k3);
+    ce(k0, k1);
+    ce(k2, k3);
+}
+// The 32 lowest of the 256 keys a 64-lane row kept, ascending over element 4 * lane + register of lanes 0-7: every 16-lane quarter sorts
+// its 64 keys, then the quarters are merged two at a time -- lanes 8-15 of the receiving quarter take the 32 lowest of the other one in
+// REVERSE (ds_bpermute), which makes the quarter's 64 keys a bitonic sequence whose lower half is the 32 lowest of both.
+__device__ __forceinline__ void row64_lowest32(unsigned &k0, unsigned &k1, unsigned &k2, unsigned &k3) {
+    row16_sort64(k0, k1, k2, k3);
+    const int ln = lane_id(), l = ln & 15, q = ln >> 4;
+    for (int round = 0; round < 2; ++round) {  // quarters 1 -> 0 and 3 -> 2, then 2 -> 0
+        const int step = round == 0 ? 1 : 2;
+        const bool recv = l >= 8 && (q & (2 * step - 1)) == 0;
+        const int src = recv ? ((q + step) * 16 + (15 - l)) : ln;
+        const unsigned p0 = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)k3), p1 = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)k2);
+        const unsigned p2 = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)k1), p3 = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)k0);
+        k0 = recv ? p0 : k0;
+        k1 = recv ? p1 : k1;
+        k2 = recv ? p2 : k2;
+        k3 = recv ? p3 : k3;
+        row16_clean64(k0, k1, k2, k3);
+    }
+}
+// sum of a double over a 16-lane row (every lane gets it): exact whatever the order only where the caller has made sure of that
+__device__ __forceinline__ double row16_sum_f64(double v) {
+    auto step = [&](auto mover) {
+        const long long b = __double_as_longlong(v);
+        const int lo = (int)(unsigned)(unsigned long long)b, hi = (int)((unsigned long long)b >> 32);
+        const unsigned long long o = ((unsigned long long)(unsigned)mover(hi) << 32) | (unsigned)mover(lo);
+        v += __longlong_as_double((long long)o);
+    };
+    step([](int x) { return PWPP_DPP(x, PWPP_DPP_XOR1); });
+    step([](int x) { return PWPP_DPP(x, PWPP_DPP_XOR2); });
+    step([](int x) { return PWPP_DPP(x, PWPP_DPP_HMIR); });
+    step([](int x) { return PWPP_DPP(x, PWPP_DPP_MIR); });
+    return v;
+}
+
 // LPR (ref :84-103) of streamed rows, normally in ONE pass over the points: every lane keeps its
 // four smallest eligible keys and the smallest key it had to drop.  The keff smallest of the
 // 4G kept keys are extracted in ascending order; they are the keff smallest of the row unless
@@ -657,8 +779,73 @@ __device__ double srow_lpr(const PatchRef &pts, bool need, bool use_cutoff, doub
     const int keff = total < num_lpr ? total : num_lpr;  // row-uniform
     double sum = 0.0;
     unsigned T = 0;
+    bool quick = false;  // (row-uniform) the sorted-row shortcut below has delivered sum and T
+    if constexpr (G == 16) {
+        // Round 6: SORT the row's 64 kept keys (row16_sort64) instead of extracting the lowest one by one.  The keff lowest are then
+        // elements 0 .. keff - 1, T is element keff - 1, and their sum is order-free -- hence equal to the reference's ascending sum,
+        // ref :99-101 -- whenever every one of them is 0 or has 2^-12 <= |z| < 2^8: multiples of 2^-35 whose partial sums stay below
+        // 2^14, exact in a double in any order.  Anything else among the lowest (a denormal, a height of a kilometre, inf, the INF of
+        // a row that kept fewer than keff keys) takes the extraction loop below, which works on the sorted registers just as well.
+        if (__any(need && keff > 0 && keff <= 64)) {
+            row16_sort64(k0, k1, k2, k3);
+            const unsigned kk[4] = {k0, k1, k2, k3};
+            double part = 0.0;
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool sel = 4 * j + r < keff;
+                const float zv = key_z(kk[r]);
+                const unsigned e = (__float_as_uint(zv) >> 23) & 0xffu;
+                ok = ok && (!sel || zv == 0.0f || (e >= 115u && e < 135u));
+                part += sel ? (double)zv : 0.0;
+            }
+            quick = need && keff > 0 && keff <= 64 && Row<G>::ballot(!ok) == 0ull;
+            const double s = row16_sum_f64(part);
+            const int last = keff > 0 ? keff - 1 : 0;
+            const unsigned pick = (last & 3) == 0 ? k0 : ((last & 3) == 1 ? k1 : ((last & 3) == 2 ? k2 : k3));
+            const unsigned t = (unsigned)__shfl((int)pick, last >> 2, 16);
+            if (quick) {
+                sum = s;
+                T = t;
+            }
+        }
+    }
+    if constexpr (G == 64) {
+        // the same for a 64-lane row (one patch per wave here: everything below is wave-uniform): the 32 lowest of its 256 kept keys,
+        // sorted, in lanes 0-7 (row64_lowest32); the registers are put back if the shortcut cannot be taken
+        if (need && keff > 0 && keff <= 32) {
+            const unsigned o0 = k0, o1 = k1, o2 = k2, o3 = k3;
+            row64_lowest32(k0, k1, k2, k3);
+            const unsigned kk[4] = {k0, k1, k2, k3};
+            double part = 0.0;
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool sel = j < 8 && 4 * j + r < keff;
+                const float zv = key_z(kk[r]);
+                const unsigned e = (__float_as_uint(zv) >> 23) & 0xffu;
+                ok = ok && (!sel || zv == 0.0f || (e >= 115u && e < 135u));
+                part += sel ? (double)zv : 0.0;
+            }
+            quick = __ballot(!ok) == 0ull;
+            const double s = row16_sum_f64(part);  // (lanes 0-15: the sum of lanes 0-7's parts)
+            const int last = keff - 1;
+            const unsigned pick = (last & 3) == 0 ? k0 : ((last & 3) == 1 ? k1 : ((last & 3) == 2 ? k2 : k3));
+            if (quick) {
+                const long long sb = __double_as_longlong(s);
+                const unsigned slo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)sb, 0);
+                const unsigned shi = (unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)sb >> 32), 0);
+                sum = __longlong_as_double((long long)(((unsigned long long)shi << 32) | slo));
+                T = (unsigned)__builtin_amdgcn_readlane((int)pick, last >> 2);
+            }
+            k0 = o0;
+            k1 = o1;
+            k2 = o2;
+            k3 = o3;
+        }
+    }
     for (int r = 0; r < num_lpr; ++r) {  // the keff smallest kept keys, ascending
-        const bool take = need && r < keff;
+        const bool take = need && !quick && r < keff;
         if (!__any(take)) break;
         const unsigned m = Row<G>::min_u32(k0);
         if (take) {
