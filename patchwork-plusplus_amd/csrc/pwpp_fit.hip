@@ -2055,7 +2055,36 @@ __device__ double brow_lpr(BRowShared &sh, const PatchRef &pts, bool use_hi, boo
     const int keff = total < num_lpr ? total : num_lpr;
     double sum = 0.0;
     unsigned T = 0;
-    for (int r = 0; r < keff; ++r) {  // workgroup-uniform trip count
+    // Round 6 (as in srow_lpr): the 32 lowest of the wave's 256 kept keys by a merge network instead of keff extraction rounds with a
+    // wave reduction each (20 x ~250 cycles = 2 us of the single-frame chain per lowest-point selection), their sum order-free where
+    // that is exact; otherwise the extraction loop on the untouched registers.  (A patch of one chunk lives in wave 0: the other waves
+    // hold no keys, extract nothing and take wave 0's result below.)
+    bool quick = false;
+    const int kx = (single && wv != 0) ? 0 : keff;
+    if (kx > 0 && kx <= 32) {
+        unsigned s0 = k0, s1 = k1, s2 = k2, s3 = k3;
+        row64_lowest32(s0, s1, s2, s3);
+        const unsigned kk[4] = {s0, s1, s2, s3};
+        double part = 0.0;
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool sel = ln < 8 && 4 * ln + r < kx;
+            const float zv = key_z(kk[r]);
+            const unsigned e = (__float_as_uint(zv) >> 23) & 0xffu;
+            ok = ok && (!sel || zv == 0.0f || (e >= 115u && e < 135u));
+            part += sel ? (double)zv : 0.0;
+        }
+        quick = __ballot(!ok) == 0ull;
+        if (quick) {
+            const double s = row16_sum_f64(part);
+            sum = __longlong_as_double(readlane_i64(__double_as_longlong(s), 0));
+            const int last = kx - 1;
+            const unsigned pick = (last & 3) == 0 ? s0 : ((last & 3) == 1 ? s1 : ((last & 3) == 2 ? s2 : s3));
+            T = (unsigned)__builtin_amdgcn_readlane((int)pick, last >> 2);
+        }
+    }
+    for (int r = 0; r < (quick ? 0 : kx); ++r) {  // (wave-uniform trip count; no barrier inside)
         const unsigned m = Row<64>::min_u32(k0);
         sum += (double)key_z(m);
         T = m;
