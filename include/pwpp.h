@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define PWPP_VERSION_MAJOR 0
-#define PWPP_VERSION_MINOR 1
+#define PWPP_VERSION_MINOR 2 /* round 6: pwpp_pipe_submit takes a mode; pwpp_pipe_set_num_streams, pwpp_get_arena_stats; option exact_moments */
 
 typedef enum pwpp_status {
     PWPP_OK = 0,
