@@ -732,7 +732,8 @@ __device__ __forceinline__ double row16_sum_f64(double v) {
 // the patch are all there and the high part is not read; otherwise the pass goes on through the high part.
 template <int G>
 __device__ double srow_lpr(const PatchRef &pts, bool need, bool use_cutoff, double cutoff,
-                           int num_lpr, int force = 0 /* tests: 1 = take the second pass, 2 = and the exact extraction (PWPP_DEBUG_FLAGS 16384 / 32768) */) {
+                           int num_lpr, int force = 0 /* tests: 1 = take the second pass, 2 = and the exact extraction (PWPP_DEBUG_FLAGS 16384 / 32768) */,
+                           const ChunkZ *first = nullptr /* the first chunk of the low part, already requested by the caller (load_chunk_z with need ? n_lo : 0) */) {
 #ifdef PWPP_ABLATE_NO_LPR  // (timing experiments only: no lowest-point pass)
     return -1.75;
 #endif
@@ -742,14 +743,15 @@ __device__ double srow_lpr(const PatchRef &pts, bool need, bool use_cutoff, doub
     int elig = 0;
     // (the pass is a pure latency chain -- eight loads, ~100 instructions -- so the next chunk's z values are requested
     // before this chunk's are ranked: eight registers, in a phase that is far from the kernels' register peak)
-    auto rank_part = [&](unsigned off, unsigned n, unsigned nchunks) {
+    auto rank_part = [&](unsigned off, unsigned n, unsigned nchunks, const ChunkZ *pre) {
         PartSel sel;
         sel.off = off;
         sel.n = n;
         sel.c = 0u;
         sel.moff = 0u;
         ChunkZ cp;
-        if (nchunks > 0u) load_chunk_z<G>(cp, pts, sel);
+        if (pre) cp = *pre;
+        else if (nchunks > 0u) load_chunk_z<G>(cp, pts, sel);
         for (unsigned c = 0; c < nchunks; ++c) {
             ChunkZ nx;
             sel.c = c + 1u;
@@ -769,11 +771,11 @@ __device__ double srow_lpr(const PatchRef &pts, bool need, bool use_cutoff, doub
             if (c + 1u < nchunks) cp = nx;
         }
     };
-    rank_part(pts.off_lo, need ? pts.n_lo : 0u, wave_max_u32(need ? part_chunks<G>(pts.n_lo) : 0u));
+    rank_part(pts.off_lo, need ? pts.n_lo : 0u, wave_max_u32(need ? part_chunks<G>(pts.n_lo) : 0u), first);
     int total = Row<G>::sum_i32(elig);
     const bool use_hi = need && pts.n_hi > 0u && total < num_lpr;  // row-uniform
     if (__any(use_hi)) {
-        rank_part(pts.off_hi, use_hi ? pts.n_hi : 0u, wave_max_u32(use_hi ? part_chunks<G>(pts.n_hi) : 0u));
+        rank_part(pts.off_hi, use_hi ? pts.n_hi : 0u, wave_max_u32(use_hi ? part_chunks<G>(pts.n_hi) : 0u), nullptr);
         total = Row<G>::sum_i32(elig);
     }
     const int keff = total < num_lpr ? total : num_lpr;  // row-uniform
@@ -1405,14 +1407,38 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
         const bool need_lpr = (O(kind) == ST_VPF || O(kind) == ST_SEED) && !O(lpr_valid);
         const unsigned long long lpr_mask = __ballot(need_lpr);
         if (lpr_mask) {
-            for (int sb = 0; sb < NSB; ++sb) {
-                if (((lpr_mask >> (R * sb)) & ((1ull << R) - 1ull)) == 0ull) continue;
+            // (16-lane rows: the z pass is the FIRST touch of a patch -- every sub-batch waited for its own HBM round trip, sixteen in
+            // a row.  The first chunk of the NEXT sub-batch that needs a pass is requested before this one's keys are ranked and
+            // sorted: eight registers, in a phase far from the kernel's register peak.  Round 6.)
+            constexpr bool kAhead = G == 16;
+            auto sb_needs = [&](int sb) { return sb < NSB && ((lpr_mask >> (R * sb)) & ((1ull << R) - 1ull)) != 0ull; };
+            auto request = [&](int sb, ChunkZ &cz) {
+                const int q = R * sb + row;
+                const bool need_row = (lpr_mask >> q) & 1ull;
+                const PatchRef qpts = patch_ref(Bt, fd, sh.p[q].off_lo, sh.p[q].n_lo, sh.p[q].off_hi, sh.p[q].n_hi);
+                PartSel sel;
+                sel.off = qpts.off_lo;
+                sel.n = need_row ? qpts.n_lo : 0u;
+                sel.c = 0u;
+                sel.moff = 0u;
+                load_chunk_z<G>(cz, qpts, sel);
+            };
+            ChunkZ ahead;
+            int sb = 0;
+            while (sb < NSB && !sb_needs(sb)) ++sb;
+            if (kAhead && sb < NSB) request(sb, ahead);
+            for (; sb < NSB;) {
+                int nxt = sb + 1;
+                while (nxt < NSB && !sb_needs(nxt)) ++nxt;
+                const ChunkZ cur = ahead;
+                if (kAhead && nxt < NSB) request(nxt, ahead);
                 const int q = R * sb + row;
                 const bool need_row = (lpr_mask >> q) & 1ull;
                 const bool use_cutoff = (sh.p[q].flags & 2) != 0;
                 const PatchRef qpts = patch_ref(Bt, fd, sh.p[q].off_lo, sh.p[q].n_lo, sh.p[q].off_hi, sh.p[q].n_hi);
-                const double l = srow_lpr<G>(qpts, need_row, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3);
+                const double l = srow_lpr<G>(qpts, need_row, use_cutoff, cutoff, P.num_lpr, (Bt.debug >> 14) & 3, kAhead ? &cur : nullptr);
                 if (need_row && j == 0) sh.p[q].u.lpr = l;
+                sb = nxt;
             }
             wave_lds_sync();
             if (need_lpr) {
