@@ -1779,6 +1779,23 @@ def test_overflow_arena_moves_parts_on_the_device(kitti, oracle):
             assert_frame_equal(h, i, r, odd2[i].shape[0], check_state=False)
             if ordered:
                 assert np.array_equal(odd2[i][h.ground_indices(i), 2], odd2[i][r.ground_idx, 2])
+    # a PSEUDO-bin outgrows its segment (2 500 more returns beyond max_range than any frame before: indices only are moved), and a batch
+    # of 24 frames (arena on, the small-batch variants of K5 / K6)
+    far = kitti[1][np.hypot(kitti[1][:, 0], kitti[1][:, 1]) > 40.0]
+    extra = far[rng.choice(len(far), 2500, replace=True)].copy()
+    extra[:, :2] *= 2.6  # 104 m and more: out of range
+    d2 = np.ascontiguousarray(np.concatenate([kitti[1], extra]).astype(np.float32))
+    r2 = est(d2)
+    assert len(r2.nonground_idx) >= len(refs[1].nonground_idx) + 2500
+    h = pwpp_hip.Handle()
+    small = [kitti[i % 6] for i in range(24)]
+    h.estimate_ground_batch(small, mode=pwpp_hip.MODE_FRESH)
+    odd3 = list(small)
+    odd3[7], odd3[20] = d2, d0
+    h.estimate_ground_batch(odd3, mode=pwpp_hip.MODE_FRESH)
+    assert h.redo_stats() == (48, 0) and h.arena_stats()[0] == 2, (h.redo_stats(), h.arena_stats())
+    for i, r in ((7, r2), (20, special[10]), (6, refs[0]), (8, refs[2]), (23, refs[5])):
+        assert_frame_equal(h, i, r, odd3[i].shape[0])
     # stateful streams: 70 in lock-step, stream 33 meets the dense frame at step 2 -- no state restore, no redo
     S = 70
     hs = pwpp_hip.Handle()
