@@ -124,3 +124,38 @@ def test_hip_path_equals_the_consensus_of_the_three_reference_builds():
     assert rep["consensus_frames"] == 204 and rep["product_equals_consensus"] == 204 and rep["consensus_misses"] == [], rep["consensus_misses"]
     assert [d["frame"] for d in rep["split_frames"]] == [19, 137, 144, 185], rep["split_frames"]
     assert all(d["product_vs_exact"] == 0 for d in rep["split_frames"]), rep["split_frames"]
+
+
+def _reference_job(i):
+    pts = pwpp_synth.varied_frame(40000 + i)
+    out = [pts]
+    for _, arith in FLAVOURS:
+        r = ol.Estimator(ol.reference(arith), arith=arith).run(pts)
+        out.append((np.sort(r.ground_idx), np.sort(r.nonground_idx)))
+    return out
+
+
+@pytest.mark.gpu
+def test_hip_path_directly_against_the_reference_builds_on_unseen_frames():
+    """No restatement in between: 384 varied frames no other test uses, through the three builds of the reference's
+    own source (forked workers) and through libpwpp_hip.so in one batch.  Unanimous builds -> the HIP path returns exactly their ground
+    AND non-ground lists; split builds -> it equals one of them.  (tools/hip_vs_reference.py is the same on 16 384 frames:
+    15 892 / 15 892 and 492 / 492, profiles/r06_hip_vs_reference_16384_frames.txt.)"""
+    import multiprocessing as mp
+    n = 384
+    with mp.get_context("fork").Pool(min(32, max(1, (os.cpu_count() or 2) // 2))) as pool:
+        ref = pool.map(_reference_job, range(n), chunksize=4)
+    import pwpp_hip
+    h = pwpp_hip.Handle()
+    h.estimate_ground_batch([c[0] for c in ref], mode=pwpp_hip.MODE_FRESH)
+    unanimous = split = 0
+    for i, c in enumerate(ref):
+        g, ng = np.sort(h.ground_indices(i)), np.sort(h.nonground_indices(i))
+        same = [np.array_equal(g, c[k][0]) and np.array_equal(ng, c[k][1]) for k in (1, 2, 3)]
+        if all(np.array_equal(c[1][0], c[k][0]) for k in (2, 3)):
+            unanimous += 1
+            assert all(same), "frame %d: the three builds of the reference agree, the HIP path differs by %d indices" % (40000 + i, np.setxor1d(g, c[1][0]).size)
+        else:
+            split += 1
+            assert any(same), "frame %d: the builds split and the HIP path equals none of them" % (40000 + i)
+    assert unanimous >= 0.9 * n and unanimous + split == n
