@@ -294,10 +294,11 @@ struct MomentsT<false> {
 #pragma unroll
         for (int k = 0; k < 6; ++k) s2[k] = 0;
     }
-    // (the caller adds the number of points itself, e.g. the population count of a chunk's mask)
-    __device__ __forceinline__ void add_uncounted(float x, float y, float z, double scale, const FxpOrg &o) {
+    // (the caller adds the number of points itself, e.g. the population count of a chunk's mask, and hands over the height already
+    // clamped to [zlo, zhi]: fxp_clamp_z -- it wants to know whether the clamp acted)
+    __device__ __forceinline__ void add_uncounted(float x, float y, float zc, double scale, const FxpOrg &o) {
         const int qx = fxp_q(x, scale, o.cx), qy = fxp_q(y, scale, o.cy);
-        const int qz = fxp_q(__builtin_amdgcn_fmed3f(z, o.zlo, o.zhi), scale, o.cz);  // (a NaN z never gets here: every test on it fails)
+        const int qz = fxp_q(zc, scale, o.cz);  // (a NaN z never gets here: every test on it fails)
         // first moments as multiply-adds by a 1 the compiler cannot see through: ONE v_mad_i64_i32 each, where the plain
         // 64-bit add of a sign-extended int is a shift and an add
         int one = 1;
@@ -314,7 +315,7 @@ struct MomentsT<false> {
     }
     __device__ __forceinline__ void add(float x, float y, float z, double scale, const FxpOrg &o) {
         n += 1;
-        add_uncounted(x, y, z, scale, o);
+        add_uncounted(x, y, __builtin_amdgcn_fmed3f(z, o.zlo, o.zhi), scale, o);
     }
     // this lane's sums once its pass is over (n final)
     __device__ __forceinline__ long long first(int k) const { return s1[k]; }
@@ -337,10 +338,10 @@ struct MomentsT<true> {
             ll[k] = 0u;
         }
     }
-    __device__ __forceinline__ void add_uncounted(float x, float y, float z, double scale, const FxpOrg &o) {
+    __device__ __forceinline__ void add_uncounted(float x, float y, float zc, double scale, const FxpOrg &o) {
         const unsigned long long tx = (unsigned long long)__double_as_longlong(__builtin_fma((double)x, scale, o.cx));
         const unsigned long long ty = (unsigned long long)__double_as_longlong(__builtin_fma((double)y, scale, o.cy));
-        const unsigned long long tz = (unsigned long long)__double_as_longlong(__builtin_fma((double)__builtin_amdgcn_fmed3f(z, o.zlo, o.zhi), scale, o.cz));
+        const unsigned long long tz = (unsigned long long)__double_as_longlong(__builtin_fma((double)zc, scale, o.cz));
         s1b[0] += tx;
         s1b[1] += ty;
         s1b[2] += tz;
@@ -376,7 +377,7 @@ struct MomentsT<true> {
     }
     __device__ __forceinline__ void add(float x, float y, float z, double scale, const FxpOrg &o) {
         n += 1;
-        add_uncounted(x, y, z, scale, o);
+        add_uncounted(x, y, __builtin_amdgcn_fmed3f(z, o.zlo, o.zhi), scale, o);
     }
     __device__ __forceinline__ long long first(int k) const {
         const unsigned long long b = k == 0 ? s1b[0] : (k == 1 ? s1b[1] : s1b[2]);

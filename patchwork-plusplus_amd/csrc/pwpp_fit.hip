@@ -466,9 +466,12 @@ __device__ __forceinline__ unsigned chunk_slot(const PartSel &sel, int k, unsign
 //   no branch on the stage.  The test itself is  s < T  in float, T = plane_test_threshold(d, thr) of the pass
 //   (pwpp_common.hpp): bit for bit the reference's  double(s) + d < thr.  A point R-VPF removed has a NaN for its z
 //   (strip_point) and fails like any NaN; a slot beyond the part's end holds a stand-in record and is masked by `rem`.
+// `clamp_hit` (or-ed into): some point that entered the sums lay outside z0 +- ZR, i.e. its quantised height was clamped (flag_clamped
+// below says what that means; found here, where the clamped height is formed anyway -- one compare per included point instead of four
+// per slot in a loop of its own).
 template <int G, class M>
 __device__ __forceinline__ unsigned lane_stage_accum(const ChunkPts &cp, int kind, float T, float nx, float ny, float nz,
-                                                     double scale, const FxpOrg &org, M &m) {
+                                                     double scale, const FxpOrg &org, M &m, bool &clamp_hit) {
     const bool iter = kind == ST_ITER;
     const float tx = iter ? nx : 0.0f, ty = iter ? ny : 0.0f, tz = iter ? nz : 1.0f;
     unsigned gmask = 0;
@@ -479,7 +482,9 @@ __device__ __forceinline__ unsigned lane_stage_accum(const ChunkPts &cp, int kin
         if ((int)(plane_s(tx, ty, tz, cp.x[k], cp.y[k], cp.z[k]) < T) & (int)(k_off<G>(k) < cp.rem)) {  // (a branch on purpose: a seed pass includes about half of the points, an R-GPF round ~60 %)
             gmask |= 1u << k;
 #ifndef PWPP_ABLATE_NO_ACCUM  // (timing experiments only: the pass without its sums)
-            m.add_uncounted(cp.x[k], cp.y[k], cp.z[k], scale, org);
+            const float zc = __builtin_amdgcn_fmed3f(cp.z[k], org.zlo, org.zhi);
+            clamp_hit = clamp_hit || zc != cp.z[k];
+            m.add_uncounted(cp.x[k], cp.y[k], zc, scale, org);
 #endif
         }
     }
@@ -515,15 +520,10 @@ __device__ __forceinline__ unsigned lane_strip(const ChunkPts &cp, bool on, floa
     return hit;
 }
 
-// Did a height of the FINAL ground set of a patch lie outside z0 +- ZR (its quantised value was clamped, Moments)?  Checked in
-// the passes that leave a set in the membership plane, and counted only if that set is final; the frame is flagged (PwppFrameResult.overflow bit 2, pwpp_get_clamped_frames): the
-// plane of such a patch -- more than 32 m tall with the default CZM -- is the plane of the clamped heights (include/pwpp.h).
-__device__ __forceinline__ bool chunk_clamped(const ChunkPts &cp, unsigned gm, const FxpOrg &org) {
-    bool hit = false;
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) hit = hit || ((gm >> k & 1u) && !(cp.z[k] >= org.zlo && cp.z[k] <= org.zhi));
-    return hit;
-}
+// Did a height of the FINAL ground set of a patch lie outside z0 +- ZR (its quantised value was clamped, Moments)?  Noticed where the
+// clamped height is formed (lane_stage_accum's clamp_hit) in the passes that leave a set in the membership plane, and counted only if that
+// set is final; the frame is flagged (PwppFrameResult.overflow bit 2, pwpp_get_clamped_frames): the plane of such a patch -- more than 32 m
+// tall with the default CZM -- is the plane of the clamped heights (include/pwpp.h).
 __device__ __forceinline__ void flag_clamped(const PwppBatch &Bt, int f) { atomicOr((unsigned *)&Bt.results[f].overflow, 4u); }
 
 // Contract v3 (pwpp_common.hpp, mean_cov_tiny): a fit set of one, two or three points follows the reference's own float
@@ -1117,11 +1117,10 @@ __device__ __forceinline__ void fit_srows_body(const PwppBatch &Bt, int b_lo, in
         for (unsigned c = 0; c < nchunk_max; ++c) {
             ChunkPts nx;  // the next chunk is in flight while this one is accumulated
             load_chunk<G>(nx, pts, chunk_sel<G>(pts, c + 1u, use_hi, on));
-            const unsigned gmask = lane_stage_accum<G>(cp, kind, T, pl.nx, pl.ny, pl.nz, scale, org, m);
-            if (__any(wbits)) {
-                store_member<G>(frame_member, chunk_sel<G>(pts, c, use_hi, on), gmask, wbits);
-                clamped = clamped || (wbits && chunk_clamped(cp, gmask, org));
-            }
+            bool hit = false;
+            const unsigned gmask = lane_stage_accum<G>(cp, kind, T, pl.nx, pl.ny, pl.nz, scale, org, m, hit);
+            clamped = clamped || (wbits && hit);
+            if (__any(wbits)) store_member<G>(frame_member, chunk_sel<G>(pts, c, use_hi, on), gmask, wbits);
             cp = nx;
         }
         const long long cnt = Row<G>::sum_i64(m.n);
@@ -1524,7 +1523,9 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
             for (unsigned c = 0; c < nchunk_max; ++c) {
                 ChunkPts nx;
                 if (kPrefetch && c + 1u < nchunk_max) load_chunk<G>(nx, pts, chunk_sel<G>(pts, c + 1u, use_hi, on));  // (wave-uniform)
-                const unsigned gmask = lane_stage_accum<G>(cp, pp.kind, pp.u.thr.t, pp.nx, pp.ny, pp.nz, scale, org, m);
+                bool hit = false;
+                const unsigned gmask = lane_stage_accum<G>(cp, pp.kind, pp.u.thr.t, pp.nx, pp.ny, pp.nz, scale, org, m, hit);
+                clamped = clamped || (wbits && hit);
                 if constexpr (DUAL) {
                     if (__any(dual)) {  // the band [thr_seed, thr_band) of a dual seed pass: the heights below t2 that are not in the first set
                         const unsigned rest = dual ? ~gmask : 0u;
@@ -1535,7 +1536,6 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
                 }
                 if (any_wbits) {  // the round's set -> membership plane: the split of the patch if this round turns out to be its last
                     store_member<G>(frame_member, chunk_sel<G>(pts, c, use_hi, on), gmask, wbits);
-                    clamped = clamped || (wbits && chunk_clamped(cp, gmask, org));
                 }
                 if (c + 1u < nchunk_max) {
                     if (kPrefetch)
@@ -2231,7 +2231,9 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
         for (unsigned c = (unsigned)wv; c < nchunk; c += kWaves) {
             ChunkPts nx;  // this wave's next chunk is in flight while this one is accumulated
             load_chunk<64>(nx, pts, chunk_sel<64>(pts, c + kWaves, use_hi));
-            const unsigned gmask = lane_stage_accum<64>(cp, kind, T, pl.nx, pl.ny, pl.nz, scale, org, m);
+            bool hit = false;
+            const unsigned gmask = lane_stage_accum<64>(cp, kind, T, pl.nx, pl.ny, pl.nz, scale, org, m, hit);
+            clamped = clamped || (wbits && hit);
             if (dual_now) {  // the band [thr_seed, thr_band)
                 const unsigned rest = ~gmask;
 #pragma unroll
@@ -2240,7 +2242,6 @@ __device__ __forceinline__ void fit_brows_body(BRowShared &sh, const PwppBatch &
             }
             if (wbits) {  // the round's set -> membership plane (every wave its own chunks)
                 store_member<64>(frame_member, chunk_sel<64>(pts, c, use_hi), gmask, true);
-                clamped = clamped || chunk_clamped(cp, gmask, org);
             }
             cp = nx;
         }
