@@ -244,8 +244,16 @@ __device__ __forceinline__ FxpOrg fxp_org(float ox, float oy, float z0, double s
     o.zhi = z0 + zr;
     return o;
 }
+// v * scale + c as ONE three-operand v_fma_f64.  Left to itself the compiler picks the two-operand v_fmac_f64 for about half of these
+// (shorter encoding), which accumulates into its destination and therefore needs the addend -- a per-pass constant -- copied into a
+// fresh register pair first: ten v_mov_b64 per chunk of the fit kernels' points loop.
+__device__ __forceinline__ double fxp_fma(double v, double scale, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(scale), "v"(c));
+    return r;
+}
 __device__ __forceinline__ int fxp_q(float v, double scale, double c) {
-    return (int)(unsigned)(unsigned long long)__double_as_longlong(__builtin_fma((double)v, scale, c));
+    return (int)(unsigned)(unsigned long long)__double_as_longlong(fxp_fma((double)v, scale, c));
 }
 // z origin of a patch from its first lowest-point representative (ref :103)
 __device__ __forceinline__ float fxp_z_origin(double lpr) {
@@ -339,9 +347,9 @@ struct MomentsT<true> {
         }
     }
     __device__ __forceinline__ void add_uncounted(float x, float y, float zc, double scale, const FxpOrg &o) {
-        const unsigned long long tx = (unsigned long long)__double_as_longlong(__builtin_fma((double)x, scale, o.cx));
-        const unsigned long long ty = (unsigned long long)__double_as_longlong(__builtin_fma((double)y, scale, o.cy));
-        const unsigned long long tz = (unsigned long long)__double_as_longlong(__builtin_fma((double)zc, scale, o.cz));
+        const unsigned long long tx = (unsigned long long)__double_as_longlong(fxp_fma((double)x, scale, o.cx));
+        const unsigned long long ty = (unsigned long long)__double_as_longlong(fxp_fma((double)y, scale, o.cy));
+        const unsigned long long tz = (unsigned long long)__double_as_longlong(fxp_fma((double)zc, scale, o.cz));
         s1b[0] += tx;
         s1b[1] += ty;
         s1b[2] += tz;
@@ -387,10 +395,27 @@ struct MomentsT<true> {
         const bool diag = k == 0 || k == 3 || k == 5;
         return (__int128)hh[k] * 262144 + (__int128)hl[k] * (diag ? 1024 : 512) + (__int128)ll[k];
     }
+    // The sixteen values a 16-lane row adds up for a patch below 1024 points (k_fit_w64<16, .>), none of which leaves int64 there:
+    // n, the three raw bit-pattern sums (the row total minus n times the constant is S1: wide_first), the six hh sums (<= 2^52 per
+    // point), and the six sums 2^9 (H_a L_b + L_a H_b) + L_a L_b (<= 2^46 per point) -- two shifts and an add per pair where the 128-bit
+    // second moment cost twelve instructions per lane and pass; the owner of the patch puts S2 = 2^18 hh + the rest together.
+    __device__ __forceinline__ void to_row16(long long (&v)[16]) const {
+        v[0] = n;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[1 + k] = (long long)s1b[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const bool diag = k == 0 || k == 3 || k == 5;
+            v[4 + k] = hh[k];
+            v[10 + k] = hl[k] * (diag ? 1024 : 512) + (long long)ll[k];
+        }
+    }
 };
+__device__ __forceinline__ long long wide_first(long long raw_total, long long n) { return (long long)((unsigned long long)raw_total - (unsigned long long)n * 0x4338000000000000ull); }
+__device__ __forceinline__ __int128 wide_second(long long hh_total, long long rest_total) { return (__int128)hh_total * 262144 + (__int128)rest_total; }
 // the 36-bit Q itself (the kernels that walk a patch point by point: k_fit_stream)
 __device__ __forceinline__ long long fxp_q_wide(float v, double scale, double c) {
-    const long long t = __double_as_longlong(__builtin_fma((double)v, scale, c));
+    const long long t = __double_as_longlong(fxp_fma((double)v, scale, c));
     return (t << 13) >> 13;  // bits 0..50 of the pattern = Q mod 2^51, sign-extended
 }
 

@@ -1551,7 +1551,8 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
             auto row_totals = [&](const Moments &mm, long long (*dst)[MW], bool store, bool &same) {
                 if constexpr (MW == 16) {
                     long long v[16];
-                    moments_to_16(mm, v);
+                    if constexpr (G == 16) mm.to_row16(v);  // (wide grid, 16-lane rows: the sums as they stand, MomentsT<true>::to_row16)
+                    else moments_to_16(mm, v);
                     int slot16;
                     const long long mine = Row<G>::reduce16_scatter(v, slot16);
                     if (store && j < 16) {
@@ -1650,10 +1651,13 @@ __global__ __launch_bounds__(64, G == 64 ? PWPP_W64_OCC : (WIDE ? PWPP_W16_WIDE_
                     O(stash_valid) = !(stash_cnt >= 1 && stash_cnt <= 3);  // (1-3 seeds: that stage gathers the points, it needs its own pass)
                 }
                 if (cnt > 0 && !conv) {
-                    const long long s1[3] = {tot[1], tot[2], tot[3]};
+                    constexpr bool kRaw = MW == 16 && G == 16;  // (to_row16's values)
+                    const long long s1[3] = {kRaw ? wide_first(tot[1], cnt) : tot[1], kRaw ? wide_first(tot[2], cnt) : tot[2], kRaw ? wide_first(tot[3], cnt) : tot[3]};
                     __int128 s2[6];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) s2[k] = MW == 16 ? join_halves(tot[4 + k], tot[MW == 16 ? 10 + k : 4 + k]) : (__int128)tot[4 + k];
+                    for (int k = 0; k < 6; ++k)
+                        s2[k] = kRaw ? wide_second(tot[4 + k], tot[MW == 16 ? 10 + k : 4 + k])
+                                     : (MW == 16 ? join_halves(tot[4 + k], tot[MW == 16 ? 10 + k : 4 + k]) : (__int128)tot[4 + k]);
                     mean_cov_from_totals(cnt, s1, s2, P.fxp_shift, sh.p[ln].ox, sh.p[ln].oy, O(z0), mean, c6);
                 }
             }
