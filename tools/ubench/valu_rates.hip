@@ -1,155 +1,141 @@
-// valu_rates.hip -- issue cost (cycles per wave-instruction per SIMD) of the VALU operations the fit
-// kernels lean on, measured on the device: N dependent-free copies of one instruction per loop trip,
-// 4 waves per SIMD, s_memtime around the loop of one wave.   hipcc --offload-arch=gfx950 -O3 valu_rates.hip
+// Issue cost of the VALU instructions the fit kernels are made of, per wave-instruction, relative to v_fma_f32 (2 cycles on a SIMD-32).
+// One workgroup of 256 threads per CU (one wave per SIMD) and four per CU (four waves per SIMD); eight independent chains per wave.
+//   hipcc --offload-arch=gfx950 -O3 -o valu_rates tools/ubench/valu_rates.hip && ./valu_rates
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-
+#include <string>
 #define REP8(x) x x x x x x x x
-template <int OP>
-__global__ __launch_bounds__(256) void k(unsigned long long *out, int iters, float seed) {
-    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
-    double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7;
-    int i0 = (int)a0, i1 = (int)a1, i2 = (int)a2, i3 = (int)a3, i4 = (int)a4, i5 = (int)a5, i6 = (int)a6, i7 = (int)a7;
-    long long l0 = i0, l1 = i1, l2 = i2, l3 = i3;
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    for (int it = 0; it < iters; ++it) {
-        if (OP == 0) {  // v_fma_f64
-            asm volatile("v_fma_f64 %0, %0, %0, %0\n v_fma_f64 %1, %1, %1, %1\n v_fma_f64 %2, %2, %2, %2\n v_fma_f64 %3, %3, %3, %3\n"
-                         "v_fma_f64 %4, %4, %4, %4\n v_fma_f64 %5, %5, %5, %5\n v_fma_f64 %6, %6, %6, %6\n v_fma_f64 %7, %7, %7, %7\n"
-                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
-        } else if (OP == 1) {  // v_cvt_f64_i32
-            asm volatile("v_cvt_f64_i32 %0, %8\n v_cvt_f64_i32 %1, %9\n v_cvt_f64_i32 %2, %10\n v_cvt_f64_i32 %3, %11\n"
-                         "v_cvt_f64_i32 %4, %12\n v_cvt_f64_i32 %5, %13\n v_cvt_f64_i32 %6, %14\n v_cvt_f64_i32 %7, %15\n"
-                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7)
-                         : "v"(i0), "v"(i1), "v"(i2), "v"(i3), "v"(i4), "v"(i5), "v"(i6), "v"(i7));
-        } else if (OP == 2) {  // v_cvt_f64_f32
-            asm volatile("v_cvt_f64_f32 %0, %8\n v_cvt_f64_f32 %1, %9\n v_cvt_f64_f32 %2, %10\n v_cvt_f64_f32 %3, %11\n"
-                         "v_cvt_f64_f32 %4, %12\n v_cvt_f64_f32 %5, %13\n v_cvt_f64_f32 %6, %14\n v_cvt_f64_f32 %7, %15\n"
-                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7)
-                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
-        } else if (OP == 3) {  // v_add_f64
-            asm volatile("v_add_f64 %0, %0, %0\n v_add_f64 %1, %1, %1\n v_add_f64 %2, %2, %2\n v_add_f64 %3, %3, %3\n"
-                         "v_add_f64 %4, %4, %4\n v_add_f64 %5, %5, %5\n v_add_f64 %6, %6, %6\n v_add_f64 %7, %7, %7\n"
-                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
-        } else if (OP == 4) {  // v_cmp_lt_f64 (to vcc)
-            asm volatile("v_cmp_lt_f64 vcc, %0, %1\n v_cmp_lt_f64 vcc, %1, %2\n v_cmp_lt_f64 vcc, %2, %3\n v_cmp_lt_f64 vcc, %3, %4\n"
-                         "v_cmp_lt_f64 vcc, %4, %5\n v_cmp_lt_f64 vcc, %5, %6\n v_cmp_lt_f64 vcc, %6, %7\n v_cmp_lt_f64 vcc, %7, %0\n"
-                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7)::"vcc");
-        } else if (OP == 5) {  // v_fma_f32
-            asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n"
-                         "v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7\n"
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
-        } else if (OP == 6) {  // v_cvt_i32_f32
-            asm volatile("v_cvt_i32_f32 %0, %8\n v_cvt_i32_f32 %1, %9\n v_cvt_i32_f32 %2, %10\n v_cvt_i32_f32 %3, %11\n"
-                         "v_cvt_i32_f32 %4, %12\n v_cvt_i32_f32 %5, %13\n v_cvt_i32_f32 %6, %14\n v_cvt_i32_f32 %7, %15\n"
-                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7)
-                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
-        } else if (OP == 7) {  // v_rndne_f32
-            asm volatile("v_rndne_f32 %0, %0\n v_rndne_f32 %1, %1\n v_rndne_f32 %2, %2\n v_rndne_f32 %3, %3\n"
-                         "v_rndne_f32 %4, %4\n v_rndne_f32 %5, %5\n v_rndne_f32 %6, %6\n v_rndne_f32 %7, %7\n"
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
-        } else if (OP == 8) {  // v_mad_i64_i32
-            asm volatile("v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %1, vcc, %5, %6, %1\n v_mad_i64_i32 %2, vcc, %6, %7, %2\n v_mad_i64_i32 %3, vcc, %7, %4, %3\n"
-                         "v_mad_i64_i32 %0, vcc, %4, %6, %0\n v_mad_i64_i32 %1, vcc, %5, %7, %1\n v_mad_i64_i32 %2, vcc, %6, %4, %2\n v_mad_i64_i32 %3, vcc, %7, %5, %3\n"
-                         : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3) : "v"(i0), "v"(i1), "v"(i2), "v"(i3) : "vcc");
-        } else if (OP == 9) {  // v_med3_i32
-            asm volatile("v_med3_i32 %0, %0, %1, %2\n v_med3_i32 %1, %1, %2, %3\n v_med3_i32 %2, %2, %3, %4\n v_med3_i32 %3, %3, %4, %5\n"
-                         "v_med3_i32 %4, %4, %5, %6\n v_med3_i32 %5, %5, %6, %7\n v_med3_i32 %6, %6, %7, %0\n v_med3_i32 %7, %7, %0, %1\n"
-                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
-        } else if (OP == 10) {  // v_mov_b32 dpp row_shr:1
-            asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-                         "v_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-                         "v_mov_b32_dpp %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-                         "v_mov_b32_dpp %6, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
-        } else if (OP == 11) {  // v_mul_f64
-            asm volatile("v_mul_f64 %0, %0, %1\n v_mul_f64 %1, %1, %2\n v_mul_f64 %2, %2, %3\n v_mul_f64 %3, %3, %4\n"
-                         "v_mul_f64 %4, %4, %5\n v_mul_f64 %5, %5, %6\n v_mul_f64 %6, %6, %7\n v_mul_f64 %7, %7, %0\n"
-                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
-        } else if (OP == 12) {  // v_pk_mul_f32
-            asm volatile("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %2\n v_pk_mul_f32 %2, %2, %3\n v_pk_mul_f32 %3, %3, %4\n"
-                         "v_pk_mul_f32 %4, %4, %5\n v_pk_mul_f32 %5, %5, %6\n v_pk_mul_f32 %6, %6, %7\n v_pk_mul_f32 %7, %7, %0\n"
-                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
-        } else if (OP == 13) {  // v_cmp_lt_f32 + s_and_saveexec + s_or exec (an if without a skip branch)
-            asm volatile("v_cmp_lt_f32 vcc, %0, %1\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %0, %0, %1\n s_or_b64 exec, exec, s[20:21]\n"
-                         "v_cmp_lt_f32 vcc, %2, %3\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %2, %2, %3\n s_or_b64 exec, exec, s[20:21]\n"
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)::"vcc", "s20", "s21");
-        } else if (OP == 14) {  // v_rcp_f32
-            asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
-                         "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
-        } else if (OP == 15) {  // v_rndne_f64
-            asm volatile("v_rndne_f64 %0, %0\n v_rndne_f64 %1, %1\n v_rndne_f64 %2, %2\n v_rndne_f64 %3, %3\n"
-                         "v_rndne_f64 %4, %4\n v_rndne_f64 %5, %5\n v_rndne_f64 %6, %6\n v_rndne_f64 %7, %7\n"
-                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
-        } else if (OP == 16) {  // v_cvt_i32_f64
-            asm volatile("v_cvt_i32_f64 %0, %8\n v_cvt_i32_f64 %1, %9\n v_cvt_i32_f64 %2, %10\n v_cvt_i32_f64 %3, %11\n"
-                         "v_cvt_i32_f64 %4, %12\n v_cvt_i32_f64 %5, %13\n v_cvt_i32_f64 %6, %14\n v_cvt_i32_f64 %7, %15\n"
-                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7)
-                         : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(d4), "v"(d5), "v"(d6), "v"(d7));
-        } else if (OP == 17) {  // v_max_f64
-            asm volatile("v_max_f64 %0, %0, %1\n v_max_f64 %1, %1, %2\n v_max_f64 %2, %2, %3\n v_max_f64 %3, %3, %4\n"
-                         "v_max_f64 %4, %4, %5\n v_max_f64 %5, %5, %6\n v_max_f64 %6, %6, %7\n v_max_f64 %7, %7, %0\n"
-                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
-        } else if (OP == 18) {  // v_lshl_add_u64 (64-bit integer add)
-            asm volatile("v_lshl_add_u64 %0, %0, 0, %1\n v_lshl_add_u64 %1, %1, 0, %2\n v_lshl_add_u64 %2, %2, 0, %3\n v_lshl_add_u64 %3, %3, 0, %0\n"
-                         "v_lshl_add_u64 %0, %0, 0, %2\n v_lshl_add_u64 %1, %1, 0, %3\n v_lshl_add_u64 %2, %2, 0, %0\n v_lshl_add_u64 %3, %3, 0, %1\n"
-                         : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
-        } else if (OP == 19) {  // v_mul_lo_u32
-            asm volatile("v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %1, %1, %2\n v_mul_lo_u32 %2, %2, %3\n v_mul_lo_u32 %3, %3, %4\n"
-                         "v_mul_lo_u32 %4, %4, %5\n v_mul_lo_u32 %5, %5, %6\n v_mul_lo_u32 %6, %6, %7\n v_mul_lo_u32 %7, %7, %0\n"
-                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
-        }
+#define KERNEL(name, decl, body, sink)                                                          \
+    __global__ __launch_bounds__(256) void name(long long *out, int iters) {                    \
+        decl;                                                                                   \
+        for (int it = 0; it < iters; ++it) { REP8(body) }                                       \
+        sink;                                                                                   \
     }
-    const unsigned long long t1 = __builtin_readcyclecounter();
-    double s = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7 + l0 + l1 + l2 + l3;
-    if (s == 1.2345) out[1] = 1;
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = t1 - t0;
+typedef int v4i __attribute__((ext_vector_type(4)));
+KERNEL(k_fma_f32, float a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i; float b = out[0] * 1e-30f + 1.0f,
+       asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                    "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b));,
+       float s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345.f) out[1] = 1)
+KERNEL(k_fma_f64, double a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i; double b = out[0] * 1e-30 + 1.0,
+       asm volatile("v_fma_f64 %0, %0, %8, %8\n v_fma_f64 %1, %1, %8, %8\n v_fma_f64 %2, %2, %8, %8\n v_fma_f64 %3, %3, %8, %8\n"
+                    "v_fma_f64 %4, %4, %8, %8\n v_fma_f64 %5, %5, %8, %8\n v_fma_f64 %6, %6, %8, %8\n v_fma_f64 %7, %7, %8, %8\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b));,
+       double s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345.) out[1] = 1)
+KERNEL(k_add_f64, double a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i; double b = out[0] * 1e-30 + 1.0,
+       asm volatile("v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+                    "v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b));,
+       double s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345.) out[1] = 1)
+KERNEL(k_mad_i64_i32, long long a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i; int b = (int)out[0] + 3; int c = (int)out[0] + 5,
+       asm volatile("v_mad_i64_i32 %0, vcc, %8, %9, %0\n v_mad_i64_i32 %1, vcc, %8, %9, %1\n v_mad_i64_i32 %2, vcc, %8, %9, %2\n v_mad_i64_i32 %3, vcc, %8, %9, %3\n"
+                    "v_mad_i64_i32 %4, vcc, %8, %9, %4\n v_mad_i64_i32 %5, vcc, %8, %9, %5\n v_mad_i64_i32 %6, vcc, %8, %9, %6\n v_mad_i64_i32 %7, vcc, %8, %9, %7\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c) : "vcc");,
+       long long s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345) out[1] = 1)
+KERNEL(k_mad_u32_u24, unsigned a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i; unsigned b = (int)out[0] + 3; unsigned c = (int)out[0] + 5,
+       asm volatile("v_mad_u32_u24 %0, %8, %9, %0\n v_mad_u32_u24 %1, %8, %9, %1\n v_mad_u32_u24 %2, %8, %9, %2\n v_mad_u32_u24 %3, %8, %9, %3\n"
+                    "v_mad_u32_u24 %4, %8, %9, %4\n v_mad_u32_u24 %5, %8, %9, %5\n v_mad_u32_u24 %6, %8, %9, %6\n v_mad_u32_u24 %7, %8, %9, %7\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c));,
+       unsigned s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345) out[1] = 1)
+KERNEL(k_mul_lo_u32, unsigned a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i; unsigned b = (int)out[0] + 3,
+       asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n"
+                    "v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b));,
+       unsigned s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345) out[1] = 1)
+KERNEL(k_lshl_add_u64, unsigned long long a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i; unsigned long long b = out[0] + 3,
+       asm volatile("v_lshl_add_u64 %0, %0, 0, %8\n v_lshl_add_u64 %1, %1, 0, %8\n v_lshl_add_u64 %2, %2, 0, %8\n v_lshl_add_u64 %3, %3, 0, %8\n"
+                    "v_lshl_add_u64 %4, %4, 0, %8\n v_lshl_add_u64 %5, %5, 0, %8\n v_lshl_add_u64 %6, %6, 0, %8\n v_lshl_add_u64 %7, %7, 0, %8\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b));,
+       unsigned long long s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345) out[1] = 1)
+KERNEL(k_alignbit, unsigned a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i; unsigned b = (int)out[0] + 3,
+       asm volatile("v_alignbit_b32 %0, %0, %8, 9\n v_alignbit_b32 %1, %1, %8, 9\n v_alignbit_b32 %2, %2, %8, 9\n v_alignbit_b32 %3, %3, %8, 9\n"
+                    "v_alignbit_b32 %4, %4, %8, 9\n v_alignbit_b32 %5, %5, %8, 9\n v_alignbit_b32 %6, %6, %8, 9\n v_alignbit_b32 %7, %7, %8, 9\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b));,
+       unsigned s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345) out[1] = 1)
+KERNEL(k_mad_i32_i24, int a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i; int b = (int)out[0] + 3; int c = (int)out[0] + 5,
+       asm volatile("v_mad_i32_i24 %0, %8, %9, %0\n v_mad_i32_i24 %1, %8, %9, %1\n v_mad_i32_i24 %2, %8, %9, %2\n v_mad_i32_i24 %3, %8, %9, %3\n"
+                    "v_mad_i32_i24 %4, %8, %9, %4\n v_mad_i32_i24 %5, %8, %9, %5\n v_mad_i32_i24 %6, %8, %9, %6\n v_mad_i32_i24 %7, %8, %9, %7\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c));,
+       int s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345) out[1] = 1)
+KERNEL(k_dot2_i32_i16, int a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i; int b = (int)out[0] + 3; int c = (int)out[0] + 5,
+       asm volatile("v_dot2_i32_i16 %0, %8, %9, %0\n v_dot2_i32_i16 %1, %8, %9, %1\n v_dot2_i32_i16 %2, %8, %9, %2\n v_dot2_i32_i16 %3, %8, %9, %3\n"
+                    "v_dot2_i32_i16 %4, %8, %9, %4\n v_dot2_i32_i16 %5, %8, %9, %5\n v_dot2_i32_i16 %6, %8, %9, %6\n v_dot2_i32_i16 %7, %8, %9, %7\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c));,
+       int s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345) out[1] = 1)
+KERNEL(k_dot4_i32_i8, int a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i; int b = (int)out[0] + 3; int c = (int)out[0] + 5,
+       asm volatile("v_dot4_i32_i8 %0, %8, %9, %0\n v_dot4_i32_i8 %1, %8, %9, %1\n v_dot4_i32_i8 %2, %8, %9, %2\n v_dot4_i32_i8 %3, %8, %9, %3\n"
+                    "v_dot4_i32_i8 %4, %8, %9, %4\n v_dot4_i32_i8 %5, %8, %9, %5\n v_dot4_i32_i8 %6, %8, %9, %6\n v_dot4_i32_i8 %7, %8, %9, %7\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c));,
+       int s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345) out[1] = 1)
+KERNEL(k_perm_b32, unsigned a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i; unsigned b = (int)out[0] + 3; unsigned c = 0x05010400u + (unsigned)out[0],
+       asm volatile("v_perm_b32 %0, %0, %8, %9\n v_perm_b32 %1, %1, %8, %9\n v_perm_b32 %2, %2, %8, %9\n v_perm_b32 %3, %3, %8, %9\n"
+                    "v_perm_b32 %4, %4, %8, %9\n v_perm_b32 %5, %5, %8, %9\n v_perm_b32 %6, %6, %8, %9\n v_perm_b32 %7, %7, %8, %9\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c));,
+       unsigned s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345) out[1] = 1)
+KERNEL(k_cvt_f64_f32, double a[8]; float f[8]; for (int i = 0; i < 8; ++i) f[i] = threadIdx.x + i + (float)out[0],
+       asm volatile("v_cvt_f64_f32 %0, %8\n v_cvt_f64_f32 %1, %9\n v_cvt_f64_f32 %2, %10\n v_cvt_f64_f32 %3, %11\n"
+                    "v_cvt_f64_f32 %4, %12\n v_cvt_f64_f32 %5, %13\n v_cvt_f64_f32 %6, %14\n v_cvt_f64_f32 %7, %15\n"
+                    : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
+                    : "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "v"(f[6]), "v"(f[7]));,
+       double s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345.) out[1] = 1)
+KERNEL(k_mov_dpp, unsigned a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i,
+       asm volatile("s_nop 1\n v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                    "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));,
+       unsigned s = 0; for (int i = 0; i < 8; ++i) s += a[i]; if (s == 12345) out[1] = 1)
+// the int8 matrix instruction: four independent 16 x 16 accumulators, K = 64 per instruction (counts as 4 "instructions" per body: see main)
+__global__ __launch_bounds__(256) void k_mfma_i8(long long *out, int iters) {
+    v4i acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    v4i a = {(int)threadIdx.x, 2, 3, (int)out[0]}, b = {5, (int)threadIdx.x, 7, 8};
+    for (int it = 0; it < iters; ++it) {
+        REP8(acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[0], 0, 0, 0); acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[1], 0, 0, 0);
+             acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[2], 0, 0, 0); acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[3], 0, 0, 0);)
+    }
+    int s = 0;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345) out[1] = 1;
 }
-
-template <int OP>
-void run(const char *name, int per_trip, unsigned long long *d_out) {
-    const int iters = 20000;
-    // 256 CUs x 4 blocks of 256 threads = 4 waves per SIMD everywhere
+struct Case { const char *name; void (*fn)(long long *, int); int per_body; };
+int main() {
+    long long *d;
+    hipMalloc(&d, 64);
+    hipMemset(d, 0, 64);
+    hipDeviceProp_t pr;
+    hipGetDeviceProperties(&pr, 0);
+    const int cus = pr.multiProcessorCount;
+    const double ghz = pr.clockRate * 1e-6;
+    std::vector<Case> cases = {{"v_fma_f32", k_fma_f32, 64}, {"v_fma_f64", k_fma_f64, 64}, {"v_add_f64", k_add_f64, 64}, {"v_mad_i64_i32", k_mad_i64_i32, 64},
+                               {"v_mad_u32_u24", k_mad_u32_u24, 64}, {"v_mad_i32_i24", k_mad_i32_i24, 64}, {"v_mul_lo_u32", k_mul_lo_u32, 64},
+                               {"v_lshl_add_u64", k_lshl_add_u64, 64}, {"v_alignbit_b32", k_alignbit, 64}, {"v_dot2_i32_i16", k_dot2_i32_i16, 64},
+                               {"v_dot4_i32_i8", k_dot4_i32_i8, 64}, {"v_perm_b32", k_perm_b32, 64}, {"v_cvt_f64_f32", k_cvt_f64_f32, 64},
+                               {"v_mov_b32_dpp", k_mov_dpp, 64}, {"v_mfma_i32_16x16x64_i8", k_mfma_i8, 32}};
+    const int iters = 4000;
+    printf("%d CUs, %.2f GHz nominal; cycles per wave-instruction on one SIMD (nominal clock; compare with v_fma_f32)\n", cus, ghz);
+    printf("%-26s %14s %14s\n", "instruction", "1 wave/SIMD", "4 waves/SIMD");
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<OP>, dim3(1024), dim3(256), 0, 0, d_out, 100, 1.5f);
-    hipEventRecord(e0);
-    hipLaunchKernelGGL(k<OP>, dim3(1024), dim3(256), 0, 0, d_out, iters, 1.5f);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    // wave-instructions per SIMD = 4 waves * iters * per_trip ; cycles at 2.4 GHz nominal
-    const double inst_per_simd = 4.0 * iters * per_trip;
-    printf("%-28s %.3f ms  -> %.2f ns per wave-instruction per SIMD (= %.1f cycles at 2.4 GHz)\n", name, ms, ms * 1e6 / inst_per_simd,
-           ms * 1e6 / inst_per_simd * 2.4);
-}
-
-int main() {
-    unsigned long long *d_out;
-    hipMalloc(&d_out, 64);
-    run<5>("v_fma_f32", 8, d_out);
-    run<0>("v_fma_f64", 8, d_out);
-    run<11>("v_mul_f64", 8, d_out);
-    run<3>("v_add_f64", 8, d_out);
-    run<4>("v_cmp_lt_f64", 8, d_out);
-    run<1>("v_cvt_f64_i32", 8, d_out);
-    run<2>("v_cvt_f64_f32", 8, d_out);
-    run<6>("v_cvt_i32_f32", 8, d_out);
-    run<7>("v_rndne_f32", 8, d_out);
-    run<9>("v_med3_i32", 8, d_out);
-    run<8>("v_mad_i64_i32", 8, d_out);
-    run<10>("v_mov_b32 dpp", 8, d_out);
-    run<12>("v_pk_mul_f32", 8, d_out);
-    run<14>("v_rcp_f32", 8, d_out);
-    run<15>("v_rndne_f64", 8, d_out);
-    run<16>("v_cvt_i32_f64", 8, d_out);
-    run<17>("v_max_f64", 8, d_out);
-    run<18>("v_lshl_add_u64", 8, d_out);
-    run<19>("v_mul_lo_u32", 8, d_out);
-    run<13>("cmp+saveexec+add+or (x2)", 2, d_out);
+    for (auto &c : cases) {
+        double cyc[2];
+        for (int w = 0; w < 2; ++w) {
+            const int wgs = cus * (w ? 4 : 1);
+            hipLaunchKernelGGL(c.fn, dim3(wgs), dim3(256), 0, 0, d, 10);
+            hipDeviceSynchronize();
+            float best = 1e30f;
+            for (int r = 0; r < 3; ++r) {
+                hipEventRecord(e0, 0);
+                hipLaunchKernelGGL(c.fn, dim3(wgs), dim3(256), 0, 0, d, iters);
+                hipEventRecord(e1, 0);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                best = ms < best ? ms : best;
+            }
+            const double instr_per_simd = (double)iters * c.per_body * (w ? 4 : 1);
+            cyc[w] = best * 1e-3 * ghz * 1e9 / instr_per_simd;
+        }
+        printf("%-26s %14.2f %14.2f\n", c.name, cyc[0], cyc[1]);
+    }
     return 0;
 }
