@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define PWPP_VERSION_MAJOR 0
-#define PWPP_VERSION_MINOR 2 /* round 6: pwpp_pipe_submit takes a mode; pwpp_pipe_set_num_streams, pwpp_get_arena_stats; option exact_moments */
+#define PWPP_VERSION_MINOR 2 /* round 6: pwpp_pipe_submit takes a mode; pwpp_pipe_set_num_streams, pwpp_get_arena_stats; options exact_moments, split_k5 */
 
 typedef enum pwpp_status {
     PWPP_OK = 0,
@@ -212,7 +212,9 @@ PWPP_API int pwpp_get_patch_records(pwpp_handle *h, int frame, pwpp_patch_record
 /* getHeight(), reference patchworkpp.h:154 (stream 0) */
 PWPP_API double pwpp_get_height(pwpp_handle *h);
 /* getTimeTaken(), reference patchworkpp.h:155: microseconds of the last estimate call
- * (GPU time between HIP events on the handle's stream, batch calls: whole batch) */
+ * (GPU time between HIP events on the handle's stream, batch calls: whole batch: first kernel -> index lists written.  With up to 64
+ * stateful streams the update of the streams' adaptive thresholds -- K5's second launch, option "split_k5" -- runs on the handle's second
+ * stream and ends ~8 us after the lists; every call that reads results or state, and the next estimate call, waits for it) */
 PWPP_API double pwpp_get_time_us(pwpp_handle *h);
 
 /* ---- adaptive state --------------------------------------------------------------------- */
@@ -357,6 +359,10 @@ PWPP_API int pwpp_pipe_destroy(pwpp_pipe *pipe);
  *   "exact_moments"       "1" (default): the plane-fit sums of 4+ points exact on the reference's floats (2^-30 m grid, contract v4);
  *                         "0": rounds 3-5's 2^-21 m grid -- 7 % faster, off the reference by a few indices on 0.2 % of varied frames
  *                         (see pwpp_get_ground_indices above).  May be changed between calls.
+ *   "split_k5"            "1" (default): calls with up to 64 stateful streams run K5 (GLE / TGR / thresholds) in two launches -- the index lists
+ *                         wait for the first only; the statistics over the streams' A-GLE histories (two chains of ~1000 dependent f64 adds
+ *                         in the reference's order) run on the handle's second stream, under K6 and the host's turn-around: one stream in steady
+ *                         state 108 -> 100 us per frame.  "0": one kernel
  *   "fit_plan"            which fit kernel handles which patch sizes, e.g. "W16:1023,W64.2:65535"; "" = automatic
  *   "fit_concurrent"      "1": the classes of a plan side by side on two streams
  *   "one_pass"            "0": always the two-pass binning

@@ -111,6 +111,9 @@ struct pwpp_handle {
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;  // second stream for the latency plan (few frames)
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+    bool k5_tail_unjoined = false;  // the last call left K5's second part on aux_stream (aux_join recorded behind it): the main stream has not waited for it yet
+    bool k5_tail_unsynced = false;  // ... and neither has the host
+    int split_k5 = 1;               // option "split_k5": a few stateful streams run K5 in two launches (k_gle_tgr PART 1 / 2)
     bool overlap = true;   // pwpp_set_overlap: big batches as a pipeline of frame ranges over the two streams (default on)
     int overlap_ranges = 2;  // (more ranges were slower at every setting tried: each range's fit kernels end with the tail of their
                              // longest waves -- docs/history/design_through_round4.md section 9)
@@ -667,6 +670,10 @@ PwppBatch frame_range(const pwpp_handle *h, const PwppBatch &bt, int f0, int nf)
 int launch_prepared(pwpp_handle *h, bool one_pass) {
     const int NP = PWPP_NUM_PARTS(h->dp.num_bins);
     const int frames = h->frames;
+    if (h->k5_tail_unjoined) {  // the threshold update of the streams' last frames (K5's second part) comes before anything of this call
+        HIPCHK(hipStreamWaitEvent(h->stream, h->aux_join, 0));
+        h->k5_tail_unjoined = false;
+    }
     // where a frame's bins live in the bin-ordered buffers
     int64_t base = 0;
     for (int f = 0; f < frames; ++f) {
@@ -700,6 +707,11 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     bt.next_slabs = slabs;
     bt.no_clear = pre_cleared ? 1 : 0;
 
+    // A few stateful streams (the latency plan): the index lists wait for the first part of K5 only; the statistics over the streams'
+    // histories -- what only their NEXT frames need -- run on aux_stream under K6 and the host's turn-around.
+    const bool split_k5 = h->split_k5 != 0 && h->mode == PWPP_MODE_STREAMS && frames <= 64 && !h->profiling && bt.debug == 0 &&
+                          h->output_order != PWPP_ORDER_REFERENCE && h->dp.min_pts != 0;
+    bt.k5_split = split_k5 ? 1 : 0;
     bt.cap_off = one_pass ? h->d_cap_off.p : nullptr;
     if (one_pass) {
         bt.arena_base = h->arena_base;
@@ -834,6 +846,7 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
         return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     }
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
+    if (bt.k5_split && !(h->overlap && !h->profiling && !ordered && frames >= 128 && bt.debug == 0)) h->k5_tail_unjoined = h->k5_tail_unsynced = true;
     h->next_clean = true;  // every frame's K5 is enqueued: the other copy will be zero for a call of this shape
     h->next_clean_frames = frames;
     h->next_clean_slabs = slabs;
@@ -852,6 +865,10 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
 int finish_pending(pwpp_handle *h) {
     if (!h->pending) return PWPP_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->k5_tail_unsynced) {  // (the streams' state and results[].hist_state are complete once K5's second part has run)
+        HIPCHK(hipStreamSynchronize(h->aux_stream));
+        h->k5_tail_unsynced = false;
+    }
     h->pending = false;
     float ms = 0.0f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
@@ -1909,6 +1926,8 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
         std::vector<float2> origin;
         h->dp.fxp_wide = v;
         h->dp.fxp_zr = (float)fxp_geometry(h->dp, origin, h->dp.fxp_shift, v != 0);
+    } else if (k == "split_k5") {
+        h->split_k5 = std::atoi(value) != 0;
     } else if (k == "redo_whole_batch") {
         h->redo_whole_batch = std::atoi(value) != 0;
     } else if (k == "one_pass_min_frames") {

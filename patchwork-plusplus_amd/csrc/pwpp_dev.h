@@ -198,6 +198,7 @@ struct PwppBatch {
     float *normals;              // [frames][B][3]
     PwppFrameResult *results;    // [frames]
     PwppFrameResult *results_host;  // [frames] pinned host mirror, written by K6 (no D2H copy command behind the pipeline)
+    int k5_split;                // K5 in two launches (k_gle_tgr PART 1 / 2): the second on the handle's other stream, joined by the host before the next call
     unsigned long long *dbg;     // [64] timing probes, only written when debug & 4
     // host side only (the kernels never read these)
     const char *fit_plan;        // option "fit_plan": overrides the plan pwpp_launch_fit would choose; null or empty = automatic

@@ -1333,7 +1333,12 @@ __device__ __forceinline__ void block_excl_scan(unsigned v[K], unsigned (*s_wave
 // stage instead of three; otherwise the tile lives in the retired prefix arrays (32 KB).
 // PER: consecutive bins per thread the kernel is compiled for (2 covers the default 504-bin model: every per-bin loop, and the
 // registers of the patch records, four times shorter than for the largest model)
-template <bool LAT, int PER>
+// PART (a single stream's chain, round 6): the kernel in two launches.  1 = everything the index lists wait for (decisions, history pushes,
+// TGR, list offsets, the plane members) -- K6 follows it on the same stream; 2 = what only the stream's NEXT frame needs (the statistics of
+// the eight histories, thresholds, sensor height, erase): launched on the handle's second stream, it runs under K6 and the host's turn-around
+// instead of holding the lists back by its two chains of ~1000 dependent f64 adds (11 of 27 us).  Part 1 hands over through the stream's
+// state (history lengths after the pushes) and results[f].hist_state (a slab was full).  0 = the whole kernel.
+template <bool LAT, int PER, int PART = 0>
 __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     // timing probes (debug_flags & 8): 100 MHz ticks along the chain of frame 0, slots 32.. of the probe array (tools/k5_chain.py)
     int probe_i = 32;
@@ -1341,7 +1346,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         if ((Bt.debug & 8) && blockIdx.x == 0 && threadIdx.x == 0 && probe_i < 60) Bt.dbg[probe_i++] = wall_clock64();
     };
     probe();
-    clear_next_counters(Bt, blockIdx.x, kBlock);
+    if constexpr (PART != 2) clear_next_counters(Bt, blockIdx.x, kBlock);
     probe();
     __shared__ uint8_t s_dec[PWPP_MAX_BINS];
     __shared__ __attribute__((aligned(16))) unsigned s_e[4][PWPP_MAX_BINS + 1];   // exclusive prefixes: gmain, gtail, nmain, ntail;
@@ -1372,7 +1377,13 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     double *hist_out = Bt.st_hist + (size_t)fd.state_out * 8 * P.hist_cap;
     const int roi = P.num_rings_of_interest;
 
-    if (threadIdx.x == 0) {
+    if (PART == 2 && threadIdx.x == 0) {  // the state as part 1 left it
+        s_st = Bt.st_scalar[fd.state_out];
+        s_dropped = Bt.results[f].hist_state & 1;
+        s_last_patch = -1;
+        for (int k = 0; k < PWPP_MAX_ROI; ++k) s_len0[0][k] = s_len0[1][k] = 1;  // (not a frame that starts from empty histories: they are read back)
+    }
+    if (PART != 2 && threadIdx.x == 0) {
         s_dropped = 0;
         s_last_patch = -1;
         PwppStateScalar st;
@@ -1411,6 +1422,13 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     const int b0 = threadIdx.x * per;
     unsigned nn[PER];
     PwppPatchRec rr[PER];
+    uint8_t dec[PER];
+    int ci_of[PER];
+    if constexpr (PART == 2) {
+        if (dst_a[0] == kAwaitsFixup) return;  // (part 1 left the frame to k_fit_fixup; workgroup-uniform)
+        __syncthreads();
+    }
+    if constexpr (PART != 2) {
     int awaits = 0;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -1437,8 +1455,6 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     // ---- pass 1: per-bin GLE (ref :217-282) ------------------------------------------------
     unsigned a_patch = 0, a_push = 0;
     int my_last = -1;  // this thread's last fitted bin -> s_last_patch: one LDS atomic per WAVE (256 on one address serialise: 1.5 us)
-    uint8_t dec[PER];
-    int ci_of[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int bin = b0 + j;
@@ -1562,6 +1578,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     }
     __syncthreads();
     probe();  // 4: history pushes, ring statistics
+    }  // (PART != 2)
 
     // The histories are complete now (this frame's pushes included): start fetching their first tile
     // for the threshold statistics at the end of the kernel, the loads fly while TGR and the list
@@ -1582,7 +1599,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     // A frame that starts from EMPTY histories (fresh state: a single frame, the first frame of a stream) has just written all
     // their entries itself, and they are still in LDS in push order (s_pelev, s_pseq): the threshold statistics take them from
     // there -- no read-back of the histories from global memory, no staging tiles (5 of 22 us of a single frame).
-    bool fresh_hist = LAT && s_dropped == 0;
+    bool fresh_hist = LAT && PART != 2 && s_dropped == 0;
 #pragma unroll
     for (int k = 0; k < PWPP_MAX_ROI; ++k) fresh_hist = fresh_hist && s_len0[0][k] == 0 && s_len0[1][k] == 0;
     // (two entries per thread and load: a 256-thread workgroup issuing forty 8-byte loads per thread took 3.2 us to ISSUE them;
@@ -1600,8 +1617,9 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
                 v[w][q] = *reinterpret_cast<const double2 *>(hist_out + (size_t)w * P.hist_cap + (i < len_w[w] && i + 1 < P.hist_cap ? i : 0));
             }
     };
-    if (ntiles > 0 && !fresh_hist) fetch(0);
+    if (PART != 1 && ntiles > 0 && !fresh_hist) fetch(0);
 
+    if constexpr (PART != 2) {
     // ---- pass 2: TGR (ref :416-461) and what each bin appends to which list -----------------
     unsigned q4[4] = {0, 0, 0, 0};  // gmain, gtail, nmain, ntail of this thread's bins
     unsigned gm[PER], gt[PER], nm[PER], nt[PER];
@@ -1708,6 +1726,35 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
     __threadfence_block();
     __syncthreads();
     probe();  // 6: list offsets written
+    }  // (PART != 2)
+    // the plane members after this frame: those of its last fitted bin, else what the stream's last frame left
+    auto write_plane_state = [&]() {
+        PwppPlaneState ps;
+        if (s_last_patch >= 0) {
+            const PwppPatchRec lr = recs[s_last_patch];
+            for (int i = 0; i < 3; ++i) {
+                ps.mean[i] = lr.mean[i];
+                ps.normal[i] = lr.normal[i];
+                ps.sv[i] = lr.sv[i];
+            }
+            ps.d = lr.d;
+        } else if (fd.state_in >= 0) {
+            ps = Bt.st_plane[fd.state_in];
+        } else {
+            for (int i = 0; i < 3; ++i) ps.mean[i] = ps.normal[i] = ps.sv[i] = 0.0f;
+            ps.d = 0.0;
+        }
+        ps.pad_ = 0.0f;
+        Bt.st_plane[fd.state_out] = ps;
+    };
+    if constexpr (PART == 1) {  // hand-over to part 2: the history lengths after this frame's pushes (thresholds and sensor height still the old ones)
+        if (threadIdx.x == 0) {
+            Bt.st_scalar[fd.state_out] = s_st;
+            write_plane_state();
+            Bt.results[f].hist_state = s_dropped;
+        }
+        return;
+    }
 
     // ---- adaptive thresholds for the next frame of this stream (ref :338-375) ---------------
     // lanes 0..3: elevation history of ring i, lanes 4..7: flatness history; sequential sums
@@ -1872,31 +1919,14 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
             }
         }
         Bt.st_scalar[fd.state_out] = s_st;
-        {   // the plane members after this frame: those of its last fitted bin, else what the stream's last frame left
-            PwppPlaneState ps;
-            if (s_last_patch >= 0) {
-                const PwppPatchRec lr = recs[s_last_patch];
-                for (int i = 0; i < 3; ++i) {
-                    ps.mean[i] = lr.mean[i];
-                    ps.normal[i] = lr.normal[i];
-                    ps.sv[i] = lr.sv[i];
-                }
-                ps.d = lr.d;
-            } else if (fd.state_in >= 0) {
-                ps = Bt.st_plane[fd.state_in];
-            } else {
-                for (int i = 0; i < 3; ++i) ps.mean[i] = ps.normal[i] = ps.sv[i] = 0.0f;
-                ps.d = 0.0;
-            }
-            ps.pad_ = 0.0f;
-            Bt.st_plane[fd.state_out] = ps;
-        }
+        if constexpr (PART == 0) write_plane_state();
         int mx = 0;
         for (int k = 0; k < 4; ++k) {
             mx = s_st.elev_len[k] > mx ? s_st.elev_len[k] : mx;
             mx = s_st.flat_len[k] > mx ? s_st.flat_len[k] : mx;
         }
         Bt.results[f].hist_state = (mx << 1) | s_dropped;  // the host grows the slabs before they run out (pwpp_capi.cpp)
+        if constexpr (PART == 2) Bt.results_host[f].hist_state = (mx << 1) | s_dropped;  // (K6 copies the other fields: it may run before this)
     }
     __syncthreads();
     probe();  // 8: state written
@@ -1961,7 +1991,21 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(PwppBatch Bt, unsigned l
     }
     // the frame's counters are final since K5: hand them to the host through its pinned mirror (eight posted
     // PCIe writes) instead of a copy command behind the pipeline (a dispatch of its own, ~9 us of a single frame)
-    if (!Bt.emit_long_pass && seg == 0 && blockIdx.z == 0 && threadIdx.x == 0) Bt.results_host[f] = Bt.results[f];
+    if (!Bt.emit_long_pass && seg == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+        const PwppFrameResult r = Bt.results[f];
+        if (Bt.k5_split) {  // every field but hist_state: K5's second part writes that one from its own stream, before or after this
+            PwppFrameResult *d = Bt.results_host + f;
+            d->n_ground = r.n_ground;
+            d->n_nonground = r.n_nonground;
+            d->n_patches = r.n_patches;
+            d->n_rnr = r.n_rnr;
+            d->n_oor = r.n_oor;
+            d->n_dropped = r.n_dropped;
+            d->overflow = r.overflow;
+        } else {
+            Bt.results_host[f] = r;
+        }
+    }
     const PwppDevParams &P = Bt.P;
     const int B = P.num_bins, NB = B + 2;
     // A pseudo-bin is one part -- its own count / offset stand in -- and has no patch record: that of bin 0 is read and ignored.
@@ -2634,7 +2678,16 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
         if (frc) return frc;
         if (B.P.min_pts == 0)
             hipLaunchKernelGGL(k_gle_tgr_seq, dim3(F), dim3(64), 0, stream, B);  // empty bins inherit planes: serial
-        else if (F <= 64) {  // every workgroup alone on a CU: the big-LDS variant
+        else if (F <= 64 && B.k5_split && !ev && aux && aux_fork && aux_join && !(stages & 8)) {
+            // a stream's chain: the lists wait for the first part only, the second runs on the other stream (joined by the caller: aux_join)
+            if (B.P.num_bins <= 2 * kBlock) hipLaunchKernelGGL((k_gle_tgr<true, 2, 1>), dim3(F), dim3(kBlock), 0, stream, B);
+            else hipLaunchKernelGGL((k_gle_tgr<true, kGlePer, 1>), dim3(F), dim3(kBlock), 0, stream, B);
+            (void)hipEventRecord(aux_fork, stream);
+            (void)hipStreamWaitEvent(aux, aux_fork, 0);
+            if (B.P.num_bins <= 2 * kBlock) hipLaunchKernelGGL((k_gle_tgr<true, 2, 2>), dim3(F), dim3(kBlock), 0, aux, B);
+            else hipLaunchKernelGGL((k_gle_tgr<true, kGlePer, 2>), dim3(F), dim3(kBlock), 0, aux, B);
+            (void)hipEventRecord(aux_join, aux);
+        } else if (F <= 64) {  // every workgroup alone on a CU: the big-LDS variant
             if (B.P.num_bins <= 2 * kBlock) hipLaunchKernelGGL((k_gle_tgr<true, 2>), dim3(F), dim3(kBlock), 0, stream, B);
             else hipLaunchKernelGGL((k_gle_tgr<true, kGlePer>), dim3(F), dim3(kBlock), 0, stream, B);
         } else {

@@ -945,6 +945,46 @@ def test_history_statistics_shortcut_only_where_it_is_exact(kitti):
     assert seen[0] == seen[1]
 
 
+def test_k5_in_two_launches_leaves_the_same_state(kitti, oracle):
+    """Up to 64 stateful streams run K5 in two launches (option split_k5, default 1): the index lists wait for the first part only, the
+    statistics over the A-GLE histories run on the handle's second stream and are joined before the next call and before the host reads
+    anything.  Three streams, ten steps from restored histories long enough to be trimmed every frame: thresholds, sensor height, histories
+    and lists after every step must equal those of a handle whose K5 is one kernel, and the last step the oracle's."""
+    rng = np.random.default_rng(5)
+    hist = [[(rng.normal(-1.73, 0.05, 990 + 3 * r)).astype(np.float32).astype(np.float64) if w == 0 else
+             np.abs(rng.normal(2e-3, 1e-3, 985 + 5 * r)).astype(np.float32).astype(np.float64) for r in range(4)] for w in range(2)]
+    S, seen = 3, []
+    for split in (1, 0):
+        h = pwpp_hip.Handle()
+        h.set_option("split_k5", split)
+        h.set_num_streams(S)
+        h.estimate_ground_batch([kitti[s] for s in range(S)], mode=pwpp_hip.MODE_STREAMS)
+        for s in range(S):
+            for w in range(2):
+                for r in range(4):
+                    h.set_history(s, w, r, hist[w][r][s:])
+        trace = []
+        for t in range(1, 11):
+            h.estimate_ground_batch([kitti[(s + t) % 6] for s in range(S)], mode=pwpp_hip.MODE_STREAMS)
+            for s in range(S):
+                st = h.state(s)
+                trace.append((st.sensor_height, list(st.elevation_thr), list(st.flatness_thr),
+                              [h.history(s, w, r).tobytes() for w in range(2) for r in range(4)],
+                              np.sort(h.ground_indices(s)).tobytes(), np.sort(h.nonground_indices(s)).tobytes()))  # (the lists' order is the scatter's)
+        seen.append(trace)
+        h.close()
+    assert seen[0] == seen[1]
+    # ... and a stream that starts from nothing follows the oracle through the split kernel (its first frames take their statistics from
+    # the histories read back, not from the LDS copy of a frame that starts from empty histories)
+    h = pwpp_hip.Handle()
+    h.set_num_streams(1)
+    est = ol.Estimator(oracle, arith=ol.ARITH_FXP)
+    for t in range(4):
+        h.estimate_ground_batch([kitti[t]], mode=pwpp_hip.MODE_STREAMS)
+        ref = est.run(kitti[t])
+        assert_frame_equal(h, 0, ref, kitti[t].shape[0], state_index=0)
+
+
 def test_history_statistics_of_a_big_stream_batch_equal_the_single_stream_kernel(kitti):
     """k_gle_tgr has two variants: up to 64 frames a workgroup stages a whole 1000-entry history in one LDS tile (the variant the
     long-sequence tests hold against the oracle), larger batches walk it in tiles of 496 entries, fetched two entries per load
