@@ -362,7 +362,8 @@ PWPP_API int pwpp_pipe_destroy(pwpp_pipe *pipe);
  *   "split_k5"            "1" (default): calls with up to 64 stateful streams run K5 (GLE / TGR / thresholds) in two launches -- the index lists
  *                         wait for the first only; the statistics over the streams' A-GLE histories (two chains of ~1000 dependent f64 adds
  *                         in the reference's order) run on the handle's second stream, under K6 and the host's turn-around: one stream in steady
- *                         state 108 -> 100 us per frame.  "0": one kernel
+ *                         state 108 -> 100 us per frame.  "2": the second launch starts only when the lists are written (not beside K6): the
+ *                         lists another ~4 us earlier, the state ~15 us later (pwpp_synchronize waits for both).  "0": one kernel
  *   "fit_plan"            which fit kernel handles which patch sizes, e.g. "W16:1023,W64.2:65535"; "" = automatic
  *   "fit_concurrent"      "1": the classes of a plan side by side on two streams
  *   "one_pass"            "0": always the two-pass binning

@@ -26,6 +26,7 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
                                     hipEvent_t aux_fork, hipEvent_t aux_join, unsigned long long *order_a, unsigned long long *order_b,
                                     int stages);
 extern "C" int pwpp_launch_clear(const PwppBatch *batch, hipStream_t stream);
+extern "C" int pwpp_launch_k5_tail(const PwppBatch *batch, hipStream_t aux, hipEvent_t aux_fork, hipEvent_t aux_join);
 extern "C" int pwpp_launch_histogram(const PwppBatch *batch, hipStream_t stream);
 extern "C" int pwpp_launch_gather_xyz(const PwppFrameDesc *fd, const int *idx, int count, float *out, hipStream_t stream);
 
@@ -711,7 +712,7 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     // histories -- what only their NEXT frames need -- run on aux_stream under K6 and the host's turn-around.
     const bool split_k5 = h->split_k5 != 0 && h->mode == PWPP_MODE_STREAMS && frames <= 64 && !h->profiling && bt.debug == 0 &&
                           h->output_order != PWPP_ORDER_REFERENCE && h->dp.min_pts != 0;
-    bt.k5_split = split_k5 ? 1 : 0;
+    bt.k5_split = split_k5 ? h->split_k5 : 0;
     bt.cap_off = one_pass ? h->d_cap_off.p : nullptr;
     if (one_pass) {
         bt.arena_base = h->arena_base;
@@ -846,7 +847,17 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
         return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     }
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
-    if (bt.k5_split && !(h->overlap && !h->profiling && !ordered && frames >= 128 && bt.debug == 0)) h->k5_tail_unjoined = h->k5_tail_unsynced = true;
+    if (bt.k5_split && !(h->overlap && !h->profiling && !ordered && frames >= 128 && bt.debug == 0)) {
+        if (bt.k5_split == 2) {  // the second part behind the lists
+            HIPCHK(hipEventRecord(h->aux_fork, h->stream));
+            const int trc = pwpp_launch_k5_tail(&bt, h->aux_stream, h->aux_fork, h->aux_join);
+            if (trc != 0) {
+                sync_all_streams(h);
+                return fail(PWPP_E_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)trc));
+            }
+        }
+        h->k5_tail_unjoined = h->k5_tail_unsynced = true;
+    }
     h->next_clean = true;  // every frame's K5 is enqueued: the other copy will be zero for a call of this shape
     h->next_clean_frames = frames;
     h->next_clean_slabs = slabs;
@@ -1927,7 +1938,9 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
         h->dp.fxp_wide = v;
         h->dp.fxp_zr = (float)fxp_geometry(h->dp, origin, h->dp.fxp_shift, v != 0);
     } else if (k == "split_k5") {
-        h->split_k5 = std::atoi(value) != 0;
+        const int v = std::atoi(value);
+        if (v < 0 || v > 2) return fail(PWPP_E_ARG, "split_k5=%s: 0, 1 or 2 expected", value);
+        h->split_k5 = v;
     } else if (k == "redo_whole_batch") {
         h->redo_whole_batch = std::atoi(value) != 0;
     } else if (k == "one_pass_min_frames") {

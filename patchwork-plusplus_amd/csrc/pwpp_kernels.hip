@@ -2610,6 +2610,16 @@ extern "C" int pwpp_launch_clear(const PwppBatch *batch, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// K5's second part on its own (k5_split = 2): the caller has recorded aux_fork on the main stream where the part may start
+extern "C" int pwpp_launch_k5_tail(const PwppBatch *batch, hipStream_t aux, hipEvent_t aux_fork, hipEvent_t aux_join) {
+    const PwppBatch &B = *batch;
+    (void)hipStreamWaitEvent(aux, aux_fork, 0);
+    if (B.P.num_bins <= 2 * kBlock) hipLaunchKernelGGL((k_gle_tgr<true, 2, 2>), dim3(B.num_frames), dim3(kBlock), 0, aux, B);
+    else hipLaunchKernelGGL((k_gle_tgr<true, kGlePer, 2>), dim3(B.num_frames), dim3(kBlock), 0, aux, B);
+    (void)hipEventRecord(aux_join, aux);
+    return (int)hipGetLastError();
+}
+
 // K0 + K1 + K2 only: the histogram of a few sample frames (sizes the one-pass segments before the first batch)
 // dynamic LDS of the binning kernels: one (K1), two (K3) or two-and-a-bit (K1') words per part of this model
 static size_t binning_lds_bytes(const PwppBatch &B, int words_per_part) {
@@ -2682,11 +2692,13 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
             // a stream's chain: the lists wait for the first part only, the second runs on the other stream (joined by the caller: aux_join)
             if (B.P.num_bins <= 2 * kBlock) hipLaunchKernelGGL((k_gle_tgr<true, 2, 1>), dim3(F), dim3(kBlock), 0, stream, B);
             else hipLaunchKernelGGL((k_gle_tgr<true, kGlePer, 1>), dim3(F), dim3(kBlock), 0, stream, B);
-            (void)hipEventRecord(aux_fork, stream);
-            (void)hipStreamWaitEvent(aux, aux_fork, 0);
-            if (B.P.num_bins <= 2 * kBlock) hipLaunchKernelGGL((k_gle_tgr<true, 2, 2>), dim3(F), dim3(kBlock), 0, aux, B);
-            else hipLaunchKernelGGL((k_gle_tgr<true, kGlePer, 2>), dim3(F), dim3(kBlock), 0, aux, B);
-            (void)hipEventRecord(aux_join, aux);
+            if (B.k5_split == 1) {  // (2: the caller launches the second part behind the lists, pwpp_launch_k5_tail)
+                (void)hipEventRecord(aux_fork, stream);
+                (void)hipStreamWaitEvent(aux, aux_fork, 0);
+                if (B.P.num_bins <= 2 * kBlock) hipLaunchKernelGGL((k_gle_tgr<true, 2, 2>), dim3(F), dim3(kBlock), 0, aux, B);
+                else hipLaunchKernelGGL((k_gle_tgr<true, kGlePer, 2>), dim3(F), dim3(kBlock), 0, aux, B);
+                (void)hipEventRecord(aux_join, aux);
+            }
         } else if (F <= 64) {  // every workgroup alone on a CU: the big-LDS variant
             if (B.P.num_bins <= 2 * kBlock) hipLaunchKernelGGL((k_gle_tgr<true, 2>), dim3(F), dim3(kBlock), 0, stream, B);
             else hipLaunchKernelGGL((k_gle_tgr<true, kGlePer>), dim3(F), dim3(kBlock), 0, stream, B);
