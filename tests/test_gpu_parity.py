@@ -954,7 +954,7 @@ def test_k5_in_two_launches_leaves_the_same_state(kitti, oracle):
     hist = [[(rng.normal(-1.73, 0.05, 990 + 3 * r)).astype(np.float32).astype(np.float64) if w == 0 else
              np.abs(rng.normal(2e-3, 1e-3, 985 + 5 * r)).astype(np.float32).astype(np.float64) for r in range(4)] for w in range(2)]
     S, seen = 3, []
-    for split in (1, 0):
+    for split in (1, 0, 2):  # (2: the second launch behind the lists instead of beside K6)
         h = pwpp_hip.Handle()
         h.set_option("split_k5", split)
         h.set_num_streams(S)
@@ -973,7 +973,7 @@ def test_k5_in_two_launches_leaves_the_same_state(kitti, oracle):
                               np.sort(h.ground_indices(s)).tobytes(), np.sort(h.nonground_indices(s)).tobytes()))  # (the lists' order is the scatter's)
         seen.append(trace)
         h.close()
-    assert seen[0] == seen[1]
+    assert seen[0] == seen[1] and seen[0] == seen[2]
     # ... and a stream that starts from nothing follows the oracle through the split kernel (its first frames take their statistics from
     # the histories read back, not from the LDS copy of a frame that starts from empty histories)
     h = pwpp_hip.Handle()
