@@ -364,6 +364,9 @@ PWPP_API int pwpp_pipe_destroy(pwpp_pipe *pipe);
  *                         in the reference's order) run on the handle's second stream, under K6 and the host's turn-around: one stream in steady
  *                         state 108 -> 100 us per frame.  "2": the second launch starts only when the lists are written (not beside K6): the
  *                         lists another ~4 us earlier, the state ~15 us later (pwpp_synchronize waits for both).  "0": one kernel
+ *   "fuse_scan"           "1": fewer than eight frames run the part scan (K2) inside the binning kernel -- the workgroup that takes a frame's
+ *                         last ticket scans (rounds 4-5's default).  "0" (default): a kernel of its own -- 1-2 us faster per frame since the
+ *                         ticket is an agent-scope acquire-release
  *   "fit_plan"            which fit kernel handles which patch sizes, e.g. "W16:1023,W64.2:65535"; "" = automatic
  *   "fit_concurrent"      "1": the classes of a plan side by side on two streams
  *   "one_pass"            "0": always the two-pass binning

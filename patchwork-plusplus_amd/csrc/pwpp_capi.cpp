@@ -114,6 +114,7 @@ struct pwpp_handle {
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     bool k5_tail_unjoined = false;  // the last call left K5's second part on aux_stream (aux_join recorded behind it): the main stream has not waited for it yet
     bool k5_tail_unsynced = false;  // ... and neither has the host
+    int fuse_scan = 0;              // option "fuse_scan": K2 inside K1' for fewer than eight frames (rounds 4-5's default)
     int split_k5 = 1;               // option "split_k5": a few stateful streams run K5 in two launches (k_gle_tgr PART 1 / 2)
     bool overlap = true;   // pwpp_set_overlap: big batches as a pipeline of frame ranges over the two streams (default on)
     int overlap_ranges = 2;  // (more ranges were slower at every setting tried: each range's fit kernels end with the tail of their
@@ -713,6 +714,7 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     const bool split_k5 = h->split_k5 != 0 && h->mode == PWPP_MODE_STREAMS && frames <= 64 && !h->profiling && bt.debug == 0 &&
                           h->output_order != PWPP_ORDER_REFERENCE && h->dp.min_pts != 0;
     bt.k5_split = split_k5 ? h->split_k5 : 0;
+    bt.fuse_scan = h->fuse_scan;
     bt.cap_off = one_pass ? h->d_cap_off.p : nullptr;
     if (one_pass) {
         bt.arena_base = h->arena_base;
@@ -1937,6 +1939,8 @@ int pwpp_set_option(pwpp_handle *h, const char *name, const char *value) {
         std::vector<float2> origin;
         h->dp.fxp_wide = v;
         h->dp.fxp_zr = (float)fxp_geometry(h->dp, origin, h->dp.fxp_shift, v != 0);
+    } else if (k == "fuse_scan") {
+        h->fuse_scan = std::atoi(value) != 0;
     } else if (k == "split_k5") {
         const int v = std::atoi(value);
         if (v < 0 || v > 2) return fail(PWPP_E_ARG, "split_k5=%s: 0, 1 or 2 expected", value);

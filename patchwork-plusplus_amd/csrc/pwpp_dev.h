@@ -198,6 +198,7 @@ struct PwppBatch {
     float *normals;              // [frames][B][3]
     PwppFrameResult *results;    // [frames]
     PwppFrameResult *results_host;  // [frames] pinned host mirror, written by K6 (no D2H copy command behind the pipeline)
+    int fuse_scan;               // a few frames: K2 inside K1' (the last workgroup of a frame to take a ticket scans) instead of a kernel of its own
     int k5_split;                // K5 in two launches (k_gle_tgr PART 1 / 2): the second on the handle's other stream, joined by the host before the next call
     unsigned long long *dbg;     // [64] timing probes, only written when debug & 4
     // host side only (the kernels never read these)

@@ -2657,7 +2657,11 @@ extern "C" int pwpp_launch_pipeline(const PwppBatch *batch, hipStream_t stream, 
             const bool spread = F < 8;  // (see the kernel: a few frames are dealt over all XCDs)
             const dim3 grid(gx1 * (unsigned)(spread ? F : (F + 7) / 8 * 8));
             const int tpf = spread ? -(int)gx1 : (int)gx1;
-            const bool fused = spread && gx1 > 0 && bb == kBlock && !(B.debug & 256);  // K2 inside K1' (debug 256: as two kernels; 128 is taken by K5's statistics)
+            // K2 inside K1' (option fuse_scan; debug 256 selects the OTHER variant; 128 is taken by K5's statistics).  Rounds 4-5: the default for
+            // a few frames -- no kernel boundary in a single frame's chain.  Round 6: off -- since the ticket that elects the scanning
+            // workgroup is an agent-scope acquire-release it costs what the boundary cost (the L2 write-back of a release:
+            // ~3 us), and the two kernels are 1-2 us FASTER on every KITTI sample.
+            const bool fused = spread && gx1 > 0 && bb == kBlock && ((B.fuse_scan != 0) != ((B.debug & 256) != 0));
             if (fused) {
                 const dim3 fgrid(gx1 * (unsigned)F + (B.snap_scalar ? 8u * (unsigned)F : 0u));
                 hipLaunchKernelGGL((k_czm_bin_scatter<kBlock, true>), fgrid, dim3(kBlock), binning_lds_bytes(B, 2), stream, B, tpf);

@@ -1168,8 +1168,8 @@ def test_error_reporting_on_the_device(kitti):
 
 def test_schedules_and_binning_variants_give_one_result(kitti, oracle):
     """The same 136-frame batch through every schedule the library has -- one stream, the in-handle overlap schedule, that schedule
-    on CU-partitioned streams (option cu_split, round 5's experiment), four frame ranges, the scan as a kernel of its own for a
-    single frame (debug 256; by default K2 runs inside K1' for fewer than eight frames) -- and two handles with a batch each in
+    on CU-partitioned streams (option cu_split, round 5's experiment), four frame ranges, the scan inside the binning kernel for a
+    single frame (debug 256, or option fuse_scan: rounds 4-5's default for fewer than eight frames) -- and two handles with a batch each in
     flight: identical counts everywhere, spot frames identical to the oracle."""
     refs = [ol.Estimator(oracle, arith=ol.ARITH_FXP).run(k) for k in kitti]
     F = 136
@@ -1227,6 +1227,10 @@ def test_schedules_and_binning_variants_give_one_result(kitti, oracle):
         for k in (2, 5):
             one.estimate_ground_batch([kitti[k]], mode=pwpp_hip.MODE_FRESH)
             assert_frame_equal(one, 0, refs[k], kitti[k].shape[0])
+    one.set_option("fuse_scan", 1)
+    for k in (1, 4):
+        one.estimate_ground_batch([kitti[k]], mode=pwpp_hip.MODE_FRESH)
+        assert_frame_equal(one, 0, refs[k], kitti[k].shape[0])
 
 
 def test_cpp_class_with_eigen_types(kitti, golden, tmp_path):
