@@ -1,9 +1,9 @@
 """The stateful form of tools/hip_vs_reference.py: S long-lived sensors (streams) over L frames each -- stream s sees
-pwpp_synth.varied_frame(500000 + 1000 s + t) at step t -- through ONE long-lived object per stream and build of the reference
+pwpp_synth.varied_frame(FIRST + 1000 s + t) at step t -- through ONE long-lived object per stream and build of the reference
 (oracle/_ref: three builds, forked workers on the host cores) and through libpwpp_hip.so as S streams in lock-step
 (PWPP_MODE_STREAMS).  At every step of every stream: where the three builds agree on the ground set the HIP path must return it, where
 they split it must equal one of them; the sensor heights are compared at the end.
-   run on the GPU box:  python tools/hip_vs_reference_streams.py [S] [L]"""
+   run on the GPU box:  python tools/hip_vs_reference_streams.py [S] [L] [FIRST = 500000]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ('tests', 'patchwork-plusplus_amd/python'):
@@ -15,6 +15,7 @@ import pwpp_synth
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+FIRST = int(sys.argv[3]) if len(sys.argv) > 3 else 500000
 FLAV = (("eigen_f32", ol.ARITH_EIGEN_F32), ("f32_packet4", ol.ARITH_F32_PACKET4), ("exact_f64", ol.ARITH_EXACT_F64))
 
 
@@ -22,7 +23,7 @@ def stream_job(s):
     est = [ol.Estimator(ol.reference(a), arith=a) for _, a in FLAV]
     rows = []
     for t in range(L):
-        pts = pwpp_synth.varied_frame(500000 + 1000 * s + t)
+        pts = pwpp_synth.varied_frame(FIRST + 1000 * s + t)
         rows.append([np.sort(e.run(pts).ground_idx) for e in est])
     return rows, [float(e._l.lib.pwo_get_height(e._h)) for e in est]
 
@@ -38,7 +39,7 @@ if __name__ == "__main__":
     h.set_num_streams(S)
     unanimous = equal_unanimous = split = equal_some = 0
     for t in range(L):
-        h.estimate_ground_batch([pwpp_synth.varied_frame(500000 + 1000 * s + t) for s in range(S)], mode=pwpp_hip.MODE_STREAMS)
+        h.estimate_ground_batch([pwpp_synth.varied_frame(FIRST + 1000 * s + t) for s in range(S)], mode=pwpp_hip.MODE_STREAMS)
         for s in range(S):
             g = np.sort(h.ground_indices(s))
             sets = ref[s][0][t]
