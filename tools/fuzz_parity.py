@@ -143,6 +143,9 @@ def one_case(seed, oracle):
     if rng.random() < 0.17:
         h.set_option("exact_moments", 0)
         ARITH = ol.ARITH_FXP21
+    rng2 = np.random.default_rng(seed + 10 ** 9)  # (a generator of its own: the cases of earlier records stay what they were)
+    h.set_option("split_k5", int(rng2.choice([1, 1, 0, 2])))   # K5 of a few stateful streams in one launch / two / the second behind the lists
+    h.set_option("fuse_scan", int(rng2.random() < 0.3))        # the part scan of a few frames inside the binning kernel
     ordered = rng.random() < 0.2   # the reference's own order inside the lists (ties among equal heights aside)
     h.set_output_order(ordered)
     fortran = rng.random() < 0.2   # column-major matrices (Eigen's storage)
