@@ -1346,8 +1346,7 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         if ((Bt.debug & 8) && blockIdx.x == 0 && threadIdx.x == 0 && probe_i < 60) Bt.dbg[probe_i++] = wall_clock64();
     };
     probe();
-    if constexpr (PART != 2) clear_next_counters(Bt, blockIdx.x, kBlock);
-    probe();
+    probe();  // (slot 1 of the chain: the next call's counters used to be cleared here, in front of the first loads; now behind them)
     __shared__ uint8_t s_dec[PWPP_MAX_BINS];
     __shared__ __attribute__((aligned(16))) unsigned s_e[4][PWPP_MAX_BINS + 1];   // exclusive prefixes: gmain, gtail, nmain, ntail;
                                                                                 // later the staging tile of the histories
@@ -1436,6 +1435,14 @@ __global__ __launch_bounds__(kBlock) void k_gle_tgr(PwppBatch Bt) {
         const bool have = j < per && bin < B;
         nn[j] = have ? cnt[bin] : 0u;
         rr[j] = recs[have ? bin : 0];
+    }
+    // the next call's counters (clear_next_counters): stores that nothing of this kernel waits for, issued while the loads above are on
+    // their way -- in front of them they held the records back by the microsecond it takes to issue them
+    clear_next_counters(Bt, blockIdx.x, kBlock);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int bin = b0 + j;
+        const bool have = j < per && bin < B;
         if (have && nn[j] > 0u && (uint64_t)nn[j] >= P.min_pts && rr[j].valid == 4) awaits = 1;
     }
     if (__syncthreads_or(awaits && !Bt.fixup_run)) {  // a patch awaits k_fit_fixup: hands off (workgroup-uniform)
