@@ -730,7 +730,9 @@ __global__ __launch_bounds__(BLOCK, FUSE ? 2 : 8) void k_czm_bin_scatter(PwppBat
                     sorted_z[seg + r] = pz[j];
                     sorted_xy[seg + r] = make_float2(px[j], py[j]);
                 }
+#ifndef PWPP_ABLATE_NO_IDX_STORE  // (timing experiment only: the step without a quarter of K1's stores -- how much of it is bytes?)
                 sorted_idx[seg + r] = first + j * kBlock + (int)threadIdx.x;
+#endif
             } else {
                 over = true;
                 over_mask |= 1u << j;
