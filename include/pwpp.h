@@ -214,7 +214,8 @@ PWPP_API double pwpp_get_height(pwpp_handle *h);
 /* getTimeTaken(), reference patchworkpp.h:155: microseconds of the last estimate call
  * (GPU time between HIP events on the handle's stream, batch calls: whole batch: first kernel -> index lists written.  With up to 64
  * stateful streams the update of the streams' adaptive thresholds -- K5's second launch, option "split_k5" -- runs on the handle's second
- * stream and ends ~8 us after the lists; every call that reads results or state, and the next estimate call, waits for it) */
+ * stream and ends ~8 us after the lists; the next estimate call and every call that touches a stream's state wait for it, pwpp_synchronize
+ * and the getters of a call's results -- counts, lists, patch rows -- do not) */
 PWPP_API double pwpp_get_time_us(pwpp_handle *h);
 
 /* ---- adaptive state --------------------------------------------------------------------- */
@@ -363,7 +364,7 @@ PWPP_API int pwpp_pipe_destroy(pwpp_pipe *pipe);
  *                         wait for the first only; the statistics over the streams' A-GLE histories (two chains of ~1000 dependent f64 adds
  *                         in the reference's order) run on the handle's second stream, under K6 and the host's turn-around: one stream in steady
  *                         state 108 -> 100 us per frame.  "2": the second launch starts only when the lists are written (not beside K6): the
- *                         lists another ~4 us earlier, the state ~15 us later (pwpp_synchronize waits for both).  "0": one kernel
+ *                         lists another ~4-5 us earlier, the state ~15 us later (a caller that steps the stream again at once waits for it there).  "0": one kernel
  *   "fuse_scan"           "1": fewer than eight frames run the part scan (K2) inside the binning kernel -- the workgroup that takes a frame's
  *                         last ticket scans (rounds 4-5's default).  "0" (default): a kernel of its own -- 1-2 us faster per frame since the
  *                         ticket is an agent-scope acquire-release

@@ -114,6 +114,7 @@ struct pwpp_handle {
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     bool k5_tail_unjoined = false;  // the last call left K5's second part on aux_stream (aux_join recorded behind it): the main stream has not waited for it yet
     bool k5_tail_unsynced = false;  // ... and neither has the host
+    bool hist_check_due = false;    // the fill of the streams' histories after the last call has not been looked at yet (settle_k5_tail)
     int fuse_scan = 0;              // option "fuse_scan": K2 inside K1' for fewer than eight frames (rounds 4-5's default)
     int split_k5 = 1;               // option "split_k5": a few stateful streams run K5 in two launches (k_gle_tgr PART 1 / 2)
     bool overlap = true;   // pwpp_set_overlap: big batches as a pipeline of frame ranges over the two streams (default on)
@@ -389,7 +390,7 @@ void fill_default_state(const pwpp_handle *h, PwppStateScalar &s) {
     }
 }
 
-int finish_pending(pwpp_handle *h);
+int finish_pending(pwpp_handle *h, bool lists_only = false);
 extern "C" const char *pwpp_big_batch_plan(int max_n, int num_bins, int wide);  // pwpp_fit.hip
 
 // every stream a schedule may have put work on (error paths, pwpp_destroy): the main stream alone is not the join of a
@@ -875,10 +876,42 @@ int launch_prepared(pwpp_handle *h, bool one_pass) {
     return PWPP_OK;
 }
 
-int finish_pending(pwpp_handle *h) {
-    if (!h->pending) return PWPP_OK;
-    HIPCHK(hipStreamSynchronize(h->stream));
+// What K5's second launch (split_k5) leaves behind the index lists: the streams' state, and how full their histories are.
+int settle_k5_tail(pwpp_handle *h) {
     if (h->k5_tail_unsynced) {  // (the streams' state and results[].hist_state are complete once K5's second part has run)
+        HIPCHK(hipStreamSynchronize(h->aux_stream));
+        h->k5_tail_unsynced = false;
+    }
+    if (h->hist_check_due) {
+        h->hist_check_due = false;
+        // The reference's history vectors are unbounded (update_flatness_thr stops trimming the higher rings while a
+        // lower one holds <= 1 entries, patchworkpp.cpp:363-364).  The slabs grow before a call could fill them.
+        int fill = 0;
+        bool dropped = false;
+        for (int f = 0; f < h->frames; ++f) {
+            const int hs = h->h_results.p[f].hist_state;
+            fill = (hs >> 1) > fill ? (hs >> 1) : fill;
+            dropped = dropped || (hs & 1);
+        }
+        if (dropped) return fail(PWPP_E_STATE, "an A-GLE history outgrew its slab (%d entries): the adaptive thresholds of this stream are no longer the reference's", h->stream_hist_cap);
+        if (fill + h->max_pushes_per_frame + 8 > h->stream_hist_cap) {
+            const int rc = grow_stream_histories(h, 2 * h->stream_hist_cap);
+            if (rc) return rc;
+        }
+    }
+    return PWPP_OK;
+}
+
+// lists_only (pwpp_synchronize, the getters of a call's results, pwpp_get_time_us): the caller wants what the main stream delivers -- counts,
+// index lists, patch rows.  K5's second launch may then stay on its stream (the next estimate call and everything that touches a stream's
+// state settle it first), unless a frame of the call needs the host: a redo or a fix-up restores / continues the streams' state.
+int finish_pending(pwpp_handle *h, bool lists_only) {
+    if (!h->pending) return lists_only ? PWPP_OK : settle_k5_tail(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    bool defer_tail = lists_only && h->k5_tail_unsynced;
+    for (int f = 0; f < h->frames && defer_tail; ++f)
+        if (h->h_results.p[f].overflow & 3) defer_tail = false;
+    if (h->k5_tail_unsynced && !defer_tail) {
         HIPCHK(hipStreamSynchronize(h->aux_stream));
         h->k5_tail_unsynced = false;
     }
@@ -1025,30 +1058,15 @@ int finish_pending(pwpp_handle *h) {
         for (size_t b = 0; b < h->cap_table.size() && !h->table_stale; ++b)
             if (h->observed[b] > (b < h->cap_seen.size() ? h->cap_seen[b] : 0u) && h->cap_table[b] > 0u) h->table_stale = true;
     }
-    if (h->mode == PWPP_MODE_STREAMS) {
-        // The reference's history vectors are unbounded (update_flatness_thr stops trimming the higher rings while a
-        // lower one holds <= 1 entries, patchworkpp.cpp:363-364).  The slabs grow before a call could fill them.
-        int fill = 0;
-        bool dropped = false;
-        for (int f = 0; f < h->frames; ++f) {
-            const int hs = h->h_results.p[f].hist_state;
-            fill = (hs >> 1) > fill ? (hs >> 1) : fill;
-            dropped = dropped || (hs & 1);
-        }
-        if (dropped) return fail(PWPP_E_STATE, "an A-GLE history outgrew its slab (%d entries): the adaptive thresholds of this stream are no longer the reference's", h->stream_hist_cap);
-        if (fill + h->max_pushes_per_frame + 8 > h->stream_hist_cap) {
-            const int rc = grow_stream_histories(h, 2 * h->stream_hist_cap);
-            if (rc) return rc;
-        }
-    }
-    return PWPP_OK;
+    if (h->mode == PWPP_MODE_STREAMS) h->hist_check_due = true;
+    return defer_tail ? PWPP_OK : settle_k5_tail(h);
 }
 
 int check_frame(pwpp_handle *h, int frame) {
     if (!h) return fail(PWPP_E_ARG, "null handle");
     int rc = use_device(h);
     if (rc) return rc;
-    rc = finish_pending(h);
+    rc = finish_pending(h, true);  // (a call's results: counts, lists, patch rows)
     if (rc) return rc;
     if (!h->have_results) return fail(PWPP_E_STATE, "no frame has been processed yet");
     if (frame < 0 || frame >= h->frames) return fail(PWPP_E_ARG, "frame %d out of range [0,%d)", frame, h->frames);
@@ -1535,7 +1553,7 @@ int pwpp_synchronize(pwpp_handle *h) {
     if (!h) return fail(PWPP_E_ARG, "null handle");
     int rc = use_device(h);
     if (rc) return rc;
-    return finish_pending(h);
+    return finish_pending(h, true);  // (the call's results; a stream's state is settled by whoever touches it: settle_k5_tail)
 }
 
 int pwpp_get_counts(pwpp_handle *h, int frame, int32_t *n_ground, int32_t *n_nonground, int32_t *n_patches) {
@@ -1640,7 +1658,7 @@ double pwpp_get_height(pwpp_handle *h) {
 
 double pwpp_get_time_us(pwpp_handle *h) {
     if (!h) return 0.0;
-    if (use_device(h) || finish_pending(h)) return 0.0;
+    if (use_device(h) || finish_pending(h, true)) return 0.0;
     return h->time_us;
 }
 
